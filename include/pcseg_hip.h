@@ -1,0 +1,200 @@
+/*
+ * pcseg_hip.h -- C ABI of libpcseg_hip.so, the MI355X (gfx950) sparse-voxel hot path.
+ *
+ * This is the drop-in boundary ("B-B" in SURVEY.md section 8b): every entry point below
+ * replaces one function of the reference's native module `torchsparse.backend`
+ * (TS = /root/reference/package/torchsparse.zip, member prefix torchsparse/), i.e. what the
+ * reference's pybind table TS:torchsparse/backend/pybind_cuda.cpp:18-39 binds, plus the
+ * rulebook construction that the reference does in Python on top of those functions
+ * (TS:torchsparse/nn/functional/conv.py:156-176, downsample.py:11-52).
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers + sizes, no torch types, no allocation inside the library.
+ *     Scratch memory is caller-provided ("ws"); its size comes from the matching *_ws_bytes().
+ *   - every launch goes to the hipStream_t passed as `stream` (void* here so that plain C
+ *     callers need no HIP headers). Nothing synchronises the device or the host.
+ *   - return value: PCS_OK (0) or a negative PCS_E* code; pcs_last_error() gives the text.
+ *   - all tensors are dense row-major; "coords" rows are int32 [x, y, z, batch]
+ *     (TS:torchsparse/tensor.py:10-21).
+ *   - dtype suffix _f32 = IEEE fp32 storage and fp32 MFMA / FMA arithmetic.
+ */
+#ifndef PCSEG_HIP_H_
+#define PCSEG_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCS_OK 0
+#define PCS_EINVAL (-1)   /* bad argument (shape / alignment / null pointer)            */
+#define PCS_EWORKSPACE (-2) /* caller workspace too small                                */
+#define PCS_ELAUNCH (-3)  /* hipLaunch / hipMemsetAsync failed (pcs_last_error has text) */
+#define PCS_EUNSUPPORTED (-4)
+
+#define PCS_ABI_VERSION 1
+
+int pcs_abi_version(void);
+const char *pcs_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  hash_cuda          TS:torchsparse/backend/hash/hash_cuda.cu:10-23,67-73
+ * 64-bit FNV-1a over the four uint32 words of a coord row, folded to 60 bits. Bit-exact.
+ * coords (n,4) int32 -> out (n,) int64
+ */
+int pcs_hash(const int32_t *coords, int64_t n, int64_t *out, void *stream);
+
+/* K2  kernel_hash_cuda   TS:torchsparse/backend/hash/hash_cuda.cu:27-55,75-84
+ * hash of (coords[:, :3] + offsets[k], coords[:, 3]) for every kernel offset.
+ * coords (n,4) int32, offsets (K,3) int32 -> out (K,n) int64, k-major. Bit-exact.
+ */
+int pcs_kernel_hash(const int32_t *coords, int64_t n, const int32_t *offsets, int32_t K,
+                    int64_t *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3-K5  hash_query_cuda  TS:torchsparse/backend/others/query_cuda.cu:9-56
+ *                         TS:torchsparse/backend/hashmap/hashmap_cuda.cu:8-127
+ * The reference builds a 3-function cuckoo table with a host-driven rehash loop on every
+ * call. Here: ONE open-addressing (linear probe) table of {key:int64, value:int32}, built
+ * by a single kernel with 64-bit CAS, no host round trip. Value = position of the key in
+ * `keys`; with duplicate keys the SMALLEST position wins (the reference's CPU twin keeps the
+ * first insert, TS:torchsparse/backend/others/query_cpu.cpp:22-26).
+ * Table storage is caller-owned: `capacity` slots (power of two, from pcs_hashtable_capacity)
+ * laid out as  uint64 key[capacity] | int32 val[capacity]  (pcs_hashtable_bytes).
+ */
+int64_t pcs_hashtable_capacity(int64_t n);
+size_t pcs_hashtable_bytes(int64_t capacity);
+int pcs_hashtable_build(const int64_t *keys, int64_t n, void *table, int64_t capacity,
+                        void *stream);
+/* out[i] = (position of queries[i] in keys) + 1, or 0 when absent -- the reference's
+ * backend convention (query_cuda.cu / hashmap_cuda.cu:104-127; Python subtracts 1,
+ * TS:torchsparse/nn/functional/query.py:32). */
+int pcs_hashtable_query(const void *table, int64_t capacity, const int64_t *queries,
+                        int64_t n1, int64_t *out, void *stream);
+
+/* K6  count_cuda  TS:torchsparse/backend/others/count_cuda.cu:10-31
+ * out[idx[i]] += 1 for idx[i] >= 0; out (s,) int32 is zeroed inside. */
+int pcs_count(const int32_t *idx, int64_t n, int32_t *out, int64_t s, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7/K8  voxelize_forward_cuda / voxelize_backward_cuda
+ *        TS:torchsparse/backend/voxelize/voxelize_cuda.cu:12-80
+ * fwd: out[idx[i], :] += feats[i, :] / counts[idx[i]]   (divide BEFORE accumulating, as the
+ *      reference does); out (m,c) is zeroed inside; rows with idx[i] < 0 are skipped.
+ * bwd: gin[i, :] = gout[idx[i], :] / counts[idx[i]]      (0 where idx[i] < 0)
+ */
+int pcs_voxelize_fwd_f32(const float *feats, const int32_t *idx, const int32_t *counts,
+                         int64_t n, int64_t m, int32_t c, float *out, void *stream);
+int pcs_voxelize_bwd_f32(const float *gout, const int32_t *idx, const int32_t *counts,
+                         int64_t n, int32_t c, float *gin, void *stream);
+
+/* K9/K10  devoxelize_forward_cuda / devoxelize_backward_cuda
+ *         TS:torchsparse/backend/devoxelize/devoxelize_cuda.cu:11-98
+ * fwd: out[i,:] = sum_{k<8} w[i,k] * feat[idx[i,k],:]  (idx -1 => 0), accumulated in
+ *      registers in k = 0..7 order and written once.
+ * bwd: gfeat[idx[i,k],:] += w[i,k] * gout[i,:]; gfeat (m,c) is zeroed inside.
+ * idx (n,8) int32, w (n,8) fp32.
+ */
+int pcs_devoxelize_fwd_f32(const float *feat, const int32_t *idx8, const float *w8, int64_t n,
+                           int32_t c, float *out, void *stream);
+int pcs_devoxelize_bwd_f32(const float *gout, const int32_t *idx8, const float *w8, int64_t n,
+                           int64_t m, int32_t c, float *gfeat, void *stream);
+
+/* calc_ti_weights  TS:torchsparse/nn/functional/devoxelize.py:10-48  (about 25 small torch
+ * kernels in the reference, one kernel here). coords (n, coord_ld) fp32 (first 3 columns
+ * used), idx_query (8,n) int64 (-1 = miss), -> w (8,n) fp32: trilinear corner weights in
+ * get_kernel_offsets(2) order, /scale^3 when scale != 1, zeroed at misses, renormalised by
+ * (sum + 1e-8). */
+int pcs_ti_weights_f32(const float *coords, int32_t coord_ld, const int64_t *idx_query,
+                       int64_t n, float scale, float *w, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * spdownsample  TS:torchsparse/nn/functional/downsample.py:11-52
+ * Step 1 (this call): candidate output coordinates as packed sortable 64-bit keys
+ *   key = (batch << 54) | ((x + 2^17) << 36) | ((y + 2^17) << 18) | (z + 2^17)
+ * whose ascending order equals the reference's lexicographic order over [b, x, y, z]
+ * (downsample.py:49-51). mode 0 = fast branch (downsample.py:25-28): one key per input row,
+ * coordinate truncated toward zero to a multiple of sample_stride[d]. mode 1 = general
+ * branch (downsample.py:29-45): n*K keys for coords+offsets[k]; rows that fail
+ * `% sample_stride == 0` or `>= coords_min` get the key INT64_MAX (sorts last).
+ * Step 2: the caller sorts/uniques the keys. Step 3: pcs_downsample_unpack.
+ * *err (device int32, caller-zeroed) is set to 1 if a coordinate does not fit the packing
+ * (|x|,|y|,|z| >= 2^17 or batch outside [0, 511]).
+ * sample_stride3 is a HOST pointer (three small positive ints); offsets / coords_min3 are
+ * device pointers.
+ */
+int pcs_downsample_pack(const int32_t *coords, int64_t n, const int32_t *sample_stride3,
+                        int32_t mode, const int32_t *offsets, int32_t K,
+                        const int32_t *coords_min3, int64_t *keys, int32_t *err, void *stream);
+int pcs_downsample_unpack(const int64_t *keys, int64_t m, int32_t *coords, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Rulebook (kernel map)  TS:torchsparse/nn/functional/conv.py:156-176
+ * For every kernel offset k and every query row j (ascending): look up
+ * hash(qcoords[j,:3] + offsets[k], qcoords[j,3]) in the table built over hash(ref coords).
+ * The reference materialises a (K,N) int64 hash matrix, a (K,N) int64 result matrix, then
+ * sum + nonzero. Here the hash is computed in registers and probed immediately:
+ *   pass 1  pcs_rulebook_probe : results (K,nq) int32 (ref row or -1) + per-k hit counts
+ *   pass 2  pcs_rulebook_fill  : pairs (P,2) int32 = (ref_row, query_row), ordered k-major
+ *           then query_row ascending -- exactly the reference's nbmaps order
+ *           (conv.py:169-172) -- and koff (K+1) int32 prefix offsets of each k's slice.
+ * The same two calls with (query = input coords, ref = output coords, negated offsets)
+ * give the input-sorted map used by dgrad / transposed convs.
+ * nbsizes (K,) int64 mirrors the reference's `nbsizes` (conv.py:168).
+ */
+size_t pcs_rulebook_ws_bytes(int64_t nq, int32_t K);
+int pcs_rulebook_probe(const int32_t *qcoords, int64_t nq, const int32_t *offsets, int32_t K,
+                       const void *table, int64_t capacity, int32_t *results,
+                       int64_t *nbsizes, void *ws, size_t ws_bytes, void *stream);
+int pcs_rulebook_fill(const int32_t *results, int64_t nq, int32_t K, const void *ws,
+                      int32_t *pairs, int32_t *koff, void *stream);
+/* Per (k, tile) segment table for the output-stationary convolution: for tile t of
+ * `tile_rows` consecutive destination rows, seg[k*(ntiles+1)+t] is the first pair of offset
+ * k (absolute index into pairs) whose destination row >= t*tile_rows.
+ * dst_col selects the column of `pairs` that holds the destination row (must be the sorted
+ * one, i.e. 1 for maps produced by pcs_rulebook_fill). */
+int pcs_rulebook_tile_segments(const int32_t *pairs, const int32_t *koff, int32_t K,
+                               int64_t n_dst, int32_t tile_rows, int32_t dst_col,
+                               int32_t *seg, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * F1  convolution_forward_cuda   TS:torchsparse/backend/convolution/convolution_cuda.cu:53-165
+ * F2  convolution_backward_cuda  TS:torchsparse/backend/convolution/convolution_cuda.cu:167-278
+ * (gather_kernel :14-24, scatter_kernel :27-37, torch::mm_out per offset :149, :259-263)
+ *
+ * pcs_conv_gather_gemm_f32: output-stationary fused gather-GEMM-accumulate
+ *      dst[d, :] = sum over pairs (s, d) of offset k:  src[s, :] @ W[k]      (+ bias)
+ * One workgroup owns `tile_rows` consecutive dst rows x a column tile, walks the kernel
+ * offsets, gathers the needed src rows into LDS, contracts with W[k] on the fp32 MFMA pipe
+ * and accumulates in LDS; every dst row is written exactly once (no atomics, no zero fill
+ * needed, deterministic). Used for forward (src = input feats), for dgrad (src = grad_out,
+ * W = per-offset transposed weights, input-sorted map) and for transposed convolutions.
+ *   src (n_src, cin), W (K, cin, cout), dst (n_dst, cout); pairs (P,2) with the src row in
+ *   column src_col and the dst row in column 1-src_col, sorted k-major / dst ascending;
+ *   seg from pcs_rulebook_tile_segments with the same tile_rows; bias (cout) or NULL.
+ * pcs_conv_tile_rows returns the tile height this library uses for (cin, cout).
+ */
+int32_t pcs_conv_tile_rows(int32_t cin, int32_t cout);
+int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t cin, const float *W,
+                             int32_t K, int32_t cout, const int32_t *pairs, int32_t src_col,
+                             const int32_t *seg, int32_t tile_rows, int64_t n_dst,
+                             const float *bias, float *dst, void *stream);
+
+/* wgrad:  gW[k] = sum over pairs (a, b) of offset k:  fa[a, :]^T (outer) fb[b, :]
+ *   fa (na, ca) rows indexed by pairs column a_col, fb (nb, cb) by the other column;
+ *   gW (K, ca, cb). Deterministic two-pass split reduction; ws from pcs_conv_wgrad_ws_bytes.
+ *   koff_dev / koff_host: the K+1 prefix offsets of each offset's slice of `pairs`, on the
+ *   device (read by the kernels) and on the HOST (the caller has them from the rulebook
+ *   build; they size the launch and the workspace). */
+size_t pcs_conv_wgrad_ws_bytes(const int32_t *koff_host, int32_t K, int32_t ca, int32_t cb);
+int pcs_conv_wgrad_f32(const float *fa, int32_t ca, const float *fb, int32_t cb,
+                       const int32_t *pairs, int32_t a_col, const int32_t *koff_dev,
+                       const int32_t *koff_host, int32_t K, float *gW, void *ws,
+                       size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCSEG_HIP_H_ */

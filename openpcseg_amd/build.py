@@ -1,0 +1,60 @@
+"""Compile openpcseg_amd/csrc/*.hip into openpcseg_amd/lib/libpcseg_hip.so for gfx950.
+
+hipcc cross-compiles without a GPU. The library has no torch dependency: it is the C ABI of
+include/pcseg_hip.h and links only the HIP runtime.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libpcseg_hip.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fPIC",
+         "-Wno-unused-value"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [
+        os.path.join(HERE, "..", "include", "pcseg_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Build the shared library if it is missing or older than its sources."""
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    objs = []
+    procs = []
+    for s in sources():
+        o = os.path.join(LIB_DIR, os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (s, out.decode()))
+        if verbose and out:
+            print(out.decode())
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,282 @@
+// K7-K10 point<->voxel kernels + calc_ti_weights -- gfx950, fp32.
+// Reference semantics: TS:torchsparse/backend/voxelize/voxelize_cuda.cu:12-80,
+// TS:torchsparse/backend/devoxelize/devoxelize_cuda.cu:11-98,
+// TS:torchsparse/nn/functional/devoxelize.py:10-48.
+// All HBM-bound. The reference launches <<<N, c>>> (c-thread blocks: 4 threads for c = 4) and
+// accumulates the 8 trilinear corners through global memory; here a 256-thread workgroup
+// covers 256/TX rows with TX lanes x 16 bytes per row, the corner sum lives in registers and
+// every output row is written once.
+#include "pcs_common.h"
+
+using namespace pcs;
+
+namespace {
+
+// Row-tiled 2-D launch: TX lanes walk the (vectorised) channels of one row, TY rows per block.
+struct RowLaunch {
+  dim3 block, grid;
+  int cv;  // vectors per row
+};
+
+template <int V>
+RowLaunch row_launch(int64_t n, int c) {
+  RowLaunch r;
+  r.cv = c / V;
+  int tx = 1;
+  while (tx < r.cv && tx < 64) tx <<= 1;
+  int ty = 256 / tx;
+  r.block = dim3(tx, ty);
+  int64_t g = ceil_div(n, ty);
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  r.grid = dim3((unsigned)g);
+  return r;
+}
+
+template <int V> struct Vec;
+template <> struct Vec<4> { using T = float4; };
+template <> struct Vec<1> { using T = float; };
+
+__device__ __forceinline__ float4 vscale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float vscale(float a, float s) { return a * s; }
+__device__ __forceinline__ float4 vdiv(float4 a, float s) { return make_float4(a.x / s, a.y / s, a.z / s, a.w / s); }
+__device__ __forceinline__ float vdiv(float a, float s) { return a / s; }
+__device__ __forceinline__ float4 vfma(float w, float4 f, float4 a) {
+  return make_float4(fmaf(w, f.x, a.x), fmaf(w, f.y, a.y), fmaf(w, f.z, a.z), fmaf(w, f.w, a.w));
+}
+__device__ __forceinline__ float vfma(float w, float f, float a) { return fmaf(w, f, a); }
+__device__ __forceinline__ void vatomic_add(float *p, float4 v) {
+  atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+__device__ __forceinline__ void vatomic_add(float *p, float v) { atomicAdd(p, v); }
+__device__ __forceinline__ void vzero(float4 &v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void vzero(float &v) { v = 0.f; }
+
+// ---- K7: scatter-mean -----------------------------------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(256) voxelize_fwd_kernel(const float *__restrict__ feats,
+                                                           const int32_t *__restrict__ idx,
+                                                           const int32_t *__restrict__ counts,
+                                                           int64_t n, int64_t m, int c, int cv,
+                                                           float *out) {
+  using VT = typename Vec<V>::T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; i < n;
+       i += (int64_t)gridDim.x * blockDim.y) {
+    const int32_t pos = idx[i];
+    if (pos < 0 || pos >= m) continue;
+    const int32_t cnt = counts[pos];
+    if (cnt == 0) continue;
+    const float fc = (float)cnt;
+    const VT *src = reinterpret_cast<const VT *>(feats + i * c);
+    float *dst = out + (int64_t)pos * c;
+    for (int j = threadIdx.x; j < cv; j += blockDim.x) vatomic_add(dst + j * V, vdiv(src[j], fc));
+  }
+}
+
+// ---- K8: gather back / count ------------------------------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(256) voxelize_bwd_kernel(const float *__restrict__ gout,
+                                                           const int32_t *__restrict__ idx,
+                                                           const int32_t *__restrict__ counts,
+                                                           int64_t n, int c, int cv,
+                                                           float *__restrict__ gin) {
+  using VT = typename Vec<V>::T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; i < n;
+       i += (int64_t)gridDim.x * blockDim.y) {
+    const int32_t pos = idx[i];
+    VT *dst = reinterpret_cast<VT *>(gin + i * c);
+    int32_t cnt = pos >= 0 ? counts[pos] : 0;
+    if (cnt == 0) {
+      VT z; vzero(z);
+      for (int j = threadIdx.x; j < cv; j += blockDim.x) dst[j] = z;
+      continue;
+    }
+    const float fc = (float)cnt;
+    const VT *src = reinterpret_cast<const VT *>(gout + (int64_t)pos * c);
+    for (int j = threadIdx.x; j < cv; j += blockDim.x) dst[j] = vdiv(src[j], fc);
+  }
+}
+
+// ---- K9: trilinear gather ---------------------------------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(256) devoxelize_fwd_kernel(const float *__restrict__ feat,
+                                                             const int32_t *__restrict__ idx8,
+                                                             const float *__restrict__ w8,
+                                                             int64_t n, int c, int cv,
+                                                             float *__restrict__ out) {
+  using VT = typename Vec<V>::T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; i < n;
+       i += (int64_t)gridDim.x * blockDim.y) {
+    int32_t id[8];
+    float w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { id[k] = idx8[i * 8 + k]; w[k] = w8[i * 8 + k]; }
+    VT *dst = reinterpret_cast<VT *>(out + i * c);
+    for (int j = threadIdx.x; j < cv; j += blockDim.x) {
+      VT acc; vzero(acc);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (id[k] >= 0) acc = vfma(w[k], reinterpret_cast<const VT *>(feat + (int64_t)id[k] * c)[j], acc);
+      }
+      dst[j] = acc;
+    }
+  }
+}
+
+// ---- K10: trilinear scatter -------------------------------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(256) devoxelize_bwd_kernel(const float *__restrict__ gout,
+                                                             const int32_t *__restrict__ idx8,
+                                                             const float *__restrict__ w8,
+                                                             int64_t n, int c, int cv,
+                                                             float *gfeat) {
+  using VT = typename Vec<V>::T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; i < n;
+       i += (int64_t)gridDim.x * blockDim.y) {
+    int32_t id[8];
+    float w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { id[k] = idx8[i * 8 + k]; w[k] = w8[i * 8 + k]; }
+    const VT *src = reinterpret_cast<const VT *>(gout + i * c);
+    for (int j = threadIdx.x; j < cv; j += blockDim.x) {
+      const VT g = src[j];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (id[k] >= 0) vatomic_add(gfeat + (int64_t)id[k] * c + j * V, vscale(g, w[k]));
+      }
+    }
+  }
+}
+
+// ---- calc_ti_weights ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ti_weights_kernel(const float *__restrict__ coords, int ld,
+                                                         const int64_t *__restrict__ idxq,
+                                                         int64_t n, float scale, float inv_s3,
+                                                         int scaled, float *__restrict__ w) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = coords[i * ld + 0], y = coords[i * ld + 1], z = coords[i * ld + 2];
+    float xf, yf, zf;
+    if (scaled) {
+      xf = floorf(x / scale) * scale; yf = floorf(y / scale) * scale; zf = floorf(z / scale) * scale;
+    } else {
+      xf = floorf(x); yf = floorf(y); zf = floorf(z);
+    }
+    const float xc = xf + scale, yc = yf + scale, zc = zf + scale;
+    const float ax[2] = {xc - x, x - xf}, ay[2] = {yc - y, y - yf}, az[2] = {zc - z, z - zf};
+    float wk[8];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {  // corner order = get_kernel_offsets(2): z fastest
+      float v = (ax[(k >> 2) & 1] * ay[(k >> 1) & 1]) * az[k & 1];
+      if (scaled) v *= inv_s3;
+      if (idxq[(int64_t)k * n + i] == -1) v = 0.f;
+      wk[k] = v;
+      sum += v;
+    }
+    const float den = sum + 1e-8f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[(int64_t)k * n + i] = wk[k] / den;
+  }
+}
+
+}  // namespace
+
+#define PV_DISPATCH(KERNEL, N_ROWS, C, ...)                                                  \
+  do {                                                                                       \
+    if (((C) & 3) == 0) {                                                                    \
+      RowLaunch rl = row_launch<4>((N_ROWS), (C));                                           \
+      hipLaunchKernelGGL(KERNEL<4>, rl.grid, rl.block, 0, st, __VA_ARGS__, rl.cv);           \
+    } else {                                                                                 \
+      RowLaunch rl = row_launch<1>((N_ROWS), (C));                                           \
+      hipLaunchKernelGGL(KERNEL<1>, rl.grid, rl.block, 0, st, __VA_ARGS__, rl.cv);           \
+    }                                                                                        \
+  } while (0)
+
+static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int pcs_voxelize_fwd_f32(const float *feats, const int32_t *idx,
+                                    const int32_t *counts, int64_t n, int64_t m, int32_t c,
+                                    float *out, void *stream) {
+  if (n < 0 || m < 0 || c <= 0) { set_error("pcs_voxelize_fwd: bad sizes"); return PCS_EINVAL; }
+  hipStream_t st = as_stream(stream);
+  if (m > 0) {
+    if (!out) { set_error("pcs_voxelize_fwd: null out"); return PCS_EINVAL; }
+    if (hipMemsetAsync(out, 0, (size_t)m * c * 4, st) != hipSuccess) { set_error("pcs_voxelize_fwd: memset failed"); return PCS_ELAUNCH; }
+  }
+  if (n == 0 || m == 0) return PCS_OK;
+  if (!feats || !idx || !counts) { set_error("pcs_voxelize_fwd: null input"); return PCS_EINVAL; }
+  if ((c & 3) == 0 && aligned16(feats)) {
+    RowLaunch rl = row_launch<4>(n, c);
+    hipLaunchKernelGGL(voxelize_fwd_kernel<4>, rl.grid, rl.block, 0, st, feats, idx, counts, n, m, c, rl.cv, out);
+  } else {
+    RowLaunch rl = row_launch<1>(n, c);
+    hipLaunchKernelGGL(voxelize_fwd_kernel<1>, rl.grid, rl.block, 0, st, feats, idx, counts, n, m, c, rl.cv, out);
+  }
+  return check_launch("pcs_voxelize_fwd");
+}
+
+extern "C" int pcs_voxelize_bwd_f32(const float *gout, const int32_t *idx, const int32_t *counts,
+                                    int64_t n, int32_t c, float *gin, void *stream) {
+  if (n < 0 || c <= 0) { set_error("pcs_voxelize_bwd: bad sizes"); return PCS_EINVAL; }
+  if (n == 0) return PCS_OK;
+  if (!gout || !idx || !counts || !gin) { set_error("pcs_voxelize_bwd: null pointer"); return PCS_EINVAL; }
+  hipStream_t st = as_stream(stream);
+  if ((c & 3) == 0 && aligned16(gout) && aligned16(gin)) {
+    RowLaunch rl = row_launch<4>(n, c);
+    hipLaunchKernelGGL(voxelize_bwd_kernel<4>, rl.grid, rl.block, 0, st, gout, idx, counts, n, c, rl.cv, gin);
+  } else {
+    RowLaunch rl = row_launch<1>(n, c);
+    hipLaunchKernelGGL(voxelize_bwd_kernel<1>, rl.grid, rl.block, 0, st, gout, idx, counts, n, c, rl.cv, gin);
+  }
+  return check_launch("pcs_voxelize_bwd");
+}
+
+extern "C" int pcs_devoxelize_fwd_f32(const float *feat, const int32_t *idx8, const float *w8,
+                                      int64_t n, int32_t c, float *out, void *stream) {
+  if (n < 0 || c <= 0) { set_error("pcs_devoxelize_fwd: bad sizes"); return PCS_EINVAL; }
+  if (n == 0) return PCS_OK;
+  if (!idx8 || !w8 || !out) { set_error("pcs_devoxelize_fwd: null pointer"); return PCS_EINVAL; }
+  hipStream_t st = as_stream(stream);
+  if ((c & 3) == 0 && aligned16(feat) && aligned16(out)) {
+    RowLaunch rl = row_launch<4>(n, c);
+    hipLaunchKernelGGL(devoxelize_fwd_kernel<4>, rl.grid, rl.block, 0, st, feat, idx8, w8, n, c, rl.cv, out);
+  } else {
+    RowLaunch rl = row_launch<1>(n, c);
+    hipLaunchKernelGGL(devoxelize_fwd_kernel<1>, rl.grid, rl.block, 0, st, feat, idx8, w8, n, c, rl.cv, out);
+  }
+  return check_launch("pcs_devoxelize_fwd");
+}
+
+extern "C" int pcs_devoxelize_bwd_f32(const float *gout, const int32_t *idx8, const float *w8,
+                                      int64_t n, int64_t m, int32_t c, float *gfeat,
+                                      void *stream) {
+  if (n < 0 || m < 0 || c <= 0) { set_error("pcs_devoxelize_bwd: bad sizes"); return PCS_EINVAL; }
+  hipStream_t st = as_stream(stream);
+  if (m > 0) {
+    if (!gfeat) { set_error("pcs_devoxelize_bwd: null gfeat"); return PCS_EINVAL; }
+    if (hipMemsetAsync(gfeat, 0, (size_t)m * c * 4, st) != hipSuccess) { set_error("pcs_devoxelize_bwd: memset failed"); return PCS_ELAUNCH; }
+  }
+  if (n == 0 || m == 0) return PCS_OK;
+  if (!gout || !idx8 || !w8) { set_error("pcs_devoxelize_bwd: null pointer"); return PCS_EINVAL; }
+  if ((c & 3) == 0 && aligned16(gout)) {
+    RowLaunch rl = row_launch<4>(n, c);
+    hipLaunchKernelGGL(devoxelize_bwd_kernel<4>, rl.grid, rl.block, 0, st, gout, idx8, w8, n, c, rl.cv, gfeat);
+  } else {
+    RowLaunch rl = row_launch<1>(n, c);
+    hipLaunchKernelGGL(devoxelize_bwd_kernel<1>, rl.grid, rl.block, 0, st, gout, idx8, w8, n, c, rl.cv, gfeat);
+  }
+  return check_launch("pcs_devoxelize_bwd");
+}
+
+extern "C" int pcs_ti_weights_f32(const float *coords, int32_t coord_ld, const int64_t *idx_query,
+                                  int64_t n, float scale, float *w, void *stream) {
+  if (n < 0 || coord_ld < 3) { set_error("pcs_ti_weights: bad sizes"); return PCS_EINVAL; }
+  if (n == 0) return PCS_OK;
+  if (!coords || !idx_query || !w) { set_error("pcs_ti_weights: null pointer"); return PCS_EINVAL; }
+  const int scaled = (scale != 1.0f);
+  const float inv_s3 = 1.0f / (scale * scale * scale);
+  hipLaunchKernelGGL(ti_weights_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream),
+                     coords, coord_ld, idx_query, n, scale, inv_s3, scaled, w);
+  return check_launch("pcs_ti_weights");
+}

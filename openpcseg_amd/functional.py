@@ -1,0 +1,226 @@
+"""Functional operator API of the reference (`torchsparse.nn.functional`), on the HIP backend.
+
+Same names, argument meaning and error behaviour as
+  sphash          TS:torchsparse/nn/functional/hash.py:10-37
+  sphashquery     TS:torchsparse/nn/functional/query.py:8-33
+  spcount         TS:torchsparse/nn/functional/count.py:8-16
+  spvoxelize      TS:torchsparse/nn/functional/voxelize.py:10-56
+  spdevoxelize / calc_ti_weights   TS:torchsparse/nn/functional/devoxelize.py:10-98
+  spdownsample    TS:torchsparse/nn/functional/downsample.py:11-52
+  conv3d          TS:torchsparse/nn/functional/conv.py:16-205
+Internals differ: every op is one or a few C-ABI calls (openpcseg_amd.native); the rulebook is
+built by a fused probe/compaction pass instead of kernel_hash -> hashquery -> sum -> nonzero,
+and the convolution is an output-stationary fused gather-GEMM (no per-offset launches, no
+`nbsizes.cpu()` per call).
+Autocast: the reference casts op inputs to fp16 under AMP (`custom_fwd(cast_inputs=torch.half)`);
+this round the kernels are fp32, so under autocast inputs are cast to fp32 instead.
+"""
+import torch
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+from . import native
+from .sparse import SparseTensor, get_kernel_offsets, make_ntuple
+
+__all__ = ["sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize", "calc_ti_weights",
+           "spdownsample", "conv3d", "relu", "leaky_relu"]
+
+
+def _be():
+    return native.backend()
+
+
+# ---------------------------------------------------------------------------------------------
+def sphash(coords, offsets=None):
+    assert coords.dtype == torch.int, coords.dtype
+    assert coords.ndim == 2 and coords.shape[1] == 4, coords.shape
+    coords = coords.contiguous()
+    if offsets is None:
+        return _be().hash(coords)
+    assert offsets.dtype == torch.int, offsets.dtype
+    assert offsets.ndim == 2 and offsets.shape[1] == 3, offsets.shape
+    return _be().kernel_hash(coords, offsets.contiguous())
+
+
+def sphashquery(queries, references):
+    queries = queries.contiguous()
+    references = references.contiguous()
+    sizes = queries.size()
+    return _be().hash_query(queries.view(-1), references).view(*sizes)
+
+
+def spcount(coords, num):
+    return _be().count(coords.contiguous(), num)
+
+
+# ---------------------------------------------------------------------------------------------
+class _Voxelize(Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, feats, coords, counts):
+        feats = feats.contiguous()
+        coords = coords.contiguous().int()
+        out = _be().voxelize_fwd(feats, coords, counts)
+        ctx.for_backwards = (coords, counts, feats.shape[0])
+        return out
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_output):
+        coords, counts, n = ctx.for_backwards
+        return _be().voxelize_bwd(grad_output.contiguous(), coords, counts, n), None, None
+
+
+def spvoxelize(feats, coords, counts):
+    return _Voxelize.apply(feats, coords, counts)
+
+
+class _Devoxelize(Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, feats, coords, weights):
+        feats = feats.contiguous()
+        coords = coords.contiguous().int()
+        weights = weights.contiguous()
+        out = _be().devoxelize_fwd(feats, coords, weights)
+        ctx.for_backwards = (coords, weights, feats.shape[0])
+        return out
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_output):
+        coords, weights, m = ctx.for_backwards
+        return _be().devoxelize_bwd(grad_output.contiguous(), coords, weights, m), None, None
+
+
+def spdevoxelize(feats, coords, weights):
+    return _Devoxelize.apply(feats, coords, weights)
+
+
+def calc_ti_weights(coords, idx_query, scale=1):
+    """(8,N) trilinear weights; coords (N,>=3) float, idx_query (8,N) with -1 = missing corner."""
+    with torch.no_grad():
+        return _be().ti_weights(coords.float(), idx_query.long(), scale)
+
+
+# ---------------------------------------------------------------------------------------------
+def spdownsample(coords, stride=2, kernel_size=2, tensor_stride=1):
+    stride = make_ntuple(stride, ndim=3)
+    kernel_size = make_ntuple(kernel_size, ndim=3)
+    tensor_stride = make_ntuple(tensor_stride, ndim=3)
+    sample_stride = [stride[k] * tensor_stride[k] for k in range(3)]
+    if all(stride[k] in [1, kernel_size[k]] for k in range(3)):
+        return _be().downsample(coords, sample_stride)
+    offsets = get_kernel_offsets(kernel_size, tensor_stride, device=coords.device)
+    coords_min = torch.min(coords[:, :3], dim=0).values.int()
+    return _be().downsample(coords, sample_stride, offsets, coords_min)
+
+
+# ---------------------------------------------------------------------------------------------
+class KmapEntry(list):
+    """kmaps[(stride, kernel_size, conv_stride, dilation)] = [nbmaps, nbsizes, (n_in, n_out)]
+    like the reference (conv.py:174-176), plus the native maps the kernels use:
+      .fwd  pairs (in_row, out_row), out ascending within an offset  (= nbmaps)
+      .rev  pairs (out_row, in_row), in ascending within an offset   (built on first use;
+            needed by dgrad and by transposed convolutions)"""
+
+    def __init__(self, fwd, in_coords, out_coords, offsets):
+        super().__init__([fwd.pairs, fwd.nbsizes, (in_coords.shape[0], out_coords.shape[0])])
+        self.fwd = fwd
+        self._rev = None
+        self._ctx = (in_coords, out_coords, offsets)
+
+    @property
+    def rev(self):
+        if self._rev is None:
+            in_coords, out_coords, offsets = self._ctx
+            self._rev = _be().build_kmap(out_coords, in_coords, -offsets)
+        return self._rev
+
+
+def build_kernel_map(in_coords, out_coords, kernel_size, in_stride, dilation):
+    offsets = get_kernel_offsets(kernel_size, stride=in_stride, dilation=dilation,
+                                 device=in_coords.device)
+    fwd = _be().build_kmap(in_coords, out_coords, offsets)
+    return KmapEntry(fwd, in_coords, out_coords, offsets)
+
+
+class _SparseConv(Function):
+    """out = conv(input) over a kernel map; backward = dgrad (same fused kernel on the other
+    map, per-offset transposed weights) + wgrad (split reduction)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, input, weight, entry, transposed):
+        input = input.contiguous()
+        weight = weight.contiguous()
+        w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
+        kmap = entry.rev if transposed else entry.fwd
+        out = _be().conv_gather_gemm(input, w3, kmap)
+        ctx.for_backwards = (input, weight, entry, transposed)
+        return out
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_output):
+        input, weight, entry, transposed = ctx.for_backwards
+        grad_output = grad_output.contiguous()
+        w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
+        grad_input = grad_weight = None
+        if ctx.needs_input_grad[0]:
+            wt = w3.transpose(1, 2).contiguous()
+            grad_input = _be().conv_gather_gemm(grad_output, wt, entry.fwd if transposed else entry.rev)
+        if ctx.needs_input_grad[1]:
+            # fwd pairs are (in_row, out_row) of the NON-transposed conv; a transposed conv's
+            # input lives on the out rows (column 1)
+            grad_weight = _be().conv_wgrad(input, grad_output, entry.fwd, 1 if transposed else 0)
+            grad_weight = grad_weight.view_as(weight)
+        return grad_input, grad_weight, None, None
+
+
+def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transposed=False):
+    kernel_size = make_ntuple(kernel_size, ndim=3)
+    stride = make_ntuple(stride, ndim=3)
+    dilation = make_ntuple(dilation, ndim=3)
+    ones = (1, 1, 1)
+
+    if kernel_size == ones and stride == ones and dilation == ones:
+        output_stride = input.stride
+        output_coords = input.coords
+        output_feats = input.feats.matmul(weight)
+    elif not transposed:
+        output_stride = tuple(input.stride[k] * stride[k] for k in range(3))
+        if output_stride in input.cmaps:
+            output_coords = input.cmaps[output_stride]
+        elif all(stride[k] == 1 for k in range(3)):
+            output_coords = input.coords
+        else:
+            output_coords = spdownsample(input.coords, stride, kernel_size, input.stride)
+        key = (input.stride, kernel_size, stride, dilation)
+        if key not in input.kmaps:
+            input.kmaps[key] = build_kernel_map(input.coords, output_coords, kernel_size,
+                                                input.stride, dilation)
+        output_feats = _SparseConv.apply(input.feats, weight, input.kmaps[key], False)
+    else:
+        output_stride = tuple(input.stride[k] // stride[k] for k in range(3))
+        output_coords = input.cmaps[output_stride]
+        key = (output_stride, kernel_size, stride, dilation)
+        output_feats = _SparseConv.apply(input.feats, weight, input.kmaps[key], True)
+
+    if bias is not None:
+        output_feats += bias
+
+    output = SparseTensor(coords=output_coords, feats=output_feats, stride=output_stride)
+    output.cmaps = input.cmaps
+    output.cmaps.setdefault(output_stride, output_coords)
+    output.kmaps = input.kmaps
+    return output
+
+
+# ---------------------------------------------------------------------------------------------
+def relu(input, inplace=True):
+    return input._like(torch.nn.functional.relu(input.feats, inplace=inplace))
+
+
+def leaky_relu(input, negative_slope=0.1, inplace=True):
+    return input._like(torch.nn.functional.leaky_relu(input.feats, negative_slope, inplace=inplace))

@@ -1,0 +1,81 @@
+"""Host-side (NumPy, dataloader-worker) voxel dedup and batch collation.
+
+These run on the CPU in the reference too; a device version is a
+"next" row. Same signatures and ordering contract as
+  sparse_quantize / ravel_hash   TS:torchsparse/utils/quantize.py:9-46
+  sparse_collate(_fn)            TS:torchsparse/utils/collate.py:11-59
+"""
+from itertools import repeat
+
+import numpy as np
+import torch
+
+from .sparse import SparseTensor
+
+__all__ = ["ravel_hash", "sparse_quantize", "sparse_collate", "sparse_collate_fn"]
+
+
+def ravel_hash(x):
+    """Row-major linear index of integer coords inside their bounding box (uint64)."""
+    assert x.ndim == 2, x.shape
+    x = (x - x.min(axis=0)).astype(np.uint64, copy=False)
+    extent = x.max(axis=0).astype(np.uint64) + 1
+    h = np.zeros(x.shape[0], dtype=np.uint64)
+    for d in range(x.shape[1] - 1):
+        h += x[:, d]
+        h *= extent[d + 1]
+    h += x[:, -1]
+    return h
+
+
+def sparse_quantize(coords, voxel_size=1, *, return_index=False, return_inverse=False):
+    """floor(coords / voxel_size) -> unique voxels, one representative (first occurrence) per
+    voxel, output ordered by ascending ravel hash."""
+    if isinstance(voxel_size, (float, int)):
+        voxel_size = tuple(repeat(voxel_size, 3))
+    assert isinstance(voxel_size, tuple) and len(voxel_size) == 3
+    coords = np.floor(coords / np.array(voxel_size)).astype(np.int32)
+    _, indices, inverse = np.unique(ravel_hash(coords), return_index=True, return_inverse=True)
+    outputs = [coords[indices]]
+    if return_index:
+        outputs.append(indices)
+    if return_inverse:
+        outputs.append(inverse)
+    return outputs[0] if len(outputs) == 1 else outputs
+
+
+def sparse_collate(inputs):
+    """Concatenate SparseTensors along N, appending the batch index as the 4th coord column."""
+    stride = inputs[0].stride
+    coords, feats = [], []
+    for b, x in enumerate(inputs):
+        if isinstance(x.coords, np.ndarray):
+            x.coords = torch.tensor(x.coords)
+        if isinstance(x.feats, np.ndarray):
+            x.feats = torch.tensor(x.feats)
+        assert isinstance(x.coords, torch.Tensor), type(x.coords)
+        assert isinstance(x.feats, torch.Tensor), type(x.feats)
+        assert x.stride == stride, (x.stride, stride)
+        col = torch.full((x.coords.shape[0], 1), b, device=x.coords.device, dtype=torch.int)
+        coords.append(torch.cat((x.coords, col), dim=1))
+        feats.append(x.feats)
+    return SparseTensor(coords=torch.cat(coords, dim=0), feats=torch.cat(feats, dim=0), stride=stride)
+
+
+def sparse_collate_fn(inputs):
+    if not isinstance(inputs[0], dict):
+        return inputs
+    out = {}
+    for name, first in inputs[0].items():
+        column = [sample[name] for sample in inputs]
+        if isinstance(first, dict):
+            out[name] = sparse_collate_fn(column)
+        elif isinstance(first, np.ndarray):
+            out[name] = torch.stack([torch.tensor(v) for v in column], dim=0)
+        elif isinstance(first, torch.Tensor):
+            out[name] = torch.stack(column, dim=0)
+        elif isinstance(first, SparseTensor):
+            out[name] = sparse_collate(column)
+        else:
+            out[name] = column
+    return out

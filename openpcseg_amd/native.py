@@ -1,0 +1,341 @@
+"""ctypes binding of libpcseg_hip.so (include/pcseg_hip.h) + the tensor-level backend.
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the current HIP
+stream; every compute call below is one or more `pcs_*` C-ABI calls on raw device pointers.
+There is NO CPU path: a missing library or a non-HIP tensor raises.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpcseg_hip.so")
+
+# symbol -> (restype, argtypes); kept in one table so tests can check every symbol that
+# include/pcseg_hip.h declares is exported.
+_P = c_void_p
+SIGNATURES = {
+    "pcs_abi_version": (c_int32, []),
+    "pcs_last_error": (c_char_p, []),
+    "pcs_hash": (c_int32, [_P, c_int64, _P, _P]),
+    "pcs_kernel_hash": (c_int32, [_P, c_int64, _P, c_int32, _P, _P]),
+    "pcs_hashtable_capacity": (c_int64, [c_int64]),
+    "pcs_hashtable_bytes": (c_size_t, [c_int64]),
+    "pcs_hashtable_build": (c_int32, [_P, c_int64, _P, c_int64, _P]),
+    "pcs_hashtable_query": (c_int32, [_P, c_int64, _P, c_int64, _P, _P]),
+    "pcs_count": (c_int32, [_P, c_int64, _P, c_int64, _P]),
+    "pcs_voxelize_fwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int64, c_int32, _P, _P]),
+    "pcs_voxelize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P]),
+    "pcs_devoxelize_fwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P]),
+    "pcs_devoxelize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int64, c_int32, _P, _P]),
+    "pcs_ti_weights_f32": (c_int32, [_P, c_int32, _P, c_int64, c_float, _P, _P]),
+    "pcs_downsample_pack": (c_int32, [_P, c_int64, _P, c_int32, _P, c_int32, _P, _P, _P, _P]),
+    "pcs_downsample_unpack": (c_int32, [_P, c_int64, _P, _P]),
+    "pcs_rulebook_ws_bytes": (c_size_t, [c_int64, c_int32]),
+    "pcs_rulebook_probe": (c_int32, [_P, c_int64, _P, c_int32, _P, c_int64, _P, _P, _P, c_size_t, _P]),
+    "pcs_rulebook_fill": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P]),
+    "pcs_rulebook_tile_segments": (c_int32, [_P, _P, c_int32, c_int64, c_int32, c_int32, _P, _P]),
+    "pcs_conv_tile_rows": (c_int32, [c_int32, c_int32]),
+    "pcs_conv_gather_gemm_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32,
+                                           _P, c_int32, c_int64, _P, _P, _P]),
+    "pcs_conv_wgrad_ws_bytes": (c_size_t, [_P, c_int32, c_int32, c_int32]),
+    "pcs_conv_wgrad_f32": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P,
+                                     _P, c_size_t, _P]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen the C-ABI library and declare every signature. Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            "openpcseg_amd: %s is missing -- build it with `python -m openpcseg_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback." % _LIB_PATH)
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = symbol missing = broken build
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pcs_abi_version() != 1:
+        raise RuntimeError("openpcseg_amd: ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().pcs_last_error()
+        raise RuntimeError("openpcseg_amd: %s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def _dev(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("openpcseg_amd: `%s` must be a HIP device tensor (got %s); the MI355X "
+                           "backend has no CPU path" % (name, getattr(t, "device", type(t))))
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("openpcseg_amd: `%s` must be %s, got %s" % (name, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else c_void_p(0)
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class HashTable:
+    """Device open-addressing table over a vector of 60-bit hashes (value = position)."""
+
+    __slots__ = ("storage", "capacity", "n")
+
+    def __init__(self, storage, capacity, n):
+        self.storage, self.capacity, self.n = storage, capacity, n
+
+
+class KernelMap:
+    """A rulebook: pairs (P,2) int32 = (src_row, dst_row), k-major, dst ascending within k.
+
+    `koff` are the K+1 slice offsets (device int32) and `koff_host` the same numbers on the
+    host; `nbsizes` (K,) int64 mirrors the reference's kmap entry
+    (TS:torchsparse/nn/functional/conv.py:168). Tile-segment tables are cached per tile height.
+    """
+
+    def __init__(self, pairs, koff, koff_host, nbsizes, n_src, n_dst):
+        self.pairs, self.koff, self.koff_host, self.nbsizes = pairs, koff, koff_host, nbsizes
+        self.n_src, self.n_dst = n_src, n_dst
+        self.K = len(koff_host) - 1
+        self._seg = {}
+        self._koff_c = (c_int32 * (self.K + 1))(*koff_host)
+
+    @property
+    def num_pairs(self):
+        return self.koff_host[-1]
+
+
+class HipBackend:
+    """Tensor-level view of the C ABI (one method per reference backend function / fused op)."""
+
+    name = "hip-gfx950"
+
+    def __init__(self):
+        self.lib = load_library()
+
+    # -- K1 / K2 ------------------------------------------------------------------------------
+    def hash(self, coords):
+        coords = _dev(coords, "coords", torch.int32)
+        out = torch.empty(coords.shape[0], dtype=torch.int64, device=coords.device)
+        _check(self.lib.pcs_hash(_ptr(coords), coords.shape[0], _ptr(out), _stream()), "pcs_hash")
+        return out
+
+    def kernel_hash(self, coords, offsets):
+        coords = _dev(coords, "coords", torch.int32)
+        offsets = _dev(offsets, "offsets", torch.int32)
+        n, k = coords.shape[0], offsets.shape[0]
+        out = torch.empty((k, n), dtype=torch.int64, device=coords.device)
+        _check(self.lib.pcs_kernel_hash(_ptr(coords), n, _ptr(offsets), k, _ptr(out), _stream()),
+               "pcs_kernel_hash")
+        return out
+
+    # -- K3-K5 ---------------------------------------------------------------------------------
+    def table_build(self, keys):
+        keys = _dev(keys, "references", torch.int64)
+        n = keys.numel()
+        cap = self.lib.pcs_hashtable_capacity(n)
+        storage = torch.empty(self.lib.pcs_hashtable_bytes(cap), dtype=torch.uint8, device=keys.device)
+        _check(self.lib.pcs_hashtable_build(_ptr(keys), n, _ptr(storage), cap, _stream()),
+               "pcs_hashtable_build")
+        return HashTable(storage, cap, n)
+
+    def table_query(self, table, queries):
+        """-> int64, position + 1 or 0 (the reference backend's convention)."""
+        queries = _dev(queries, "queries", torch.int64)
+        out = torch.empty(queries.numel(), dtype=torch.int64, device=queries.device)
+        _check(self.lib.pcs_hashtable_query(_ptr(table.storage), table.capacity, _ptr(queries),
+                                            queries.numel(), _ptr(out), _stream()), "pcs_hashtable_query")
+        return out
+
+    def hash_query(self, queries, references):
+        """sphashquery core: index of each query hash among references, -1 when absent."""
+        table = self.table_build(references)
+        return self.table_query(table, queries.reshape(-1)) - 1
+
+    # -- K6 ------------------------------------------------------------------------------------
+    def count(self, idx, num):
+        idx = _dev(idx, "coords", torch.int32)
+        out = torch.empty(int(num), dtype=torch.int32, device=idx.device)
+        _check(self.lib.pcs_count(_ptr(idx), idx.numel(), _ptr(out), int(num), _stream()), "pcs_count")
+        return out
+
+    # -- K7-K10 ---------------------------------------------------------------------------------
+    def voxelize_fwd(self, feats, idx, counts):
+        feats = _dev(feats, "feats", torch.float32)
+        idx = _dev(idx, "coords", torch.int32)
+        counts = _dev(counts, "counts", torch.int32)
+        n, c = feats.shape
+        m = counts.shape[0]
+        out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
+        _check(self.lib.pcs_voxelize_fwd_f32(_ptr(feats), _ptr(idx), _ptr(counts), n, m, c, _ptr(out),
+                                             _stream()), "pcs_voxelize_fwd_f32")
+        return out
+
+    def voxelize_bwd(self, gout, idx, counts, n):
+        gout = _dev(gout, "grad_output", torch.float32)
+        c = gout.shape[1]
+        gin = torch.empty((n, c), dtype=torch.float32, device=gout.device)
+        _check(self.lib.pcs_voxelize_bwd_f32(_ptr(gout), _ptr(idx), _ptr(counts), n, c, _ptr(gin),
+                                             _stream()), "pcs_voxelize_bwd_f32")
+        return gin
+
+    def devoxelize_fwd(self, feats, idx8, w8):
+        feats = _dev(feats, "feats", torch.float32)
+        idx8 = _dev(idx8, "coords", torch.int32)
+        w8 = _dev(w8, "weights", torch.float32)
+        n, c = idx8.shape[0], feats.shape[1]
+        out = torch.empty((n, c), dtype=torch.float32, device=feats.device)
+        _check(self.lib.pcs_devoxelize_fwd_f32(_ptr(feats), _ptr(idx8), _ptr(w8), n, c, _ptr(out),
+                                               _stream()), "pcs_devoxelize_fwd_f32")
+        return out
+
+    def devoxelize_bwd(self, gout, idx8, w8, m):
+        gout = _dev(gout, "grad_output", torch.float32)
+        n, c = gout.shape
+        gfeat = torch.empty((m, c), dtype=torch.float32, device=gout.device)
+        _check(self.lib.pcs_devoxelize_bwd_f32(_ptr(gout), _ptr(idx8), _ptr(w8), n, m, c, _ptr(gfeat),
+                                               _stream()), "pcs_devoxelize_bwd_f32")
+        return gfeat
+
+    def ti_weights(self, coords, idx_query, scale):
+        coords = _dev(coords, "coords", torch.float32)
+        idx_query = _dev(idx_query, "idx_query", torch.int64)
+        n = coords.shape[0]
+        w = torch.empty((8, n), dtype=torch.float32, device=coords.device)
+        _check(self.lib.pcs_ti_weights_f32(_ptr(coords), coords.shape[1], _ptr(idx_query), n,
+                                           float(scale), _ptr(w), _stream()), "pcs_ti_weights_f32")
+        return w
+
+    # -- spdownsample ---------------------------------------------------------------------------
+    def downsample(self, coords, sample_stride, offsets=None, coords_min=None):
+        """Unique, (b,x,y,z)-sorted output coordinates. offsets=None -> fast branch."""
+        coords = _dev(coords, "coords", torch.int32)
+        n = coords.shape[0]
+        ss = (c_int32 * 3)(*[int(s) for s in sample_stride])
+        err = torch.zeros(1, dtype=torch.int32, device=coords.device)
+        if offsets is None:
+            keys = torch.empty(n, dtype=torch.int64, device=coords.device)
+            rc = self.lib.pcs_downsample_pack(_ptr(coords), n, ss, 0, None, 0, None, _ptr(keys),
+                                              _ptr(err), _stream())
+        else:
+            offsets = _dev(offsets, "offsets", torch.int32)
+            coords_min = _dev(coords_min, "coords_min", torch.int32)
+            k = offsets.shape[0]
+            keys = torch.empty(n * k, dtype=torch.int64, device=coords.device)
+            rc = self.lib.pcs_downsample_pack(_ptr(coords), n, ss, 1, _ptr(offsets), k,
+                                              _ptr(coords_min), _ptr(keys), _ptr(err), _stream())
+        _check(rc, "pcs_downsample_pack")
+        uniq = torch.unique(keys)  # sorted ascending == reference's lexicographic (b,x,y,z)
+        if err.item():
+            raise RuntimeError("openpcseg_amd: spdownsample coordinate out of the packed range "
+                               "(|x|,|y|,|z| < 2^17, 0 <= batch < 512)")
+        if uniq.numel() and offsets is not None and uniq[-1].item() == 0x7FFFFFFFFFFFFFFF:
+            uniq = uniq[:-1]
+        m = uniq.numel()
+        out = torch.empty((m, 4), dtype=torch.int32, device=coords.device)
+        _check(self.lib.pcs_downsample_unpack(_ptr(uniq), m, _ptr(out), _stream()), "pcs_downsample_unpack")
+        return out
+
+    # -- rulebook -------------------------------------------------------------------------------
+    def build_kmap(self, ref_coords, query_coords, offsets):
+        """pairs (ref_row, query_row) for hash(query + offsets[k]) == hash(ref); k-major, query
+        ascending. One host sync (the per-offset sizes size the pair list)."""
+        ref_coords = _dev(ref_coords, "coords", torch.int32)
+        query_coords = _dev(query_coords, "coords", torch.int32)
+        offsets = _dev(offsets, "offsets", torch.int32)
+        dev = ref_coords.device
+        table = self.table_build(self.hash(ref_coords))
+        nq, k = query_coords.shape[0], offsets.shape[0]
+        results = torch.empty((k, max(nq, 1)), dtype=torch.int32, device=dev)
+        nbsizes = torch.empty(k, dtype=torch.int64, device=dev)
+        ws_bytes = self.lib.pcs_rulebook_ws_bytes(nq, k)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _check(self.lib.pcs_rulebook_probe(_ptr(query_coords), nq, _ptr(offsets), k, _ptr(table.storage),
+                                           table.capacity, _ptr(results), _ptr(nbsizes), _ptr(ws),
+                                           ws_bytes, _stream()), "pcs_rulebook_probe")
+        sizes = nbsizes.cpu().tolist()  # the one sync of a rulebook build
+        koff_host = [0]
+        for s in sizes:
+            koff_host.append(koff_host[-1] + int(s))
+        pairs = torch.empty((koff_host[-1], 2), dtype=torch.int32, device=dev)
+        koff = torch.empty(k + 1, dtype=torch.int32, device=dev)
+        _check(self.lib.pcs_rulebook_fill(_ptr(results), nq, k, _ptr(ws), _ptr(pairs), _ptr(koff),
+                                          _stream()), "pcs_rulebook_fill")
+        return KernelMap(pairs, koff, koff_host, nbsizes, ref_coords.shape[0], nq)
+
+    def tile_rows(self, cin, cout):
+        return self.lib.pcs_conv_tile_rows(cin, cout)
+
+    def _segments(self, kmap, tile_rows):
+        seg = kmap._seg.get(tile_rows)
+        if seg is None:
+            ntiles = (kmap.n_dst + tile_rows - 1) // tile_rows
+            seg = torch.empty(kmap.K * (ntiles + 1), dtype=torch.int32, device=kmap.pairs.device)
+            _check(self.lib.pcs_rulebook_tile_segments(_ptr(kmap.pairs), _ptr(kmap.koff), kmap.K,
+                                                       kmap.n_dst, tile_rows, 1, _ptr(seg), _stream()),
+                   "pcs_rulebook_tile_segments")
+            kmap._seg[tile_rows] = seg
+        return seg
+
+    # -- convolution ----------------------------------------------------------------------------
+    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None):
+        """dst[d] = sum_{(s,d) in offset k} src[s] @ weight[k] (+bias); kmap dst-sorted."""
+        src = _dev(src, "input", torch.float32)
+        weight = _dev(weight, "weight", torch.float32)
+        k, cin, cout = weight.shape
+        if src.shape[1] != cin:
+            raise ValueError("Input feature size and kernel size mismatch")  # convolution_cuda.cu:57-59
+        if k != kmap.K:
+            raise ValueError("kernel volume %d does not match the kernel map (%d)" % (k, kmap.K))
+        if bias is not None:
+            bias = _dev(bias, "bias", torch.float32)
+        t = tile_rows or self.tile_rows(cin, cout)
+        seg = self._segments(kmap, t)
+        dst = torch.empty((kmap.n_dst, cout), dtype=torch.float32, device=src.device)
+        _check(self.lib.pcs_conv_gather_gemm_f32(_ptr(src), src.shape[0], cin, _ptr(weight), k, cout,
+                                                 _ptr(kmap.pairs), 0, _ptr(seg), t, kmap.n_dst,
+                                                 _ptr(bias) if bias is not None else None, _ptr(dst),
+                                                 _stream()), "pcs_conv_gather_gemm_f32")
+        return dst
+
+    def conv_wgrad(self, fa, fb, kmap, a_col):
+        """gW[k] = sum_{pairs of k} fa[pair[a_col]]^T (x) fb[pair[1-a_col]] -> (K, ca, cb)."""
+        fa = _dev(fa, "input", torch.float32)
+        fb = _dev(fb, "grad_output", torch.float32)
+        ca, cb = fa.shape[1], fb.shape[1]
+        gw = torch.empty((kmap.K, ca, cb), dtype=torch.float32, device=fa.device)
+        ws_bytes = self.lib.pcs_conv_wgrad_ws_bytes(kmap._koff_c, kmap.K, ca, cb)
+        ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=fa.device)
+        _check(self.lib.pcs_conv_wgrad_f32(_ptr(fa), ca, _ptr(fb), cb, _ptr(kmap.pairs), a_col,
+                                           _ptr(kmap.koff), kmap._koff_c, kmap.K, _ptr(gw), _ptr(ws),
+                                           ws_bytes, _stream()), "pcs_conv_wgrad_f32")
+        return gw
+
+
+_BACKEND = None
+
+
+def backend():
+    """The process-wide native backend (HIP only)."""
+    global _BACKEND
+    if _BACKEND is None:
+        _BACKEND = HipBackend()
+    return _BACKEND

@@ -1,0 +1,118 @@
+"""MinkUNet (ResBlock variant) workload on the HIP operator API.
+
+Architecture and state_dict layout of R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:194-434
+(so reference checkpoints load): stem 2x[k3 conv, BN, ReLU]; 4 encoder stages
+[k2 s2 conv-BN-ReLU + n residual blocks]; 4 decoder stages [k2 s2 transposed conv-BN-ReLU,
+concat skip, n residual blocks]; point branch = trilinear devoxelise at strides 1/16/4/1;
+Linear classifier over the concatenated point features. mk34 = NUM_LAYER [2,3,4,6,2,2,2,2],
+mk18 = [2,2,2,2,2,2,2,2]; PLANES [32,32,64,128,256,256,128,96,96] x cr.
+"""
+import torch
+from torch import nn
+
+from .. import modules as spnn
+from ..sparse import PointTensor, cat, fapply
+from .losses import SegLoss
+from .pointvoxel import initial_voxelize, voxel_to_point
+
+MK34_LAYERS = [2, 3, 4, 6, 2, 2, 2, 2]
+MK18_LAYERS = [2, 2, 2, 2, 2, 2, 2, 2]
+PLANES = [32, 32, 64, 128, 256, 256, 128, 96, 96]
+
+
+class _BN(nn.BatchNorm1d):
+    def forward(self, x):
+        return fapply(x, super().forward)
+
+
+class _SyncBN(nn.SyncBatchNorm):
+    def forward(self, x):
+        return fapply(x, super().forward)
+
+
+def _norm(c, dist):
+    return _SyncBN(c) if dist else _BN(c)
+
+
+class ConvBlock(nn.Module):
+    """conv -> BN -> ReLU (`net.0`, `net.1`); transposed=True gives the decoder up-conv."""
+
+    def __init__(self, cin, cout, ks, stride, dist, transposed=False):
+        super().__init__()
+        self.net = nn.Sequential(spnn.Conv3d(cin, cout, kernel_size=ks, stride=stride, transposed=transposed),
+                                 _norm(cout, dist), spnn.ReLU(True))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, cin, cout, dist):
+        super().__init__()
+        self.net = nn.Sequential(spnn.Conv3d(cin, cout, kernel_size=3), _norm(cout, dist), spnn.ReLU(True),
+                                 spnn.Conv3d(cout, cout, kernel_size=3), _norm(cout, dist))
+        if cin == cout:
+            self.downsample = nn.Identity()
+        else:
+            self.downsample = nn.Sequential(spnn.Conv3d(cin, cout, kernel_size=1), _norm(cout, dist))
+        self.relu = spnn.ReLU(True)
+
+    def forward(self, x):
+        return self.relu(self.net(x) + self.downsample(x))
+
+
+def _res_stack(cin, cout, n, dist):
+    return [ResBlock(cin if i == 0 else cout, cout, dist) for i in range(n)]
+
+
+class MinkUNet(nn.Module):
+    def __init__(self, num_class=20, in_dim=4, num_layer=MK34_LAYERS, planes=PLANES, cr=1.0,
+                 pres=0.05, vres=0.05, dist=False, ignore_label=0, label_smoothing=0.1, dropout=0.0):
+        super().__init__()
+        cs = [int(cr * c) for c in planes]
+        self.in_dim, self.pres, self.vres = in_dim, pres, vres
+        self.stem = nn.Sequential(spnn.Conv3d(in_dim, cs[0], kernel_size=3), _norm(cs[0], dist), spnn.ReLU(True),
+                                  spnn.Conv3d(cs[0], cs[0], kernel_size=3), _norm(cs[0], dist), spnn.ReLU(True))
+        enc_in = [cs[0], cs[1], cs[2], cs[3]]
+        for i in range(4):
+            setattr(self, "stage%d" % (i + 1), nn.Sequential(
+                ConvBlock(enc_in[i], enc_in[i], 2, 2, dist), *_res_stack(enc_in[i], cs[i + 1], num_layer[i], dist)))
+        skip = [cs[3], cs[2], cs[1], cs[0]]
+        cin = cs[4]
+        for i in range(4):
+            cout = cs[5 + i]
+            setattr(self, "up%d" % (i + 1), nn.ModuleList([
+                ConvBlock(cin, cout, 2, 2, dist, transposed=True),
+                nn.Sequential(*_res_stack(cout + skip[i], cout, num_layer[4 + i], dist))]))
+            cin = cout
+        self.classifier = nn.Sequential(nn.Linear(cs[4] + cs[6] + cs[8], num_class))
+        self.dropout = nn.Dropout(dropout, True)
+        self.criterion = SegLoss(ignore_index=ignore_label, label_smoothing=label_smoothing)
+
+    def point_logits(self, x):
+        """x: SparseTensor (feats (N,>=in_dim), coords (N,4) int) -> per-point logits (N, num_class)."""
+        x.F = x.F[:, :self.in_dim]
+        z = PointTensor(x.F, x.C.float())
+        x0 = self.stem(initial_voxelize(z, self.pres, self.vres))
+        z0 = voxel_to_point(x0, z)
+        x1 = self.stage1(x0)
+        x2 = self.stage2(x1)
+        x3 = self.stage3(x2)
+        x4 = self.stage4(x3)
+        z1 = voxel_to_point(x4, z0)
+        x4.F = self.dropout(x4.F)
+        y1 = self.up1[1](cat([self.up1[0](x4), x3]))
+        y2 = self.up2[1](cat([self.up2[0](y1), x2]))
+        z2 = voxel_to_point(y2, z1)
+        y2.F = self.dropout(y2.F)
+        y3 = self.up3[1](cat([self.up3[0](y2), x1]))
+        y4 = self.up4[1](cat([self.up4[0](y3), x0]))
+        z3 = voxel_to_point(y4, z2)
+        return self.classifier(torch.cat([z1.F, z2.F, z3.F], dim=1))
+
+    def forward(self, batch):
+        logits = self.point_logits(batch["lidar"])
+        out = {"logits": logits}
+        if self.training and "targets" in batch:
+            out["loss"] = self.criterion(logits, batch["targets"].F.long())
+        return out

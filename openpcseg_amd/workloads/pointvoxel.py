@@ -1,0 +1,49 @@
+"""Point <-> voxel glue used by the MinkUNet workload (the op sequences of SURVEY.md 3.2).
+
+Behaviourally equivalent to R:pcseg/model/segmentor/voxel/minkunet/utils.py:11-105
+(initial_voxelize / voxel_to_point), written against this package's functional API. The
+reference's own copy runs unmodified on top of `install_as_torchsparse()` as well (tested
+in-container); this copy exists because the reference tree does not travel to the GPU box.
+"""
+import torch
+
+from .. import functional as F
+from ..sparse import PointTensor, SparseTensor, get_kernel_offsets
+
+
+def initial_voxelize(z, init_res, after_res):
+    """Points -> stride-1 voxels ordered by ascending 60-bit hash (utils.py:11-36)."""
+    fc = torch.cat([(z.C[:, :3] * init_res) / after_res, z.C[:, -1:].clone()], dim=1)
+    cell = torch.floor(fc)
+    pc_hash = F.sphash(cell.int())
+    voxel_hash = torch.unique(pc_hash)
+    idx_query = F.sphashquery(pc_hash, voxel_hash)
+    counts = F.spcount(idx_query.int(), len(voxel_hash))
+    coords = torch.round(F.spvoxelize(cell, idx_query, counts)).int()
+    feats = F.spvoxelize(z.F, idx_query, counts)
+    x = SparseTensor(feats, coords, 1)
+    x.cmaps.setdefault(x.stride, x.coords)
+    z.additional_features["idx_query"][1] = idx_query
+    z.additional_features["counts"][1] = counts
+    z.C = fc
+    return x
+
+
+def voxel_to_point(x, z, nearest=False):
+    """Trilinear devoxelisation of x at the points of z; maps cached per stride (utils.py:69-105)."""
+    s = x.s
+    if z.idx_query.get(s) is None or z.weights.get(s) is None:
+        corners = get_kernel_offsets(2, s, 1, device=z.F.device)
+        base = torch.cat([torch.floor(z.C[:, :3] / s[0]).int() * s[0], z.C[:, -1:].int()], dim=1)
+        idx_query = F.sphashquery(F.sphash(base, corners), F.sphash(x.C.to(z.F.device)))
+        weights = F.calc_ti_weights(z.C, idx_query, scale=s[0]).t().contiguous()
+        idx_query = idx_query.t().contiguous()
+        if nearest:
+            weights[:, 1:] = 0.0
+            idx_query[:, 1:] = -1
+        z.idx_query[s] = idx_query
+        z.weights[s] = weights
+    out = PointTensor(F.spdevoxelize(x.F, z.idx_query[s], z.weights[s]), z.C,
+                      idx_query=z.idx_query, weights=z.weights)
+    out.additional_features = z.additional_features
+    return out

@@ -1,0 +1,56 @@
+"""Deterministic synthetic LiDAR scans at SemanticKITTI shape.
+
+64 rings x 1875 azimuth steps = 120 000 rays; scene = ground plane at z = -1.73 m plus a
+closed wall of radius r(az) = clip(22 + sum_i 3 k_i sin(i az + phi_i), 6, 48); range noise
+N(0, 0.02); intensity U(0,1). Then the dataset transform of the reference
+(R:pcseg/data/dataset/semantickitti/semantickitti_voxel.py:112-120):
+round(xyz / voxel) -> shift to >= 0 -> sparse_quantize. Seed 0 gives 92 321 voxels.
+"""
+import numpy as np
+import torch
+
+from ..hostdata import sparse_collate_fn, sparse_quantize
+from ..sparse import SparseTensor
+
+N_RINGS, N_AZ = 64, 1875
+
+
+def make_scan(seed=0, n_points=None):
+    """(N,4) fp32 [x, y, z, intensity]; n_points subsamples (every k-th ray) for small cases."""
+    rng = np.random.default_rng(seed)
+    elev = np.deg2rad(np.linspace(-24.8, 2.0, N_RINGS))
+    az = np.linspace(-np.pi, np.pi, N_AZ, endpoint=False)
+    k = rng.normal(size=8)
+    phi = rng.uniform(0, 2 * np.pi, size=8)
+    wall = 22.0 + sum(3.0 * k[i] * np.sin((i + 1) * az + phi[i]) for i in range(8))
+    wall = np.clip(wall, 6.0, 48.0)
+    el, a = np.meshgrid(elev, az, indexing="ij")
+    with np.errstate(divide="ignore"):
+        ground = np.where(el < 0, 1.73 / np.tan(-el), np.inf)
+    d = np.minimum(ground, wall[None, :]) + rng.normal(0, 0.02, size=el.shape)
+    pts = np.stack([d * np.cos(a), d * np.sin(a), d * np.tan(el), rng.uniform(0, 1, size=el.shape)], axis=-1)
+    pts = pts.reshape(-1, 4).astype(np.float32)
+    if n_points is not None and n_points < pts.shape[0]:
+        sel = np.linspace(0, pts.shape[0] - 1, n_points).astype(np.int64)
+        pts = pts[sel]
+    return pts
+
+
+def voxelize_scan(points, voxel_size=0.05, num_classes=20, seed=0):
+    """Reference dataset transform -> dict(lidar=SparseTensor, targets=SparseTensor) on the host."""
+    pc = np.round(points[:, :3] / voxel_size).astype(np.int32)
+    pc -= pc.min(0, keepdims=1)
+    _, inds, inverse = sparse_quantize(pc, return_index=True, return_inverse=True)
+    rng = np.random.default_rng(seed + 12345)
+    labels = rng.integers(0, num_classes, size=points.shape[0]).astype(np.int64)
+    lidar = SparseTensor(points[inds].astype(np.float32), pc[inds])
+    targets = SparseTensor(labels[inds], pc[inds])
+    return {"lidar": lidar, "targets": targets, "num_points": np.array([points.shape[0]])}
+
+
+def make_batch(seeds, n_points=None, voxel_size=0.05, num_classes=20):
+    """sparse_collate_fn over one synthetic frame per seed (host tensors)."""
+    frames = [voxelize_scan(make_scan(s, n_points), voxel_size, num_classes, s) for s in seeds]
+    batch = sparse_collate_fn(frames)
+    batch["offset"] = torch.cumsum(torch.tensor([f["lidar"].coords.shape[0] for f in frames]), 0).int()
+    return batch

@@ -1,0 +1,153 @@
+"""Torch-facing adapters that give the oracle (and the reference's compiled CPU backend) the
+same method surface as openpcseg_amd.native.HipBackend, on CPU tensors.
+
+TEST INFRASTRUCTURE ONLY. tests/ monkeypatch `openpcseg_amd.native._BACKEND` with one of these
+to exercise the host logic (containers, conv3d dispatcher, autograd wiring, DDP sharding) on a
+machine without a GPU, and to produce the expected values the HIP path is compared with;
+bench.py's cpu_baseline leg uses RefBackend to time the reference's own CPU code.
+The product never imports this module.
+"""
+import numpy as np
+import torch
+
+from . import build_ref, oracle as orc
+
+
+def _np(t):
+    return t.detach().cpu().contiguous().numpy()
+
+
+class CpuKernelMap:
+    def __init__(self, pairs, nbsizes, n_src, n_dst):
+        self.pairs = torch.from_numpy(np.ascontiguousarray(pairs, dtype=np.int32))
+        self.nbsizes = torch.from_numpy(np.ascontiguousarray(nbsizes, dtype=np.int64))
+        sizes = [int(s) for s in nbsizes]
+        self.koff_host = [0]
+        for s in sizes:
+            self.koff_host.append(self.koff_host[-1] + s)
+        self.koff = torch.tensor(self.koff_host, dtype=torch.int32)
+        self.n_src, self.n_dst, self.K = n_src, n_dst, len(sizes)
+
+    @property
+    def num_pairs(self):
+        return self.koff_host[-1]
+
+
+class OracleBackend:
+    """CPU restatement (oracle/pcs_oracle.c + oracle/oracle.py)."""
+
+    name = "oracle-cpu"
+
+    def hash(self, coords):
+        return torch.from_numpy(orc.sphash(_np(coords)))
+
+    def kernel_hash(self, coords, offsets):
+        return torch.from_numpy(orc.sphash(_np(coords), _np(offsets)))
+
+    def hash_query(self, queries, references):
+        return torch.from_numpy(orc.sphashquery(_np(queries), _np(references)))
+
+    def count(self, idx, num):
+        return torch.from_numpy(orc.spcount(_np(idx), num))
+
+    def voxelize_fwd(self, feats, idx, counts):
+        return torch.from_numpy(orc.voxelize_fwd(_np(feats), _np(idx), _np(counts)))
+
+    def voxelize_bwd(self, gout, idx, counts, n):
+        return torch.from_numpy(orc.voxelize_bwd(_np(gout), _np(idx), _np(counts), n))
+
+    def devoxelize_fwd(self, feats, idx8, w8):
+        return torch.from_numpy(orc.devoxelize_fwd(_np(feats), _np(idx8), _np(w8)))
+
+    def devoxelize_bwd(self, gout, idx8, w8, m):
+        return torch.from_numpy(orc.devoxelize_bwd(_np(gout), _np(idx8), _np(w8), m))
+
+    def ti_weights(self, coords, idx_query, scale):
+        return torch.from_numpy(orc.calc_ti_weights(_np(coords), _np(idx_query), scale))
+
+    def downsample(self, coords, sample_stride, offsets=None, coords_min=None):
+        """TS:torchsparse/nn/functional/downsample.py:25-51 given the already-derived
+        sample_stride / offsets / coords_min (what the product's backend receives)."""
+        c = _np(coords).astype(np.int32)
+        ss = np.asarray(sample_stride, dtype=np.int32)[None, :]
+        if offsets is None:
+            out = c.copy()
+            q = np.trunc(c[:, :3].astype(np.float32) / ss.astype(np.float32))
+            out[:, :3] = (q * ss.astype(np.float32)).astype(np.int32)
+        else:
+            off = _np(offsets).astype(np.int32)
+            cmin = _np(coords_min).astype(np.int32)[None, :]
+            x = (c[:, None, :3] + off[None, :, :]).reshape(-1, 3)
+            b = np.repeat(c[:, 3:], off.shape[0], axis=1).reshape(-1, 1)
+            cand = np.concatenate([x, b], axis=1)
+            mask = (np.mod(cand[:, :3], ss) == 0) & (cand[:, :3] >= cmin)
+            out = cand[mask.all(axis=1)]
+        out = np.unique(out[:, [3, 0, 1, 2]], axis=0)
+        return torch.from_numpy(np.ascontiguousarray(out[:, [1, 2, 3, 0]], dtype=np.int32))
+
+    def build_kmap(self, ref_coords, query_coords, offsets):
+        nbmaps, nbsizes = orc.build_kmap(_np(ref_coords), _np(query_coords), None, offsets=_np(offsets))
+        return CpuKernelMap(nbmaps, nbsizes, ref_coords.shape[0], query_coords.shape[0])
+
+    def tile_rows(self, cin, cout):
+        return 128
+
+    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None):
+        if src.shape[1] != weight.shape[1]:
+            raise ValueError("Input feature size and kernel size mismatch")
+        out = orc.conv_fwd(_np(src), _np(weight), _np(kmap.pairs), _np(kmap.nbsizes),
+                           (kmap.n_src, kmap.n_dst), transposed=False)
+        out = torch.from_numpy(out)
+        return out + bias if bias is not None else out
+
+    def conv_wgrad(self, fa, fb, kmap, a_col):
+        k, ca, cb = kmap.K, fa.shape[1], fb.shape[1]
+        w0 = np.zeros((k, ca, cb), dtype=np.float32)
+        _, gw = orc.conv_bwd(_np(fa), _np(fb), w0, _np(kmap.pairs), _np(kmap.nbsizes), transposed=bool(a_col))
+        return torch.from_numpy(gw)
+
+
+class RefBackend(OracleBackend):
+    """The reference's OWN compiled CPU functions (oracle/_ref) wherever its twin is sound
+    (SURVEY.md section 8c); the restatement for kernel_hash (multi-batch bug, hash_cpu.cpp:29)
+    and devoxelize backward (devoxelize_cpu.cpp:51-53)."""
+
+    name = "reference-cpu"
+
+    def __init__(self):
+        self.ref = build_ref.load()
+        if self.ref is None:
+            raise RuntimeError("oracle/_ref is not built (run oracle/build_ref.py where /root/reference exists)")
+
+    def hash(self, coords):
+        return self.ref.hash_cpu(coords.contiguous())
+
+    def hash_query(self, queries, references):
+        idx = torch.arange(references.numel(), dtype=torch.long)
+        return self.ref.hash_query_cpu(queries.reshape(-1).contiguous(), references.contiguous(), idx) - 1
+
+    def count(self, idx, num):
+        return self.ref.count_cpu(idx.contiguous(), int(num))
+
+    def voxelize_fwd(self, feats, idx, counts):
+        return self.ref.voxelize_forward_cpu(feats.contiguous(), idx.contiguous(), counts.contiguous())
+
+    def voxelize_bwd(self, gout, idx, counts, n):
+        return self.ref.voxelize_backward_cpu(gout.contiguous(), idx.contiguous(), counts.contiguous(), n)
+
+    def devoxelize_fwd(self, feats, idx8, w8):
+        return self.ref.devoxelize_forward_cpu(feats.contiguous(), idx8.contiguous(), w8.contiguous())
+
+    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None):
+        out = torch.zeros(kmap.n_dst, weight.shape[-1])
+        self.ref.convolution_forward_cpu(src.contiguous(), out, weight.contiguous(), kmap.pairs,
+                                         kmap.nbsizes.int(), False)
+        return out + bias if bias is not None else out
+
+    def conv_wgrad(self, fa, fb, kmap, a_col):
+        k, ca, cb = kmap.K, fa.shape[1], fb.shape[1]
+        gin = torch.zeros_like(fa)
+        gw = torch.zeros(k, ca, cb)
+        self.ref.convolution_backward_cpu(fa.contiguous(), gin, fb.contiguous(), torch.zeros(k, ca, cb), gw,
+                                          kmap.pairs, kmap.nbsizes.int(), bool(a_col))
+        return gw

@@ -1,0 +1,222 @@
+"""NumPy-level oracle API over pcs_oracle.c + pure-NumPy restatements of the reference's
+Python-side rulebook logic.
+
+TEST INFRASTRUCTURE ONLY (see the header of pcs_oracle.c): imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never by openpcseg_amd/.
+Every function cites the reference lines it restates (TS = package/torchsparse.zip,
+prefix torchsparse/).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(HERE, "pcs_oracle.c")
+_SO = os.path.join(HERE, "libpcs_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """gcc the C restatement (scalar, -O2, no OpenMP: cores = 1 when timed as a baseline)."""
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
+        subprocess.check_call(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", _SRC, "-o", _SO])
+    return _SO
+
+
+def _c():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+I64, I32 = ctypes.c_int64, ctypes.c_int32
+
+
+# ---- hashing -----------------------------------------------------------------------------------
+def sphash(coords, offsets=None):
+    """TS:torchsparse/nn/functional/hash.py:10-37 over hash_cuda.cu:10-55."""
+    coords = _i32(coords)
+    n = coords.shape[0]
+    if offsets is None:
+        out = np.empty(n, dtype=np.int64)
+        _c().orc_hash(_p(coords), I64(n), _p(out))
+        return out
+    offsets = _i32(offsets)
+    k = offsets.shape[0]
+    out = np.empty((k, n), dtype=np.int64)
+    _c().orc_kernel_hash(_p(coords), I64(n), _p(offsets), I32(k), _p(out))
+    return out
+
+
+def sphashquery(queries, references):
+    """TS:torchsparse/nn/functional/query.py:8-33 over query_cpu.cpp:12-37: index of the
+    FIRST reference equal to each query, -1 when absent."""
+    queries = np.asarray(queries, dtype=np.int64)
+    references = np.asarray(references, dtype=np.int64)
+    if references.size == 0:
+        return np.full(queries.shape, -1, dtype=np.int64)
+    uniq, first = np.unique(references, return_index=True)
+    pos = np.searchsorted(uniq, queries.reshape(-1))
+    pos = np.clip(pos, 0, len(uniq) - 1)
+    hit = uniq[pos] == queries.reshape(-1)
+    return np.where(hit, first[pos], -1).astype(np.int64).reshape(queries.shape)
+
+
+def spcount(idx, num):
+    """TS:torchsparse/backend/others/count_cuda.cu:10-16."""
+    idx = np.asarray(idx)
+    return np.bincount(idx[idx >= 0], minlength=int(num)).astype(np.int32)[: int(num)]
+
+
+# ---- point <-> voxel -----------------------------------------------------------------------------
+def voxelize_fwd(feats, idx, counts):
+    feats, idx, counts = _f32(feats), _i32(idx), _i32(counts)
+    n, c = feats.shape
+    m = counts.shape[0]
+    out = np.empty((m, c), dtype=np.float32)
+    _c().orc_voxelize_fwd(_p(feats), _p(idx), _p(counts), I64(n), I64(m), I32(c), _p(out))
+    return out
+
+
+def voxelize_bwd(gout, idx, counts, n):
+    gout, idx, counts = _f32(gout), _i32(idx), _i32(counts)
+    c = gout.shape[1]
+    gin = np.empty((n, c), dtype=np.float32)
+    _c().orc_voxelize_bwd(_p(gout), _p(idx), _p(counts), I64(n), I32(c), _p(gin))
+    return gin
+
+
+def devoxelize_fwd(feat, idx8, w8):
+    feat, idx8, w8 = _f32(feat), _i32(idx8), _f32(w8)
+    n, c = idx8.shape[0], feat.shape[1]
+    out = np.empty((n, c), dtype=np.float32)
+    _c().orc_devoxelize_fwd(_p(feat), _p(idx8), _p(w8), I64(n), I32(c), _p(out))
+    return out
+
+
+def devoxelize_bwd(gout, idx8, w8, m):
+    gout, idx8, w8 = _f32(gout), _i32(idx8), _f32(w8)
+    n, c = gout.shape
+    gfeat = np.empty((m, c), dtype=np.float32)
+    _c().orc_devoxelize_bwd(_p(gout), _p(idx8), _p(w8), I64(n), I64(m), I32(c), _p(gfeat))
+    return gfeat
+
+
+def calc_ti_weights(coords, idx_query, scale=1):
+    """TS:torchsparse/nn/functional/devoxelize.py:10-48, fp32 op for op. idx_query (8,N)."""
+    p = np.asarray(coords, dtype=np.float32)[:, :3]
+    s = np.float32(scale)
+    pf = np.floor(p / s) * s if scale != 1 else np.floor(p)
+    pc = pf + s
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    xf, yf, zf = pf[:, 0], pf[:, 1], pf[:, 2]
+    xc, yc, zc = pc[:, 0], pc[:, 1], pc[:, 2]
+    w = np.stack([
+        (xc - x) * (yc - y) * (zc - z), (xc - x) * (yc - y) * (z - zf),
+        (xc - x) * (y - yf) * (zc - z), (xc - x) * (y - yf) * (z - zf),
+        (x - xf) * (yc - y) * (zc - z), (x - xf) * (yc - y) * (z - zf),
+        (x - xf) * (y - yf) * (zc - z), (x - xf) * (y - yf) * (z - zf)], axis=0).astype(np.float32)
+    if scale != 1:
+        w = w / np.float32(scale ** 3)
+    w[np.asarray(idx_query) == -1] = 0
+    w = w / (w.sum(axis=0, dtype=np.float32) + np.float32(1e-8))
+    return w.astype(np.float32)
+
+
+# ---- kernel offsets / downsample / rulebook -----------------------------------------------------
+def _ntuple(x):
+    return tuple(x) if isinstance(x, (list, tuple)) else (x, x, x)
+
+
+def get_kernel_offsets(size, stride=1, dilation=1):
+    """TS:torchsparse/nn/utils/kernel.py:11-32."""
+    size, stride, dilation = _ntuple(size), _ntuple(stride), _ntuple(dilation)
+    ax = [np.arange(-size[k] // 2 + 1, size[k] // 2 + 1) * stride[k] * dilation[k] for k in range(3)]
+    if int(np.prod(size)) % 2 == 1:
+        offs = [[x, y, z] for z in ax[2] for y in ax[1] for x in ax[0]]
+    else:
+        offs = [[x, y, z] for x in ax[0] for y in ax[1] for z in ax[2]]
+    return np.array(offs, dtype=np.int32)
+
+
+def spdownsample(coords, stride=2, kernel_size=2, tensor_stride=1):
+    """TS:torchsparse/nn/functional/downsample.py:11-52."""
+    coords = _i32(coords)
+    stride, kernel_size, tensor_stride = _ntuple(stride), _ntuple(kernel_size), _ntuple(tensor_stride)
+    ss = np.array([stride[k] * tensor_stride[k] for k in range(3)], dtype=np.int32)[None, :]
+    if all(stride[k] in [1, kernel_size[k]] for k in range(3)):
+        out = coords.copy()
+        # torch.div(int, int) is a true (fp32) division, then trunc, then * stride (:25-28)
+        q = np.trunc(coords[:, :3].astype(np.float32) / ss.astype(np.float32))
+        out[:, :3] = (q * ss.astype(np.float32)).astype(np.int32)
+    else:
+        offsets = get_kernel_offsets(kernel_size, tensor_stride)
+        cmin = coords[:, :3].min(axis=0, keepdims=True)
+        x = (coords[:, None, :3] + offsets[None, :, :]).reshape(-1, 3)
+        b = np.repeat(coords[:, 3:], offsets.shape[0], axis=1).reshape(-1, 1)
+        cand = np.concatenate([x, b], axis=1)
+        mask = (np.mod(cand[:, :3], ss) == 0) & (cand[:, :3] >= cmin)
+        out = cand[mask.all(axis=1)]
+    out = out[:, [3, 0, 1, 2]]
+    out = np.unique(out, axis=0)  # lexicographic over (b, x, y, z)  (:49-51)
+    return np.ascontiguousarray(out[:, [1, 2, 3, 0]], dtype=np.int32)
+
+
+def build_kmap(in_coords, out_coords, kernel_size, in_stride=1, dilation=1, offsets=None):
+    """TS:torchsparse/nn/functional/conv.py:156-176 -> (nbmaps (P,2) int64 [in,out], nbsizes (K,) int64)."""
+    if offsets is None:
+        offsets = get_kernel_offsets(kernel_size, in_stride, dilation)
+    references = sphash(in_coords)
+    queries = sphash(out_coords, offsets)
+    results = sphashquery(queries, references)  # (K, N_out)
+    nbsizes = (results != -1).sum(axis=1).astype(np.int64)
+    kk, jj = np.nonzero(results != -1)  # row-major: k-major, out index ascending
+    nbmaps = np.stack([results[kk, jj], jj], axis=1).astype(np.int64)
+    return nbmaps, nbsizes
+
+
+# ---- convolution -----------------------------------------------------------------------------------
+def conv_fwd(feats, weight, nbmaps, nbsizes, sizes, transposed=False):
+    """TS:torchsparse/nn/functional/conv.py:16-82 -> out (sizes[1] or sizes[0], Cout)."""
+    feats, weight = _f32(feats), _f32(weight)
+    if weight.ndim == 2:
+        weight = weight[None]
+    nbm, nbs = _i32(nbmaps), _i32(nbsizes)
+    k, cin, cout = weight.shape
+    assert feats.shape[1] == cin, "Input feature size and kernel size mismatch"
+    n_out = sizes[0] if transposed else sizes[1]
+    out = np.empty((n_out, cout), dtype=np.float32)
+    _c().orc_conv_fwd(_p(feats), _p(out), _p(weight), _p(nbm), _p(nbs), I64(n_out), I32(cin), I32(cout),
+                      I32(k), I32(1 if transposed else 0))
+    return out
+
+
+def conv_bwd(feats, gout, weight, nbmaps, nbsizes, transposed=False):
+    """TS:torchsparse/nn/functional/conv.py:84-119 -> (grad_input, grad_weight)."""
+    feats, gout, weight = _f32(feats), _f32(gout), _f32(weight)
+    wshape = weight.shape
+    if weight.ndim == 2:
+        weight = weight[None]
+    nbm, nbs = _i32(nbmaps), _i32(nbsizes)
+    k, cin, cout = weight.shape
+    gin = np.empty_like(feats)
+    gw = np.empty_like(weight)
+    _c().orc_conv_bwd(_p(feats), _p(gin), _p(gout), _p(weight), _p(gw), _p(nbm), _p(nbs),
+                      I64(feats.shape[0]), I32(cin), I32(cout), I32(k), I32(1 if transposed else 0))
+    return gin, gw.reshape(wshape)

@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in this container.
+
+Needs /root/reference (so it cannot run on the GPU box; the .npz files are committed).
+  - the reference's Python package (package/torchsparse.zip, unzipped to a temp dir) is
+    imported on top of its own compiled CPU backend (oracle/_ref, built by
+    oracle/build_ref.py from the reference's C++ sources);
+  - for the end-to-end vector, the reference's MinkUNet (pcseg/model/segmentor/voxel/minkunet)
+    is imported unmodified with import stubs for packages that are absent here.
+Known reference CPU-twin defects are worked around WITHOUT changing semantics:
+  - kernel_hash_cpu uses row 0's batch index for every row (hash_cpu.cpp:29): called per batch;
+  - devoxelize_backward_cpu is wrong (devoxelize_cpu.cpp:51-53): not used for goldens.
+Usage: python tests/golden/make_golden.py
+"""
+import os
+import sys
+import tempfile
+import types
+import zipfile
+import zlib
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(OUT))
+from seeded import seeded_state  # noqa: E402
+
+
+def import_reference_torchsparse():
+    from oracle import build_ref
+    build_ref.build()
+    backend = build_ref.load()
+    tmp = tempfile.mkdtemp(prefix="pcs_golden_")
+    with zipfile.ZipFile("/root/reference/package/torchsparse.zip") as zf:
+        zf.extractall(tmp, [m for m in zf.namelist()
+                            if m.startswith("torchsparse/torchsparse/") and m.endswith(".py")])
+    sys.path.insert(0, os.path.join(tmp, "torchsparse"))
+    sys.modules["torchsparse.backend"] = backend
+    import torchsparse  # the REFERENCE package
+    torchsparse.backend = backend
+    assert torchsparse.__version__ == "1.4.0"
+    return torchsparse
+
+
+def main():
+    ts = import_reference_torchsparse()
+    import torchsparse.nn.functional as F
+    from torchsparse.nn.utils import get_kernel_offsets
+    from torchsparse.utils.quantize import sparse_quantize
+    from openpcseg_amd.workloads.synthetic import make_scan
+
+    g = {}
+    rng = np.random.default_rng(7)
+
+    # ---- K1/K2 hashes (incl. negative coords, several batches) -----------------------------------
+    kat = torch.tensor([[0, 0, 0, 0], [1, 2, 3, 0], [-1, 5, 7, 1], [100, 200, 30, 3]], dtype=torch.int32)
+    g["kat_coords"], g["kat_hash"] = kat.numpy(), F.sphash(kat).numpy()
+    c = torch.from_numpy(np.concatenate([rng.integers(-300, 300, size=(500, 3)),
+                                         rng.integers(0, 3, size=(500, 1))], axis=1).astype(np.int32))
+    c[0, :3] = torch.tensor([2 ** 31 - 1, -2 ** 31, -1])
+    g["hash_coords"], g["hash_out"] = c.numpy(), F.sphash(c).numpy()
+    off = get_kernel_offsets(3, 2)
+    kh = torch.zeros(off.shape[0], c.shape[0], dtype=torch.long)
+    for b in range(3):  # per batch: works around hash_cpu.cpp:29
+        sel = (c[:, 3] == b).nonzero().squeeze(1)
+        kh[:, sel] = F.sphash(c[sel].contiguous(), off)
+    g["khash_offsets"], g["khash_out"] = off.numpy(), kh.numpy()
+
+    # ---- a small voxelised scene (2 frames) ---------------------------------------------------------
+    frames = []
+    for b in range(2):
+        pts = make_scan(seed=b, n_points=1500)
+        pc = np.round(pts[:, :3] / 0.2).astype(np.int32)
+        pc -= pc.min(0, keepdims=1)
+        vox, inds = sparse_quantize(pc, return_index=True)
+        g["quant_in_%d" % b], g["quant_out_%d" % b], g["quant_idx_%d" % b] = pc, vox, inds
+        frames.append(np.concatenate([vox, np.full((vox.shape[0], 1), b, np.int32)], axis=1))
+    # hash order (what initial_voxelize produces) for stride 1
+    coords = torch.from_numpy(np.concatenate(frames).astype(np.int32))
+    h = F.sphash(coords)
+    coords = coords[torch.argsort(h)].contiguous()
+    g["scene_coords"] = coords.numpy()
+
+    # ---- hash query --------------------------------------------------------------------------------
+    ref_h = F.sphash(coords)
+    q = torch.cat([ref_h[::3], ref_h[:50] + 1])
+    g["query_q"], g["query_out"] = q.numpy(), F.sphashquery(q, ref_h).numpy()
+
+    # ---- spdownsample (fast + general branches) and kernel maps -------------------------------------
+    def per_batch_kmap(inc, outc, ks, in_stride):
+        """reference conv.py:156-176, with kernel_hash called per batch (CPU twin bug)."""
+        offsets = get_kernel_offsets(ks, stride=in_stride)
+        references = F.sphash(inc)
+        queries = torch.zeros(offsets.shape[0], outc.shape[0], dtype=torch.long)
+        for b in outc[:, 3].unique().tolist():
+            sel = (outc[:, 3] == b).nonzero().squeeze(1)
+            queries[:, sel] = F.sphash(outc[sel].contiguous(), offsets)
+        results = F.sphashquery(queries, references)
+        nbsizes = torch.sum(results != -1, dim=1)
+        nbmaps = torch.nonzero(results != -1)
+        nbmaps[:, 0] = results.view(-1)[nbmaps[:, 0] * results.size(1) + nbmaps[:, 1]]
+        return nbmaps, nbsizes
+
+    cases = [("k3s1", 3, 1, 1), ("k2s2", 2, 2, 1), ("k133", (1, 3, 3), 1, 1), ("k313", (3, 1, 3), 1, 1),
+             ("k3s2", 3, 2, 1), ("k3s221", 3, (2, 2, 1), 1)]
+    cur = {1: coords}
+    for name, ks, st, ts_ in cases:
+        inc = cur[1]
+        st3 = (st,) * 3 if isinstance(st, int) else st
+        if all(s == 1 for s in st3):
+            outc = inc
+        else:
+            outc = F.spdownsample(inc, st, ks, ts_)
+            g["ds_%s" % name] = outc.numpy()
+        nbmaps, nbsizes = per_batch_kmap(inc, outc, ks, ts_)
+        g["kmap_%s_nbmaps" % name], g["kmap_%s_nbsizes" % name] = nbmaps.numpy(), nbsizes.numpy()
+    # second level: tensor stride 2 -> 4 (k2 s2) and k3 at stride 2
+    c2 = torch.from_numpy(g["ds_k2s2"])
+    c4 = F.spdownsample(c2, 2, 2, 2)
+    g["ds_k2s2_l2"] = c4.numpy()
+    nbmaps, nbsizes = per_batch_kmap(c2, c2, 3, 2)
+    g["kmap_k3s1_l2_nbmaps"], g["kmap_k3s1_l2_nbsizes"] = nbmaps.numpy(), nbsizes.numpy()
+
+    # ---- convolution fwd / bwd through the reference autograd Function ---------------------------
+    from torchsparse.nn.functional.conv import ConvolutionFunction
+    tg = torch.Generator().manual_seed(3)
+    for name, cin, cout, transposed in [("k3s1", 16, 24, False), ("k2s2", 8, 12, False), ("k2s2", 12, 8, True)]:
+        nbmaps = torch.from_numpy(g["kmap_%s_nbmaps" % name])
+        nbsizes = torch.from_numpy(g["kmap_%s_nbsizes" % name])
+        n_in = coords.shape[0]
+        n_out = g["ds_%s" % name].shape[0] if ("ds_%s" % name) in g else n_in
+        k = nbsizes.shape[0]
+        x = torch.randn(n_out if transposed else n_in, cin, generator=tg, requires_grad=True)
+        w = (torch.randn(k, cin, cout, generator=tg) * 0.2).requires_grad_(True)
+        y = ConvolutionFunction.apply(x, w, nbmaps, nbsizes, (n_in, n_out), transposed)
+        gy = torch.randn(y.shape, generator=tg)
+        y.backward(gy)
+        tag = "conv_%s_%s" % (name, "T" if transposed else "N")
+        for key, val in [("x", x), ("w", w), ("y", y), ("gy", gy), ("gx", x.grad), ("gw", w.grad)]:
+            g["%s_%s" % (tag, key)] = val.detach().numpy()
+
+    # ---- voxelize / devoxelize / trilinear weights ---------------------------------------------------
+    npts = 800
+    idx = torch.from_numpy(rng.integers(0, 300, size=npts).astype(np.int32))
+    counts = F.spcount(idx, 300)
+    feats = torch.randn(npts, 6, generator=tg)
+    g["vox_idx"], g["vox_counts"], g["vox_feats"] = idx.numpy(), counts.numpy(), feats.numpy()
+    g["vox_out"] = ts.backend.voxelize_forward_cpu(feats, idx, counts).numpy()
+    g["vox_bwd"] = ts.backend.voxelize_backward_cpu(torch.from_numpy(g["vox_out"]), idx, counts, npts).numpy()
+    pcoords = torch.cat([torch.rand(npts, 3, generator=tg) * 40, torch.zeros(npts, 1)], dim=1)
+    idxq = torch.from_numpy(rng.integers(-1, 300, size=(8, npts)).astype(np.int64))
+    for scale in (1, 2, 4):
+        g["tiw_s%d" % scale] = F.calc_ti_weights(pcoords, idxq, scale=scale).numpy()
+    g["tiw_coords"], g["tiw_idxq"] = pcoords.numpy(), idxq.numpy()
+    w8 = torch.from_numpy(g["tiw_s2"]).t().contiguous()
+    vf = torch.randn(300, 10, generator=tg)
+    g["devox_feat"] = vf.numpy()
+    g["devox_out"] = ts.backend.devoxelize_forward_cpu(vf, idxq.t().contiguous().int(), w8).numpy()
+
+    np.savez_compressed(os.path.join(OUT, "ops_golden.npz"), **g)
+    print("wrote ops_golden.npz with", len(g), "arrays")
+
+    # ---- end to end: the reference's own MinkUNet on the reference backend ----------------------------
+    e2e = make_e2e(ts)
+    np.savez_compressed(os.path.join(OUT, "minkunet_e2e_golden.npz"), **e2e)
+    print("wrote minkunet_e2e_golden.npz; logits", e2e["logits"].shape)
+
+
+class _AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError:
+            raise AttributeError(k)
+        return _AttrDict(v) if isinstance(v, dict) and not isinstance(v, _AttrDict) else v
+
+    __setattr__ = dict.__setitem__
+
+
+def import_reference_minkunet():
+    for name in ["torch_scatter", "range_utils", "range_utils.nn", "range_utils.nn.functional",
+                 "rangelib_cuda", "SharedArray", "cv2", "torchvision", "torchvision.transforms",
+                 "torchvision.transforms.functional", "prettytable", "matplotlib", "matplotlib.pyplot",
+                 "torchvision.models", "torchvision.models.resnet", "numba"]:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    ed = types.ModuleType("easydict")
+    ed.EasyDict = _AttrDict
+    sys.modules.setdefault("easydict", ed)
+    sys.path.insert(0, "/root/reference")
+    import importlib
+    return importlib.import_module("pcseg.model.segmentor.voxel.minkunet.minkunet")
+
+
+def make_e2e(ts):
+    from openpcseg_amd.workloads.synthetic import make_batch
+    mod = import_reference_minkunet()
+    cfg = _AttrDict(NAME="MinkUNet", IGNORE_LABEL=0, IN_FEATURE_DIM=4, BLOCK="ResBlock",
+                    NUM_LAYER=[2, 3, 4, 6, 2, 2, 2, 2], PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96],
+                    cr=0.25, DROPOUT_P=0.0, LABEL_SMOOTHING=0.1, IF_DIST=False)
+    torch.manual_seed(0)
+    model = mod.MinkUNet(cfg, 20)
+    seeded_state(model)
+    model.train()  # batch statistics, like a training step
+    batch = make_batch([0], n_points=2000)
+    lidar = batch["lidar"]
+    feats, coords = lidar.feats.clone(), lidar.coords.clone()
+    captured = {}
+    model.classifier.register_forward_hook(lambda m, i, o: captured.__setitem__("logits", o.detach().clone()))
+    torch.Tensor.cuda = lambda self, *a, **k: self  # the model calls .cuda() on targets
+    ret, _, _ = model(batch)
+    return {"feats": feats.numpy(), "coords": coords.numpy(), "labels": batch["targets"].feats.numpy(),
+            "logits": captured["logits"].numpy(), "loss": np.array(float(ret["loss"])),
+            "state_keys": np.array(sorted(model.state_dict().keys()))}
+
+
+if __name__ == "__main__":
+    main()
