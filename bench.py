@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- LiDAR frames/sec, MinkUNet-34 cr1.0 training step at SemanticKITTI shape.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch: forward (hash-grid voxelise, 9 rulebook
+builds, 56 fused sparse convs, 4 trilinear devoxelisations), CE + Lovasz loss, backward
+(dgrad + wgrad per conv), gradient all-reduce (N > 1, RCCL), grad clip, SGD step. Inputs are
+synthetic ~120k-point scans (openpcseg_amd/workloads/synthetic.py), voxelised on the host by
+the reference's dataset transform BEFORE the timed region and resident in HBM; rulebooks are
+rebuilt every step (no cross-iteration cache, as in the reference).
+Prints ONE JSON line (rank 0) with the throughput, the roofline of the dominant kernel
+(fused gather-GEMM conv, fp32 MFMA) measured live with HIP events on the launch stream, and
+the reference's CPU backend timed on the host cores for a bounded sample (baseline only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from openpcseg_amd import native  # noqa: E402
+from openpcseg_amd.sparse import SparseTensor  # noqa: E402
+from openpcseg_amd.workloads.minkunet import MK34_LAYERS, MinkUNet  # noqa: E402
+from openpcseg_amd.workloads.synthetic import make_batch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
+POINTS_PER_FRAME = 120000
+
+
+class ConvMeter:
+    """Wraps the backend's fused conv launch: HIP events on the launch stream (torch's current
+    stream IS the stream the C ABI launches on) + algorithmic flops 2*P*Cin*Cout per launch."""
+
+    def __init__(self, be):
+        self.be, self.orig = be, be.conv_gather_gemm
+        self.records, self.enabled = [], False
+
+    def __enter__(self):
+        def wrapped(src, weight, kmap, bias=None, tile_rows=None):
+            if not self.enabled:
+                return self.orig(src, weight, kmap, bias, tile_rows)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig(src, weight, kmap, bias, tile_rows)
+            e1.record()
+            k, cin, cout = weight.shape
+            self.records.append((e0, e1, 2.0 * kmap.num_pairs * cin * cout))
+            return out
+        self.be.conv_gather_gemm = wrapped
+        return self
+
+    def __exit__(self, *a):
+        self.be.conv_gather_gemm = self.orig
+
+    def summary(self):
+        if not self.records:
+            return None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
+        flops = sum(f for _, _, f in self.records)
+        n = len(self.records)
+        achieved = flops / (ms * 1e-3) / 1e12
+        return {"kernel": "conv_os_kernel (pcs_conv_gather_gemm_f32: fwd + dgrad)", "bound": "mfma",
+                "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
+                "flops_per_launch": round(flops / n)}
+
+
+def to_device(batch, dev):
+    lidar, tg = batch["lidar"], batch["targets"]
+    coords = lidar.C.to(dev)
+    return {"lidar": SparseTensor(lidar.F.to(dev), coords), "targets": SparseTensor(tg.F.to(dev), coords)}
+
+
+def fresh(b):
+    """New containers over the SAME device tensors: every step rebuilds all maps."""
+    return {"lidar": SparseTensor(b["lidar"].F, b["lidar"].C), "targets": SparseTensor(b["targets"].F, b["targets"].C)}
+
+
+def cpu_baseline(n_points=8000):
+    """The reference's own compiled CPU backend (oracle/_ref) under the same MinkUNet-34
+    training step, on a bounded sample: ONE frame subsampled to n_points rays."""
+    try:
+        from oracle.adapter import RefBackend
+        ref = RefBackend()
+        kind = "reference"
+    except Exception:
+        from oracle.adapter import OracleBackend
+        ref, kind = OracleBackend(), "port"
+    saved = native._BACKEND
+    native._BACKEND = ref  # cpu_baseline leg only: the thing timed here IS the CPU reference
+    try:
+        torch.manual_seed(0)
+        model = MinkUNet(num_class=20, num_layer=MK34_LAYERS, cr=1.0).train()
+        b = make_batch([0], n_points=n_points)
+        batch = {"lidar": SparseTensor(b["lidar"].F, b["lidar"].C), "targets": SparseTensor(b["targets"].F, b["targets"].C)}
+        t0 = time.perf_counter()
+        out = model(batch)
+        out["loss"].backward()
+        dt = time.perf_counter() - t0
+    finally:
+        native._BACKEND = saved
+    cores = torch.get_num_threads() if kind == "reference" else 1
+    return {"value": round((n_points / POINTS_PER_FRAME) / dt, 5), "unit": "frames/s", "cores": cores, "kind": kind,
+            "sample": "1 frame subsampled to %d of 120000 rays, MinkUNet-34 cr1.0 fwd+bwd once (%.1f s), "
+                      "scaled linearly in points to full-frame frames/s" % (n_points, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames-per-gpu", type=int, default=12)  # BATCH_SIZE_PER_GPU of minkunet_mk34_cr10.yaml
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+
+    torch.manual_seed(0)
+    model = MinkUNet(num_class=20, num_layer=MK34_LAYERS, cr=1.0, dist=distributed).to(dev).train()
+    if distributed:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.02 * args.frames_per_gpu * world / 8, momentum=0.9, weight_decay=1e-4,
+                          nesterov=True)
+
+    # frames are sharded by rank: each rank owns frames_per_gpu whole frames (weak scaling)
+    seeds = [rank * args.frames_per_gpu + i for i in range(args.frames_per_gpu)]
+    batch = to_device(make_batch(seeds), dev)
+    n_vox = batch["lidar"].C.shape[0]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(fresh(batch))
+        out["loss"].backward()
+        torch.nn.utils.clip_grad_norm_(params, 10.0)
+        opt.step()
+        return out["loss"]
+
+    be = native.backend()
+    with ConvMeter(be) as meter:
+        for _ in range(args.warmup):
+            step()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        meter.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        meter.enabled = False
+        roof = meter.summary()
+    if distributed:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        frames = args.frames_per_gpu * world * args.steps
+        res = {
+            "metric": "LiDAR frames/sec training MinkUNet-34 SemanticKITTI",
+            "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MinkUNet-34 cr1.0 train step (fwd + CE/Lovasz + bwd + SGD), SemanticKITTI-shape "
+                                   "synthetic scans (120k pts, 0.05 m voxels), fp32",
+                       "frames_per_gpu": args.frames_per_gpu, "global_batch": args.frames_per_gpu * world,
+                       "voxels_per_gpu_batch": n_vox, "parallelism": "dp%d" % world, "loss": round(float(loss), 4)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

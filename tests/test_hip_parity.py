@@ -1,0 +1,312 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference goldens.
+Run with `-m gpu` on an MI355X. Integer / index work: bit-exact. fp32: tolerance stated per test.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def t(a, dtype=None):
+    x = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        x = x.to(dtype)
+    return x.to(DEV)
+
+
+def close(a, b, rtol=1e-4):
+    """fp32 MFMA / FMA vs scalar-C summation order: relative to the tensor's max magnitude."""
+    a = a.detach().cpu().numpy().astype(np.float64) if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(np.abs(b).max(), 1e-6) if b.size else 1.0
+    err = np.abs(a - b).max() / scale if b.size else 0.0
+    assert err <= rtol, err
+
+
+def random_scene(rng, n, extent, batches):
+    c = np.concatenate([rng.integers(0, extent, size=(n, 3)), rng.integers(0, batches, size=(n, 1))], axis=1)
+    c = np.unique(c.astype(np.int32), axis=0)
+    return c[rng.permutation(c.shape[0])]
+
+
+# ---- K1 / K2 -------------------------------------------------------------------------------------
+def test_hash_golden_and_random(hip, golden):
+    assert (hip.hash(t(golden["kat_coords"])).cpu().numpy() == golden["kat_hash"]).all()
+    assert (hip.hash(t(golden["hash_coords"])).cpu().numpy() == golden["hash_out"]).all()
+    kh = hip.kernel_hash(t(golden["hash_coords"]), t(golden["khash_offsets"]))
+    assert (kh.cpu().numpy() == golden["khash_out"]).all()
+    rng = np.random.default_rng(0)
+    c = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(100003, 4)).astype(np.int32)
+    assert (hip.hash(t(c)).cpu().numpy() == orc.sphash(c)).all()
+    off = orc.get_kernel_offsets((3, 1, 3), 4)
+    assert (hip.kernel_hash(t(c[:5000]), t(off)).cpu().numpy() == orc.sphash(c[:5000], off)).all()
+    assert hip.hash(torch.zeros(0, 4, dtype=torch.int32, device=DEV)).shape == (0,)
+
+
+# ---- K3-K5 / K6 ----------------------------------------------------------------------------------
+def test_hash_query(hip, golden):
+    ref_h = orc.sphash(golden["scene_coords"])
+    out = hip.hash_query(t(golden["query_q"]), t(ref_h))
+    assert (out.cpu().numpy() == golden["query_out"]).all()
+    # duplicates: smallest position wins; misses -> -1; empty query / empty table
+    out = hip.hash_query(t(np.array([5, 7, 9], np.int64)), t(np.array([7, 5, 7, 5], np.int64)))
+    assert out.cpu().tolist() == [1, 0, -1]
+    assert hip.hash_query(t(np.zeros(0, np.int64)), t(ref_h)).numel() == 0
+    assert hip.hash_query(t(np.array([3], np.int64)), t(np.zeros(0, np.int64))).cpu().tolist() == [-1]
+    rng = np.random.default_rng(1)
+    keys = rng.integers(0, 2 ** 60, size=300000)
+    q = np.concatenate([keys[::2], rng.integers(0, 2 ** 60, size=1000)])
+    assert (hip.hash_query(t(q), t(keys)).cpu().numpy() == orc.sphashquery(q, keys)).all()
+
+
+def test_count(hip):
+    rng = np.random.default_rng(2)
+    idx = rng.integers(-1, 5000, size=200000).astype(np.int32)
+    assert (hip.count(t(idx), 5000).cpu().numpy() == orc.spcount(idx, 5000)).all()
+    assert hip.count(t(np.zeros(0, np.int32)), 7).cpu().tolist() == [0] * 7
+
+
+# ---- K7-K10 ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c", [3, 4, 6, 32, 96])
+def test_voxelize(hip, c):
+    rng = np.random.default_rng(c)
+    n, m = 50000, 9000
+    idx = rng.integers(0, m, size=n).astype(np.int32)
+    idx[:17] = -1
+    counts = orc.spcount(idx, m)
+    feats = rng.normal(size=(n, c)).astype(np.float32)
+    close(hip.voxelize_fwd(t(feats), t(idx), t(counts)), orc.voxelize_fwd(feats, idx, counts), 1e-5)
+    gout = rng.normal(size=(m, c)).astype(np.float32)
+    close(hip.voxelize_bwd(t(gout), t(idx), t(counts), n), orc.voxelize_bwd(gout, idx, counts, n), 1e-6)
+
+
+def test_voxelize_golden(hip, golden):
+    out = hip.voxelize_fwd(t(golden["vox_feats"]), t(golden["vox_idx"]), t(golden["vox_counts"]))
+    close(out, golden["vox_out"], 1e-6)
+
+
+@pytest.mark.parametrize("c", [5, 32, 96, 256])
+def test_devoxelize(hip, c):
+    rng = np.random.default_rng(c)
+    n, m = 30000, 4000
+    idx8 = rng.integers(-1, m, size=(n, 8)).astype(np.int32)
+    w8 = rng.uniform(0, 1, size=(n, 8)).astype(np.float32)
+    feat = rng.normal(size=(m, c)).astype(np.float32)
+    close(hip.devoxelize_fwd(t(feat), t(idx8), t(w8)), orc.devoxelize_fwd(feat, idx8, w8), 1e-6)
+    gout = rng.normal(size=(n, c)).astype(np.float32)
+    close(hip.devoxelize_bwd(t(gout), t(idx8), t(w8), m), orc.devoxelize_bwd(gout, idx8, w8, m), 1e-5)
+
+
+def test_ti_weights_golden(hip, golden):
+    for s in (1, 2, 4):
+        w = hip.ti_weights(t(golden["tiw_coords"]), t(golden["tiw_idxq"]), s)
+        close(w, golden["tiw_s%d" % s], 2e-6)
+    out = hip.devoxelize_fwd(t(golden["devox_feat"]), t(np.ascontiguousarray(golden["tiw_idxq"].T), torch.int32),
+                             t(np.ascontiguousarray(golden["tiw_s2"].T)))
+    close(out, golden["devox_out"], 1e-6)
+
+
+# ---- downsample + rulebook: bit-exact incl. order -------------------------------------------------
+@pytest.mark.parametrize("name,args", [("k2s2", (2, 2, 1)), ("k3s2", (2, 3, 1)), ("k3s221", ((2, 2, 1), 3, 1))])
+def test_downsample_golden(hip, golden, name, args):
+    from openpcseg_amd import functional as F
+    out = F.spdownsample(t(golden["scene_coords"]), *args)
+    assert out.dtype == torch.int32 and (out.cpu().numpy() == golden["ds_" + name]).all()
+
+
+def test_downsample_random(hip):
+    from openpcseg_amd import functional as F
+    rng = np.random.default_rng(3)
+    c = random_scene(rng, 60000, 90, 4)
+    for args in [(2, 2, 1), (2, 2, 4), ((2, 2, 1), 3, 2), (2, 3, 1)]:
+        cc = c.copy()
+        ts = args[2]
+        cc[:, :3] *= ts
+        assert (F.spdownsample(t(cc), *args).cpu().numpy() == orc.spdownsample(cc, *args)).all()
+
+
+@pytest.mark.parametrize("name,ks,in_stride", [("k3s1", 3, 1), ("k2s2", 2, 1), ("k133", (1, 3, 3), 1),
+                                                ("k313", (3, 1, 3), 1), ("k3s2", 3, 1), ("k3s221", 3, 1)])
+def test_kmap_golden(hip, golden, name, ks, in_stride):
+    from openpcseg_amd import functional as F
+    inc = golden["scene_coords"]
+    outc = golden["ds_" + name] if ("ds_" + name) in golden.files else inc
+    entry = F.build_kernel_map(t(inc), t(outc), (ks,) * 3 if isinstance(ks, int) else ks, (in_stride,) * 3, (1, 1, 1))
+    assert (entry[1].cpu().numpy() == golden["kmap_%s_nbsizes" % name]).all()
+    assert (entry[0].cpu().numpy().astype(np.int64) == golden["kmap_%s_nbmaps" % name]).all()
+    assert entry[2] == (inc.shape[0], outc.shape[0])
+    # the input-sorted map holds the same pair set, sorted by input row within each offset
+    fwd, rev = entry.fwd, entry.rev
+    assert rev.koff_host == fwd.koff_host
+    fp, rp = fwd.pairs.cpu().numpy(), rev.pairs.cpu().numpy()
+    for k in range(fwd.K):
+        a, b = fwd.koff_host[k], fwd.koff_host[k + 1]
+        f = fp[a:b]
+        r = rp[a:b]
+        assert (np.diff(r[:, 1]) > 0).all()
+        order = np.argsort(f[:, 0], kind="stable")
+        assert (f[order][:, [1, 0]] == r).all()
+
+
+def test_kmap_random_multibatch(hip):
+    from openpcseg_amd import functional as F
+    rng = np.random.default_rng(4)
+    c = random_scene(rng, 40000, 60, 3)
+    for ks, st in [(3, 1), ((3, 1, 1), 1), (2, 2), (3, (2, 2, 1))]:
+        ks3 = (ks,) * 3 if isinstance(ks, int) else ks
+        st3 = (st,) * 3 if isinstance(st, int) else st
+        outc = c if all(s == 1 for s in st3) else orc.spdownsample(c, st3, ks3, 1)
+        nbmaps, nbsizes = orc.build_kmap(c, outc, ks3, 1)
+        entry = F.build_kernel_map(t(c), t(outc), ks3, (1, 1, 1), (1, 1, 1))
+        assert (entry[1].cpu().numpy() == nbsizes).all()
+        assert (entry[0].cpu().numpy().astype(np.int64) == nbmaps).all()
+
+
+# ---- convolution -----------------------------------------------------------------------------------
+def _scene_maps(hip, golden, which):
+    from openpcseg_amd import functional as F
+    inc = golden["scene_coords"]
+    if which == "k3s1":
+        return F.build_kernel_map(t(inc), t(inc), (3, 3, 3), (1, 1, 1), (1, 1, 1)), \
+            (golden["kmap_k3s1_nbmaps"], golden["kmap_k3s1_nbsizes"]), inc.shape[0], inc.shape[0]
+    outc = golden["ds_k2s2"]
+    return F.build_kernel_map(t(inc), t(outc), (2, 2, 2), (1, 1, 1), (1, 1, 1)), \
+        (golden["kmap_k2s2_nbmaps"], golden["kmap_k2s2_nbsizes"]), inc.shape[0], outc.shape[0]
+
+
+@pytest.mark.parametrize("cin,cout", [(4, 32), (32, 32), (32, 64), (96, 96), (128, 96), (192, 128), (256, 256),
+                                      (384, 256), (64, 20), (5, 33), (56, 112)])
+@pytest.mark.parametrize("tile", [64, 128])
+def test_conv_forward_and_dgrad_kernel(hip, golden, cin, cout, tile):
+    entry, (nbmaps, nbsizes), n_in, n_out = _scene_maps(hip, golden, "k3s1")
+    rng = np.random.default_rng(cin * 1000 + cout)
+    x = rng.normal(size=(n_in, cin)).astype(np.float32)
+    w = (rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32)
+    y = hip.conv_gather_gemm(t(x), t(w), entry.fwd, tile_rows=tile)
+    close(y, orc.conv_fwd(x, w, nbmaps, nbsizes, (n_in, n_out)), 2e-5)
+    # dgrad = the same kernel on the input-sorted map with per-offset transposed weights
+    gy = rng.normal(size=(n_out, cout)).astype(np.float32)
+    gx = hip.conv_gather_gemm(t(gy), t(np.ascontiguousarray(w.transpose(0, 2, 1))), entry.rev, tile_rows=tile)
+    ogx, ogw = orc.conv_bwd(x, gy, w, nbmaps, nbsizes)
+    close(gx, ogx, 2e-5)
+    close(hip.conv_wgrad(t(x), t(gy), entry.fwd, 0), ogw, 2e-5)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 128), (256, 128), (96, 96)])
+def test_conv_strided_and_transposed(hip, golden, cin, cout):
+    entry, (nbmaps, nbsizes), n_in, n_out = _scene_maps(hip, golden, "k2s2")
+    rng = np.random.default_rng(cin + cout)
+    w = (rng.normal(size=(8, cin, cout)) / np.sqrt(cin * 8)).astype(np.float32)
+    x = rng.normal(size=(n_in, cin)).astype(np.float32)
+    close(hip.conv_gather_gemm(t(x), t(w), entry.fwd), orc.conv_fwd(x, w, nbmaps, nbsizes, (n_in, n_out)), 2e-5)
+    xc = rng.normal(size=(n_out, cin)).astype(np.float32)  # transposed: input lives on the coarse rows
+    close(hip.conv_gather_gemm(t(xc), t(w), entry.rev),
+          orc.conv_fwd(xc, w, nbmaps, nbsizes, (n_in, n_out), transposed=True), 2e-5)
+    gy = rng.normal(size=(n_in, cout)).astype(np.float32)
+    ogx, ogw = orc.conv_bwd(xc, gy, w, nbmaps, nbsizes, transposed=True)
+    close(hip.conv_gather_gemm(t(gy), t(np.ascontiguousarray(w.transpose(0, 2, 1))), entry.fwd), ogx, 2e-5)
+    close(hip.conv_wgrad(t(xc), t(gy), entry.fwd, 1), ogw, 2e-5)
+
+
+@pytest.mark.parametrize("tag,ks,stride,transposed", [("conv_k3s1_N", 3, 1, False), ("conv_k2s2_N", 2, 2, False),
+                                                       ("conv_k2s2_T", 2, 2, True)])
+def test_conv3d_autograd_vs_reference_golden(hip, golden, tag, ks, stride, transposed):
+    from openpcseg_amd import functional as F
+    from openpcseg_amd.sparse import SparseTensor
+    coords = t(golden["scene_coords"])
+    x = t(golden[tag + "_x"]).requires_grad_(True)
+    w = t(golden[tag + "_w"]).requires_grad_(True)
+    if not transposed:
+        out = F.conv3d(SparseTensor(x, coords, 1), w, ks, stride=stride)
+    else:
+        fine = SparseTensor(torch.zeros(coords.shape[0], 8, device=DEV), coords, 1)
+        fine.cmaps[(1, 1, 1)] = coords
+        down = F.conv3d(fine, torch.zeros(8, 8, 12, device=DEV), ks, stride=stride)
+        inp = SparseTensor(x, down.C, down.s)
+        inp.cmaps, inp.kmaps = down.cmaps, down.kmaps
+        out = F.conv3d(inp, w, ks, stride=stride, transposed=True)
+    close(out.F, golden[tag + "_y"], 2e-5)
+    out.F.backward(t(golden[tag + "_gy"]))
+    close(x.grad, golden[tag + "_gx"], 2e-5)
+    close(w.grad, golden[tag + "_gw"], 2e-5)
+
+
+def test_conv_empty_and_ragged(hip):
+    from openpcseg_amd import functional as F
+    # isolated voxels: only the centre offset has pairs; 1 voxel; 129 voxels (tile boundary + 1)
+    for n in (1, 129, 130):
+        c = np.zeros((n, 4), np.int32)
+        c[:, 0] = np.arange(n) * 5
+        entry = F.build_kernel_map(t(c), t(c), (3, 3, 3), (1, 1, 1), (1, 1, 1))
+        assert entry[1].cpu().tolist() == [0] * 13 + [n] + [0] * 13
+        x = np.random.default_rng(n).normal(size=(n, 32)).astype(np.float32)
+        w = np.random.default_rng(n + 1).normal(size=(27, 32, 32)).astype(np.float32)
+        close(hip.conv_gather_gemm(t(x), t(w), entry.fwd), x @ w[13], 2e-5)
+        close(hip.conv_wgrad(t(x), t(x), entry.fwd, 0)[13], x.T @ x, 2e-5)
+        assert float(hip.conv_wgrad(t(x), t(x), entry.fwd, 0)[0].abs().max()) == 0.0
+
+
+# ---- end to end ------------------------------------------------------------------------------------
+def test_minkunet_logits_match_reference(hip, golden_e2e):
+    """per-point logits within 1e-3 (fp32) of the reference's MinkUNet + reference backend."""
+    from seeded import seeded_state
+    from openpcseg_amd.sparse import SparseTensor
+    from openpcseg_amd.workloads.minkunet import MinkUNet
+    model = MinkUNet(num_class=20, cr=0.25)
+    seeded_state(model)
+    model = model.to(DEV).train()
+    coords = t(golden_e2e["coords"])
+    batch = {"lidar": SparseTensor(t(golden_e2e["feats"]), coords), "targets": SparseTensor(t(golden_e2e["labels"]), coords)}
+    out = model(batch)
+    err = np.abs(out["logits"].detach().cpu().numpy() - golden_e2e["logits"]).max()
+    assert err < 1e-3, err
+    assert abs(float(out["loss"].detach()) - float(golden_e2e["loss"])) < 1e-3
+    out["loss"].backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+# ---- full-size, size-independent properties (120k-point scan, BASELINE shape) -------------------------
+def test_full_scan_properties(hip):
+    from openpcseg_amd import functional as F
+    from openpcseg_amd.workloads.synthetic import make_batch
+    batch = make_batch([0, 1])
+    coords = batch["lidar"].C.to(DEV)
+    n = coords.shape[0]
+    assert n > 150000
+    h = hip.hash(coords)
+    assert (hip.hash_query(h, h) == torch.arange(n, device=DEV)).all()       # every voxel finds itself
+    entry = F.build_kernel_map(coords, coords, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    pairs, koff = entry.fwd.pairs, entry.fwd.koff_host
+    assert koff[-1] == pairs.shape[0] and int(entry[1].sum()) == pairs.shape[0]
+    centre = pairs[koff[13]:koff[14]]
+    assert (centre[:, 0] == centre[:, 1]).all() and centre.shape[0] == n     # convolution_cuda.cu:76-88 assumption
+    for k in (0, 5, 26):
+        o = pairs[koff[k]:koff[k + 1], 1].long()
+        assert (o[1:] > o[:-1]).all()                                        # unique + ascending per offset
+    # mirror symmetry of a submanifold map: offset k pairs (i,o) <-> offset 26-k pairs (o,i)
+    a = pairs[koff[3]:koff[4]]
+    b = pairs[koff[23]:koff[24]]
+    assert a.shape == b.shape
+    assert (a[torch.argsort(a[:, 0].long())][:, [1, 0]] == b).all()
+    # linearity + run-to-run bit reproducibility of the fused conv
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x1 = torch.randn(n, 32, device=DEV, generator=g)
+    x2 = torch.randn(n, 32, device=DEV, generator=g)
+    w = torch.randn(27, 32, 64, device=DEV, generator=g) * 0.05
+    y1, y2 = hip.conv_gather_gemm(x1, w, entry.fwd), hip.conv_gather_gemm(x2, w, entry.fwd)
+    y12 = hip.conv_gather_gemm(x1 + x2, w, entry.fwd)
+    assert ((y1 + y2) - y12).abs().max() <= 1e-4 * y12.abs().max()
+    assert torch.equal(y1, hip.conv_gather_gemm(x1, w, entry.fwd))
+    gw = hip.conv_wgrad(x1, y1, entry.fwd, 0)
+    assert torch.equal(gw, hip.conv_wgrad(x1, y1, entry.fwd, 0))
+    # <conv(x), g> == <x, dgrad(g)>  (adjointness of fwd / dgrad over the two maps)
+    gy = torch.randn(n, 64, device=DEV, generator=g)
+    lhs = (y1.double() * gy.double()).sum()
+    rhs = (x1.double() * hip.conv_gather_gemm(gy, w.transpose(1, 2).contiguous(), entry.rev).double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-4 * abs(float(lhs))
