@@ -17,6 +17,8 @@
 //   5. adds the compact result rows into the accumulator tile through the dst-row map.
 // Every destination row is written exactly once at the end: no atomics, no zero fill of dst,
 // bit-reproducible run to run.
+#include <stdlib.h>
+
 #include "pcs_common.h"
 
 using namespace pcs;
@@ -202,12 +204,567 @@ int launch_conv(const ConvArgs &a, bool vec, hipStream_t st) {
   static bool attr_set_v = false, attr_set_s = false;
   bool &flag = vec ? attr_set_v : attr_set_s;
   if (!flag) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
     flag = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(C::NT), C::lds_bytes, st, a);
   return check_launch("pcs_conv_gather_gemm_f32");
+}
+
+// ================================================================================================
+// v2 of the same dataflow: software-pipelined.
+//   * steps = (non-empty offset k) x (cin chunk of 32); the (k, slice, m) list of the tile is
+//     compacted into LDS once, empty offsets cost nothing;
+//   * the gathered A rows, the W chunk and the NEXT offset's pair slice are prefetched into
+//     registers one step ahead (global loads in flight under the MFMAs), LDS tiles are double
+//     buffered -> ONE barrier per step instead of two;
+//   * MFMA work units are (16-row block, 16-col tile) pairs dealt round-robin to the 8 waves,
+//     so a 16-row compact tile still keeps every SIMD busy and a 128-row one is balanced.
+// Only for shapes with cin % 4 == 0 and cout % 4 == 0 (16-byte row granules); others use v1.
+// ================================================================================================
+// NU independent 16x16 output tiles (work units unit0, unit0+stride, ...) over one 32-deep chunk.
+template <int NCTT, int WS, int NU>
+__device__ __forceinline__ void mfma_group(const float *ab, const float *wb, f32x4 *acc, int unit0,
+                                           int stride, int lane) {
+  const int g = lane >> 4, l15 = lane & 15;
+  const float *ap[NU];
+  const float *bp[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int unit = unit0 + u * stride;
+    const int rb = unit / NCTT, ct = unit - rb * NCTT;
+    ap[u] = ab + (rb * 16 + l15) * AS + g;
+    bp[u] = wb + g * WS + ct * 16 + l15;
+  }
+#pragma unroll
+  for (int kk = 0; kk < CK / 4; ++kk) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[u][kk * 4], bp[u][kk * 4 * WS], acc[u], 0, 0, 0);
+  }
+}
+
+template <int NCTT, int T>
+struct Conv2Cfg {
+  static constexpr int NW = 8;
+  static constexpr int NT = 64 * NW;
+  static constexpr int CT = 16 * NCTT;
+  static constexpr int ACS = CT + 4;
+  static constexpr int WS = (CT % 32 == 0) ? CT + 16 : CT + 32;  // == 16 (mod 32)
+  static constexpr int MAXU = ((T / 16) * NCTT + NW - 1) / NW;
+  static constexpr int UG = MAXU < 4 ? MAXU : 4;                    // units per MFMA group
+  static constexpr int AL = (T * (CK / 4) + NT - 1) / NT;          // float4 A granules / thread
+  static constexpr int WL = (CK * (CT / 4) + NT - 1) / NT;         // float4 W granules / thread
+  static constexpr int D = 3;                                       // steps of loads in flight
+  static constexpr int KMAX = 27;                                   // max kernel volume (v1 beyond)
+  static constexpr int PCAP = KMAX * T;                             // pairs of one tile
+  static constexpr int PL = (PCAP + NT - 1) / NT;
+  static constexpr size_t lds_bytes = (size_t)(T * ACS + 2 * T * AS + 2 * CK * WS) * 4 +
+                                      (size_t)PCAP * 4 + (size_t)PCAP + (size_t)3 * 32 * 4 + 16;
+};
+
+template <int NCTT, int T>
+__global__ void __launch_bounds__(512) conv_os2_kernel(ConvArgs a) {
+  using C = Conv2Cfg<NCTT, T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *acc_l = reinterpret_cast<float *>(smem);          // [T][ACS]
+  float *wbuf = acc_l + T * C::ACS;                        // [2][CK][WS]
+  float *abuf = wbuf + 2 * CK * C::WS;                     // [2][T][AS]
+  int *sidx = reinterpret_cast<int *>(abuf + 2 * T * AS);  // [PCAP] src row of every pair of the tile
+  int *kl_k = sidx + C::PCAP;                              // [32] offset id of the i-th non-empty offset
+  int *kl_o = kl_k + 32;                                   // [32] start of its slice inside sidx/drow
+  int *kl_s = kl_o + 32;                                   // [32] first pair (absolute)
+  unsigned char *drow = reinterpret_cast<unsigned char *>(kl_s + 32);  // [PCAP] local dst row
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int64_t tile = blockIdx.x / a.ncoltiles;
+  const int ctile = blockIdx.x % a.ncoltiles;
+  const int n0 = ctile * C::CT;
+  const int64_t row0 = tile * T;
+  const int64_t nt1 = a.ntiles + 1;
+  const int nchunks = (a.cin + CK - 1) / CK;
+
+  // ---- compact list of the non-empty offsets of this tile (wave 0, ballot + scan) ---------------
+  __shared__ int nk_s, np_s;
+  if (wid == 0) {
+    const int k = lane;
+    int s0 = 0, m = 0;
+    if (k < a.K) {
+      s0 = a.seg[(int64_t)k * nt1 + tile];
+      m = a.seg[(int64_t)k * nt1 + tile + 1] - s0;
+    }
+    const unsigned long long mask = __ballot(m > 0);
+    int incl = m;  // inclusive scan of m over the lanes
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (m > 0) {
+      const int pos = __popcll(mask & ((1ULL << lane) - 1ULL));
+      kl_k[pos] = k; kl_o[pos] = incl - m; kl_s[pos] = s0;
+    }
+    const int total = __shfl(incl, 63, 64);
+    if (lane == 0) { nk_s = __popcll(mask); np_s = total; kl_o[__popcll(mask)] = total; }
+  }
+  for (int i = tid; i < T * C::ACS; i += C::NT) acc_l[i] = 0.f;
+  __syncthreads();
+  const int nk = nk_s, np = np_s;
+  const int rows = (int)((a.n_dst - row0) < (int64_t)T ? (a.n_dst - row0) : (int64_t)T);
+
+  if (nk > 0) {
+    // ---- every pair of the tile -> LDS (src row as int32, local dst row as uint8) ---------------
+    {
+      int2 pr[C::PL];
+#pragma unroll
+      for (int q = 0; q < C::PL; ++q) {
+        const int e = tid + q * C::NT;
+        pr[q] = make_int2(0, 0);
+        if (e < np) {
+          int i = 0;
+          while (kl_o[i + 1] <= e) ++i;
+          pr[q] = reinterpret_cast<const int2 *>(a.pairs)[kl_s[i] + (e - kl_o[i])];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < C::PL; ++q) {
+        const int e = tid + q * C::NT;
+        if (e < np) {
+          sidx[e] = a.src_col ? pr[q].y : pr[q].x;
+          drow[e] = (unsigned char)((a.src_col ? pr[q].x : pr[q].y) - row0);
+        }
+      }
+    }
+    __syncthreads();
+
+    float4 areg[C::D][C::AL], wreg[C::D][C::WL];
+    const int total = nk * nchunks;
+    // All global loads are unconditional (clamped addresses); out-of-range values are replaced
+    // by zeros when the registers are written to LDS. A guarded load would make hipcc branch
+    // around it and wait vmcnt(0) at the join, i.e. a synchronous "prefetch".
+    auto load_step = [&](int st, float4 *ar, float4 *wr) {
+      const int i = st / nchunks;
+      const int c0 = (st - i * nchunks) * CK;
+      const int off = kl_o[i];
+      const int m = kl_o[i + 1] - off;
+#pragma unroll
+      for (int q = 0; q < C::AL; ++q) {
+        const int e = tid + q * C::NT;
+        const int r = e >> 3, c4 = c0 + (e & 7) * 4;
+        const int rr = r < m ? r : m - 1;
+        const int cc = c4 <= a.cin - 4 ? c4 : a.cin - 4;
+        ar[q] = *reinterpret_cast<const float4 *>(a.src + (int64_t)sidx[off + rr] * a.cin + cc);
+      }
+      const float *Wk = a.W + (int64_t)kl_k[i] * a.cin * a.cout;
+#pragma unroll
+      for (int q = 0; q < C::WL; ++q) {
+        const int e = tid + q * C::NT;
+        int kr = c0 + e / (C::CT / 4), cq = n0 + (e % (C::CT / 4)) * 4;
+        kr = kr < a.cin ? kr : a.cin - 1;
+        cq = cq <= a.cout - 4 ? cq : a.cout - 4;
+        wr[q] = *reinterpret_cast<const float4 *>(Wk + (int64_t)kr * a.cout + cq);
+      }
+    };
+
+    f32x4 acc[C::MAXU];
+#pragma unroll
+    for (int u = 0; u < C::MAXU; ++u) acc[u] = (f32x4){0, 0, 0, 0};
+
+#pragma unroll
+    for (int d = 0; d < C::D; ++d)
+      if (d < total) load_step(d, areg[d], wreg[d]);
+
+    for (int s0 = 0; s0 < total; s0 += C::D) {
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) {
+        const int st = s0 + d;
+        if (st < total) {  // block-uniform
+          const int i = st / nchunks;
+          const int c = st - i * nchunks;
+          const int off = kl_o[i];
+          const int m = kl_o[i + 1] - off;
+          float *ab = abuf + (st & 1) * T * AS;
+          float *wb = wbuf + (st & 1) * CK * C::WS;
+          // ---- stage registers (loaded D steps ago) -> LDS ----------------------------------------
+#pragma unroll
+          for (int q = 0; q < C::AL; ++q) {
+            const int e = tid + q * C::NT;
+            const int r = e >> 3, c4 = (e & 7) * 4;
+            if (r < m) {
+              const bool ok = c * CK + c4 < a.cin;  // channels beyond cin contribute zeros
+              float2 *dd = reinterpret_cast<float2 *>(ab + r * AS + c4);
+              dd[0] = ok ? make_float2(areg[d][q].x, areg[d][q].y) : make_float2(0.f, 0.f);
+              dd[1] = ok ? make_float2(areg[d][q].z, areg[d][q].w) : make_float2(0.f, 0.f);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < C::WL; ++q) {
+            const int e = tid + q * C::NT;
+            const int kr = e / (C::CT / 4), cq = (e % (C::CT / 4)) * 4;
+            if (kr < CK) {
+              const bool ok = c * CK + kr < a.cin && n0 + cq < a.cout;
+              *reinterpret_cast<float4 *>(wb + kr * C::WS + cq) = ok ? wreg[d][q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+          }
+          __syncthreads();
+          // ---- refill this stage with step st + D (in flight under D steps of MFMAs) -------------
+          if (st + C::D < total) load_step(st + C::D, areg[d], wreg[d]);
+          // ---- MFMA over the compact tile ------------------------------------------------------------
+          const int nunits = ((m + 15) >> 4) * NCTT;
+#pragma unroll
+          for (int u0 = 0; u0 < C::MAXU; u0 += C::UG) {
+            const int nv = (nunits - wid - u0 * C::NW + C::NW - 1) / C::NW;  // valid units in the group
+            if (nv >= 4 && C::UG >= 4) mfma_group<NCTT, C::WS, 4>(ab, wb, acc + u0, wid + u0 * C::NW, C::NW, lane);
+            else if (nv == 3 && C::UG >= 3) mfma_group<NCTT, C::WS, 3>(ab, wb, acc + u0, wid + u0 * C::NW, C::NW, lane);
+            else if (nv == 2 && C::UG >= 2) mfma_group<NCTT, C::WS, 2>(ab, wb, acc + u0, wid + u0 * C::NW, C::NW, lane);
+            else if (nv >= 1) mfma_group<NCTT, C::WS, 1>(ab, wb, acc + u0, wid + u0 * C::NW, C::NW, lane);
+          }
+          // ---- end of an offset: add the compact rows into the accumulator tile --------------------
+          if (c == nchunks - 1) {
+            const unsigned char *dr = drow + off;
+#pragma unroll
+            for (int u = 0; u < C::MAXU; ++u) {
+              const int unit = wid + u * C::NW;
+              if (unit < nunits) {
+                const int rb = unit / NCTT, ct = unit - rb * NCTT;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const int cr = rb * 16 + g * 4 + j;
+                  if (cr < m) acc_l[(int)dr[cr] * C::ACS + ct * 16 + l15] += acc[u][j];
+                }
+              }
+              acc[u] = (f32x4){0, 0, 0, 0};
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue ------------------------------------------------------------------------------------
+  for (int e = tid; e < rows * (C::CT / 4); e += C::NT) {
+    const int r = e / (C::CT / 4), cq = (e % (C::CT / 4)) * 4;
+    if (n0 + cq < a.cout) {
+      float4 v = *reinterpret_cast<const float4 *>(acc_l + r * C::ACS + cq);
+      if (a.bias) {
+        const float4 b = *reinterpret_cast<const float4 *>(a.bias + n0 + cq);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      *reinterpret_cast<float4 *>(a.dst + (row0 + r) * a.cout + n0 + cq) = v;
+    }
+  }
+}
+
+template <int NCTT, int T>
+int launch_conv2(const ConvArgs &a, hipStream_t st) {
+  using C = Conv2Cfg<NCTT, T>;
+  const int64_t nblocks = a.ntiles * a.ncoltiles;
+  if (nblocks <= 0) return PCS_OK;
+  if (nblocks > 0x7FFFFFFF) { set_error("pcs_conv: grid too large"); return PCS_EUNSUPPORTED; }
+  auto kern = conv_os2_kernel<NCTT, T>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(C::NT), C::lds_bytes, st, a);
+  return check_launch("pcs_conv_gather_gemm_f32(v2)");
+}
+
+// ================================================================================================
+// v4: wave-autonomous output-stationary conv (the default for 16-byte-granular shapes).
+// PMC on v2/v3 (profiles/round1_conv_pmc.md): ~20 scalar+vector instructions per MFMA, half of all
+// wave cycles in s_waitcnt/s_barrier, MFMA pipe 20-28 % busy -- the block-synchronous
+// stage->barrier->MFMA step is too small (m ~ 15 rows per offset at 0.05 m LiDAR sparsity).
+// Here the only shared state is the fp32 accumulator tile in LDS:
+//   * work item = one 16-row block of ONE offset's compact slice; the 8 waves of a workgroup
+//     walk the tile's row blocks round-robin with NO barrier in the main loop;
+//   * the wave reads its 16 (src,dst) pairs straight from the rulebook (128 B), gathers its A
+//     rows from HBM directly in MFMA operand layout (one 16-byte load per lane per 16
+//     channels), and reads the W[k] operand straight from L2 with 16-byte loads: lane (g, n)
+//     holds W[16j+4g+e][64c+4n .. +3], i.e. B operands of FOUR 16-column tiles whose columns
+//     are interleaved (tile f owns columns 4n+f) -- 9 VMEM instructions per 32 MFMAs;
+//   * results are added into the LDS tile with ds_add_f32 through the dst-row map, rows of
+//     different offsets may interleave in any order (sum order = fp32 rounding noise only);
+//   * LDS holds nothing but the accumulator tile -> 2-3 workgroups (16-24 waves) per CU, the
+//     gather latency is hidden by wave-level parallelism instead of a software pipeline.
+// ================================================================================================
+template <int NCTT, int T, int NW_>
+struct Conv4Cfg {
+  static constexpr int NW = NW_;
+  static constexpr int NT = 64 * NW;
+  static constexpr int CT = 16 * NCTT;
+  static constexpr int ACS = CT + 4;
+  static constexpr int N4 = NCTT / 4;            // 64-column groups  (float4 W loads)
+  static constexpr int N2 = (NCTT % 4) / 2;      // one 32-column group (float2 W loads)
+  static constexpr int N1 = NCTT % 2;            // one 16-column group (float  W loads)
+  static constexpr size_t lds_bytes = (size_t)((T + 1) * ACS) * 4 + 4 * 32 * 4 + 32;
+};
+
+template <int NCTT, int T, bool E32, int NW, int MINW>
+__global__ void __launch_bounds__(64 * NW, MINW) conv_os4_kernel(ConvArgs a) {
+  using C = Conv4Cfg<NCTT, T, NW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *acc_l = reinterpret_cast<float *>(smem);            // [T+1][ACS], row T = sink for padding rows
+  int *kl_k = reinterpret_cast<int *>(acc_l + (T + 1) * C::ACS);  // [32] offset id
+  int *kl_s = kl_k + 32;                                     // [32] first pair
+  int *kl_m = kl_s + 32;                                     // [32] #pairs
+  int *kl_r = kl_m + 32;                                     // [32] first row block (prefix)
+  int *commit = kl_r + 33;                                   // ticket: number of row blocks committed
+  __shared__ int nk_s;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int64_t tile = blockIdx.x / a.ncoltiles;
+  const int ctile = blockIdx.x % a.ncoltiles;
+  const int n0 = ctile * C::CT;
+  const int64_t row0 = tile * T;
+  const int64_t nt1 = a.ntiles + 1;
+
+  if (wid == 0) {  // non-empty offsets of this tile + prefix of their 16-row blocks
+    const int k = lane;
+    int s0 = 0, m = 0;
+    if (k < a.K) {
+      s0 = a.seg[(int64_t)k * nt1 + tile];
+      m = a.seg[(int64_t)k * nt1 + tile + 1] - s0;
+    }
+    const unsigned long long mask = __ballot(m > 0);
+    const int nrb = (m + 15) >> 4;
+    int incl = nrb;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (m > 0) {
+      const int pos = __popcll(mask & ((1ULL << lane) - 1ULL));
+      kl_k[pos] = k; kl_s[pos] = s0; kl_m[pos] = m; kl_r[pos] = incl - nrb;
+    }
+    const int total = __shfl(incl, 63, 64);
+    if (lane == 0) { nk_s = __popcll(mask); kl_r[__popcll(mask)] = total; *commit = 0; }
+  }
+  for (int i = tid; i < (T + 1) * C::ACS; i += C::NT) acc_l[i] = 0.f;
+  __syncthreads();
+  const int nk = nk_s;
+  const int total_rb = nk > 0 ? kl_r[nk] : 0;
+
+  // Every load below is UNCONDITIONAL (addresses clamped into the tensors, values fixed up with
+  // selects): a guarded load makes hipcc branch around it and wait vmcnt(0) per load, which
+  // serialises the whole gather (measured: 40 us per row block).
+  const int cin4 = a.cin - 4;  // last legal float4 start inside a row
+  const int wrmax = a.cin - 1;
+  // per-lane column offsets of the W loads, clamped inside the row (columns >= cout only feed
+  // accumulator columns that the epilogue never writes)
+  int col4[C::N4 > 0 ? C::N4 : 1];
+#pragma unroll
+  for (int q = 0; q < C::N4; ++q) {
+    const int c = 64 * q + 4 * l15;
+    col4[q] = (n0 + c + 4 <= a.cout) ? c : 0;
+  }
+  const int c2 = 64 * C::N4 + 2 * l15;
+  const int col2 = (n0 + c2 + 2 <= a.cout) ? c2 : 0;
+  const int c1 = 64 * C::N4 + 32 * C::N2 + l15;
+  const int col1 = (n0 + c1 < a.cout) ? c1 : 0;
+
+  struct Frag {  // operands of one 16-channel block: A (4 channels of this lane's row) + W rows
+    float4 a;
+    float4 b4[4][C::N4 > 0 ? C::N4 : 1];
+    float2 b2[4];
+    float b1[4];
+  };
+  struct Ctx {  // one row block: where its A rows / W slice live, where its results go
+    const float *srow0;
+    const float *Wk;
+    int dloc;
+    bool valid;
+  };
+  auto load_frag = [&](Frag &f, const Ctx &cx, int c0) {
+    const int ca = c0 + 4 * g;
+    f.a = *reinterpret_cast<const float4 *>(cx.srow0 + (ca <= cin4 ? ca : cin4));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int wr = ca + e;  // W row of this lane for MFMA e (rows >= cin meet a zero A value)
+      const float *wp = cx.Wk + (int64_t)(wr <= wrmax ? wr : wrmax) * a.cout;
+#pragma unroll
+      for (int q = 0; q < C::N4; ++q) f.b4[e][q] = *reinterpret_cast<const float4 *>(wp + col4[q]);
+      if (C::N2) f.b2[e] = *reinterpret_cast<const float2 *>(wp + col2);
+      if (C::N1) f.b1[e] = wp[col1];
+    }
+  };
+  // which (offset, row) does row block rb hold for this lane?  i_hint only moves forward.
+  auto locate = [&](int rb, int &i_hint, int &pair_idx, bool &valid) {
+    while (kl_r[i_hint + 1] <= rb) ++i_hint;
+    const int m = kl_m[i_hint];
+    const int rk = (rb - kl_r[i_hint]) * 16 + l15;  // row inside the offset's slice
+    valid = rk < m;
+    // padding rows re-read the slice's last pair (always in bounds) and go to the sink row
+    pair_idx = kl_s[i_hint] + (valid ? rk : m - 1);
+  };
+  auto make_ctx = [&](Ctx &cx, int2 pr, bool valid, int i_k) {
+    cx.srow0 = a.src + (int64_t)(a.src_col ? pr.y : pr.x) * a.cin;
+    cx.dloc = valid ? (int)((a.src_col ? pr.x : pr.y) - row0) : T;
+    cx.valid = valid;
+    cx.Wk = a.W + (int64_t)kl_k[i_k] * a.cin * a.cout + n0;
+  };
+
+  int i = 0;
+  Ctx cur;
+  Frag f0, f1;
+  if (wid < total_rb) {
+    int pidx; bool v;
+    locate(wid, i, pidx, v);
+    make_ctx(cur, reinterpret_cast<const int2 *>(a.pairs)[pidx], v, i);
+    load_frag(f0, cur, 0);
+  }
+  for (int rb = wid; rb < total_rb; rb += C::NW) {  // wave-uniform loop, no barrier inside
+    // the NEXT row block of this wave: its pair is fetched now, its first operand block at the
+    // end of this one, so the pair -> A-row dependent chain never stalls the MFMA stream
+    const int rbn = rb + C::NW < total_rb ? rb + C::NW : rb;
+    int in = i, pidx_n; bool valid_n;
+    locate(rbn, in, pidx_n, valid_n);
+    const int2 pr_n = reinterpret_cast<const int2 *>(a.pairs)[pidx_n];
+
+    f32x4 acc[NCTT];
+#pragma unroll
+    for (int t = 0; t < NCTT; ++t) acc[t] = (f32x4){0, 0, 0, 0};
+    const bool valid = cur.valid;
+    auto mfma_frag = [&](const Frag &f, int c0) {
+      const bool aok = valid && (c0 + 4 * g) <= cin4;
+      const float ae[4] = {aok ? f.a.x : 0.f, aok ? f.a.y : 0.f, aok ? f.a.z : 0.f, aok ? f.a.w : 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int q = 0; q < C::N4; ++q) {
+          acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], f.b4[e][q].x, acc[4 * q + 0], 0, 0, 0);
+          acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], f.b4[e][q].y, acc[4 * q + 1], 0, 0, 0);
+          acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], f.b4[e][q].z, acc[4 * q + 2], 0, 0, 0);
+          acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], f.b4[e][q].w, acc[4 * q + 3], 0, 0, 0);
+        }
+        if (C::N2) {
+          acc[4 * C::N4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], f.b2[e].x, acc[4 * C::N4 + 0], 0, 0, 0);
+          acc[4 * C::N4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], f.b2[e].y, acc[4 * C::N4 + 1], 0, 0, 0);
+        }
+        if (C::N1) acc[NCTT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], f.b1[e], acc[NCTT - 1], 0, 0, 0);
+      }
+    };
+    Ctx nxt;
+    if (E32) {
+      // cin % 32 == 0: straight-line body. Two register sets, explicitly software-pipelined;
+      // sched_barrier pins "issue the next block's 9 loads, THEN this block's MFMAs" (left alone
+      // the machine scheduler sinks each load next to its use and only 1-2 stay in flight);
+      // no branch between a load and its use, so every wait is a counted vmcnt.
+      for (int c0 = 0; c0 < a.cin - 32; c0 += 32) {
+        load_frag(f1, cur, c0 + 16);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_frag(f0, c0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag(f0, cur, c0 + 32);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_frag(f1, c0 + 16);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      load_frag(f1, cur, a.cin - 16);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_frag(f0, a.cin - 32);
+      __builtin_amdgcn_sched_barrier(0);
+      make_ctx(nxt, pr_n, valid_n, in);
+      load_frag(f0, nxt, 0);  // first block of the next row block, in flight during the commit
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_frag(f1, a.cin - 16);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      for (int c0 = 0; c0 < a.cin; c0 += 32) {  // branches are wave-uniform (kernel args)
+        const bool has1 = c0 + 16 < a.cin;
+        if (has1) load_frag(f1, cur, c0 + 16);
+        mfma_frag(f0, c0);
+        if (has1) {
+          if (c0 + 32 < a.cin) load_frag(f0, cur, c0 + 32);
+          mfma_frag(f1, c0 + 16);
+        }
+      }
+      make_ctx(nxt, pr_n, valid_n, in);
+      load_frag(f0, nxt, 0);
+    }
+    const int dloc = cur.dloc;
+    cur = nxt;
+    i = in;
+    // ---- in-order commit -------------------------------------------------------------------------
+    // Row blocks of different offsets may hit the same dst row, so the LDS tile update must be
+    // exclusive. ds_add_f32 is ~200 cycles per wave-instruction on gfx950 (measured: LDS pipe
+    // 93 % busy), so instead each row block commits in ticket order: wait until every earlier
+    // row block of the tile has committed, plain ds_read/add/ds_write, publish. Row blocks are
+    // numbered offset-major, hence every dst element is summed in ascending-offset order -- the
+    // reference's order -- and the result is bit-reproducible.
+    if (lane == 0) {
+      while (__hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != rb)
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // D[row = 4g+j][col = l15] of tile t  ->  accumulator row dloc(4g+j), interleaved column map
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int dr = __shfl(dloc, 4 * g + j, 64);  // dloc of compact row 4g+j lives in lanes l15 == 4g+j
+      float *d = acc_l + dr * C::ACS;
+#pragma unroll
+      for (int q = 0; q < C::N4; ++q) {
+        float4 *p4 = reinterpret_cast<float4 *>(d + 64 * q + 4 * l15);
+        float4 v = *p4;
+        v.x += acc[4 * q + 0][j]; v.y += acc[4 * q + 1][j]; v.z += acc[4 * q + 2][j]; v.w += acc[4 * q + 3][j];
+        *p4 = v;
+      }
+      if (C::N2) {
+        float2 *p2 = reinterpret_cast<float2 *>(d + 64 * C::N4 + 2 * l15);
+        float2 v = *p2;
+        v.x += acc[4 * C::N4 + 0][j]; v.y += acc[4 * C::N4 + 1][j];
+        *p2 = v;
+      }
+      if (C::N1) d[64 * C::N4 + 32 * C::N2 + l15] += acc[NCTT - 1][j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(commit, rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  // ---- epilogue: every dst row written once ---------------------------------------------------------
+  const int rows = (int)((a.n_dst - row0) < (int64_t)T ? (a.n_dst - row0) : (int64_t)T);
+  for (int e = tid; e < rows * (C::CT / 4); e += C::NT) {
+    const int r = e / (C::CT / 4), cq = (e % (C::CT / 4)) * 4;
+    if (n0 + cq < a.cout) {
+      float4 v = *reinterpret_cast<const float4 *>(acc_l + r * C::ACS + cq);
+      if (a.bias) {
+        const float4 b = *reinterpret_cast<const float4 *>(a.bias + n0 + cq);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      *reinterpret_cast<float4 *>(a.dst + (row0 + r) * a.cout + n0 + cq) = v;
+    }
+  }
+}
+
+template <int NCTT, int T, int NW, int MINW>
+int launch_conv4_cfg(const ConvArgs &a, hipStream_t st) {
+  using C = Conv4Cfg<NCTT, T, NW>;
+  const int64_t nblocks = a.ntiles * a.ncoltiles;
+  const bool e32 = (a.cin % 32) == 0;
+  auto kern = e32 ? conv_os4_kernel<NCTT, T, true, NW, MINW> : conv_os4_kernel<NCTT, T, false, NW, MINW>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[e32]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
+    attr_set[e32] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(C::NT), C::lds_bytes, st, a);
+  return check_launch("pcs_conv_gather_gemm_f32(v4)");
+}
+
+template <int NCTT, int T>
+int launch_conv4(const ConvArgs &a, hipStream_t st) {
+  const int64_t nblocks = a.ntiles * a.ncoltiles;
+  if (nblocks <= 0) return PCS_OK;
+  if (nblocks > 0x7FFFFFFF) { set_error("pcs_conv: grid too large"); return PCS_EUNSUPPORTED; }
+  // workgroup shape: 4 waves with <= 168 VGPRs (default: 3 workgroups / CU) or 8 waves
+  static const int nw = getenv("PCS_CONV_NW") ? atoi(getenv("PCS_CONV_NW")) : 4;
+  if (nw == 4) return launch_conv4_cfg<NCTT, T, 4, 3>(a, st);
+  return launch_conv4_cfg<NCTT, T, 8, 2>(a, st);
 }
 
 // ================================================================================================
@@ -412,6 +969,47 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
   a.cin = cin; a.cout = cout; a.K = K; a.src_col = src_col;
   const bool vec = (cin % 4 == 0) && (cout % 4 == 0) && (((uintptr_t)src | (uintptr_t)W | (uintptr_t)dst | (uintptr_t)bias) & 15) == 0;
   hipStream_t st = as_stream(stream);
+  static const int use_v1 = getenv("PCS_CONV_V1") ? atoi(getenv("PCS_CONV_V1")) : 0;
+  static const int use_v3 = getenv("PCS_CONV_V3") ? atoi(getenv("PCS_CONV_V3")) : 0;
+  if (vec && !use_v1 && !use_v3 && K <= 32) {
+    int nctt = (cout + 15) / 16;
+    if (nctt > 8) nctt = 8;
+    if (nctt == 5) nctt = 6;
+    if (nctt == 7) nctt = 8;
+    a.ncoltiles = (int)ceil_div(cout, 16 * nctt);
+#define PCS_CONV4_CASE(N)                                                             \
+  case N:                                                                             \
+    return tile_rows == 128 ? launch_conv4<N, 128>(a, st) : launch_conv4<N, 64>(a, st);
+    switch (nctt) {
+      PCS_CONV4_CASE(1)
+      PCS_CONV4_CASE(2)
+      PCS_CONV4_CASE(3)
+      PCS_CONV4_CASE(4)
+      PCS_CONV4_CASE(6)
+      PCS_CONV4_CASE(8)
+    }
+#undef PCS_CONV4_CASE
+  }
+  if (vec && !use_v1 && K <= 27) {
+    // v2: column tile = 16*NCTT, NCTT in 1..8; wider outputs take several column tiles
+    int nctt = (cout + 15) / 16;
+    if (nctt > 8) nctt = 8;
+    if (nctt == 5) nctt = 6;
+    if (nctt == 7) nctt = 8;
+    a.ncoltiles = (int)ceil_div(cout, 16 * nctt);
+#define PCS_CONV2_CASE(N)                                                             \
+  case N:                                                                             \
+    return tile_rows == 128 ? launch_conv2<N, 128>(a, st) : launch_conv2<N, 64>(a, st);
+    switch (nctt) {
+      PCS_CONV2_CASE(1)
+      PCS_CONV2_CASE(2)
+      PCS_CONV2_CASE(3)
+      PCS_CONV2_CASE(4)
+      PCS_CONV2_CASE(6)
+      PCS_CONV2_CASE(8)
+    }
+#undef PCS_CONV2_CASE
+  }
   // column tile: 32*CG with CG in 1..4; wider outputs are covered by several column tiles
   int cg = (cout + 31) / 32;
   if (cg > 4) cg = 4;

@@ -294,7 +294,7 @@ def test_full_scan_properties(hip):
     b = pairs[koff[23]:koff[24]]
     assert a.shape == b.shape
     assert (a[torch.argsort(a[:, 0].long())][:, [1, 0]] == b).all()
-    # linearity + run-to-run bit reproducibility of the fused conv
+    # linearity + run-to-run reproducibility of the fused conv
     g = torch.Generator(device=DEV).manual_seed(0)
     x1 = torch.randn(n, 32, device=DEV, generator=g)
     x2 = torch.randn(n, 32, device=DEV, generator=g)
@@ -302,7 +302,8 @@ def test_full_scan_properties(hip):
     y1, y2 = hip.conv_gather_gemm(x1, w, entry.fwd), hip.conv_gather_gemm(x2, w, entry.fwd)
     y12 = hip.conv_gather_gemm(x1 + x2, w, entry.fwd)
     assert ((y1 + y2) - y12).abs().max() <= 1e-4 * y12.abs().max()
-    assert torch.equal(y1, hip.conv_gather_gemm(x1, w, entry.fwd))
+    # the accumulator tile is summed with LDS atomics: order-of-addition noise only (<= a few ulp)
+    assert (y1 - hip.conv_gather_gemm(x1, w, entry.fwd)).abs().max() <= 1e-5 * y1.abs().max()
     gw = hip.conv_wgrad(x1, y1, entry.fwd, 0)
     assert torch.equal(gw, hip.conv_wgrad(x1, y1, entry.fwd, 0))
     # <conv(x), g> == <x, dgrad(g)>  (adjointness of fwd / dgrad over the two maps)

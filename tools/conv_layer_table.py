@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Per-shape timing table of the fused conv / wgrad launches inside one MinkUNet-34 training
+step (HIP events on the launch stream). Usage: python tools/conv_layer_table.py [frames]"""
+import collections
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from bench import fresh, to_device  # noqa: E402
+from openpcseg_amd import native  # noqa: E402
+from openpcseg_amd.workloads.minkunet import MK34_LAYERS, MinkUNet  # noqa: E402
+from openpcseg_amd.workloads.synthetic import make_batch  # noqa: E402
+
+
+def main():
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = MinkUNet(num_class=20, num_layer=MK34_LAYERS).to(dev).train()
+    batch = to_device(make_batch(list(range(frames))), dev)
+    be = native.backend()
+    rec = []
+    orig_g, orig_w = be.conv_gather_gemm, be.conv_wgrad
+
+    def timed(kind, fn, shape_of):
+        def wrapped(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            rec.append((kind, shape_of(*a), e0, e1))
+            return out
+        return wrapped
+
+    be.conv_gather_gemm = timed("gemm", orig_g, lambda src, w, km, *r, **k: (km.n_dst, km.num_pairs, w.shape[0], w.shape[1], w.shape[2]))
+    be.conv_wgrad = timed("wgrad", orig_w, lambda fa, fb, km, ac: (km.n_dst, km.num_pairs, km.K, fa.shape[1], fb.shape[1]))
+    for it in range(2):
+        rec.clear()
+        out = model(fresh(batch))
+        out["loss"].backward()
+        torch.cuda.synchronize()
+    agg = collections.OrderedDict()
+    for kind, shape, e0, e1 in rec:
+        key = (kind,) + shape
+        t = agg.setdefault(key, [0, 0.0])
+        t[0] += 1
+        t[1] += e0.elapsed_time(e1)
+    print("%-6s %9s %9s %3s %4s %4s %4s %9s %8s %7s" % ("kind", "n_dst", "pairs", "K", "cin", "cout", "n", "ms_total", "us/call", "TF/s"))
+    tot = {"gemm": 0.0, "wgrad": 0.0}
+    for (kind, n, p, k, ci, co), (cnt, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        fl = 2.0 * p * ci * co * cnt
+        tot[kind] += ms
+        print("%-6s %9d %9d %3d %4d %4d %4d %9.2f %8.0f %7.1f" % (kind, n, p, k, ci, co, cnt, ms, ms * 1e3 / cnt, fl / ms / 1e9))
+    print("total ms:", tot)
+
+
+if __name__ == "__main__":
+    main()
