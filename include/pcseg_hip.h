@@ -102,6 +102,14 @@ int pcs_devoxelize_fwd_f32(const float *feat, const int32_t *idx8, const float *
 int pcs_devoxelize_bwd_f32(const float *gout, const int32_t *idx8, const float *w8, int64_t n,
                            int64_t m, int32_t c, float *gfeat, void *stream);
 
+/* K10 without atomics: the same sum as pcs_devoxelize_bwd_f32, as a per-voxel segmented
+ * reduction. order (E,) int64 = flat positions i*8+k of the VALID (idx >= 0) entries of idx8,
+ * sorted by voxel; rowptr (m+1,) int64 = start of each voxel's run in `order`. Every gfeat row
+ * is written once, in `order` order (deterministic). The caller builds order/rowptr once per
+ * idx8 (one sort) and reuses them for every backward through the same map. */
+int pcs_devoxelize_bwd_csr_f32(const float *gout, const int64_t *order, const int64_t *rowptr,
+                               const float *w8, int64_t m, int32_t c, float *gfeat, void *stream);
+
 /* calc_ti_weights  TS:torchsparse/nn/functional/devoxelize.py:10-48  (about 25 small torch
  * kernels in the reference, one kernel here). coords (n, coord_ld) fp32 (first 3 columns
  * used), idx_query (8,n) int64 (-1 = miss), -> w (8,n) fp32: trilinear corner weights in

@@ -931,12 +931,142 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
   }
 }
 
-int wgrad_plan(const int32_t *koff_host, int K, int *pch_out) {
-  // aim for ~2048 splits in total, at least 256 pairs per split
+// ================================================================================================
+// wgrad v2: wave-autonomous, operands straight from HBM/L2 into MFMA layout, no LDS, no barrier.
+//   gW[k][a][b] = sum over the pairs p of offset k:  fa[ia_p][a] * fb[ib_p][b]
+// MFMA 16x16x4 with the PAIR axis as the contraction: lane (n = lane&15, g = lane>>4) holds, for
+// pair 4j+g, the 16-byte pieces fa[ia][a0+4n .. +3] and fb[ib][b0+4n .. +3]; component f of the
+// A piece and component h of the B piece feed output tile (f,h), whose rows/cols are the
+// interleaved channels {a0+4i+f} x {b0+4n+h}. One 64x64 output block = 16 tiles = 16 MFMAs per
+// TWO 16-byte loads per lane. A workgroup = 4 waves = 4 output blocks of one (offset, pair chunk)
+// split; partial blocks go to the workspace and wgrad_reduce_kernel sums the splits in order.
+// ================================================================================================
+struct Wgrad2Args {
+  const float *fa;
+  const float *fb;
+  const int32_t *pairs;
+  const int32_t *koff;
+  float *partial;  // [nsplit_total][ca][cb]
+  int ca, cb, K, a_col, pch, nbg;  // nbg = number of b-groups
+};
+
+__host__ __device__ inline int wg_ngroups(int c) { return (c + 63) / 64; }
+// width class of group gi (0-based) of a c-channel operand: 64, 32 or 16 columns of MFMA tiles
+__host__ __device__ inline int wg_gwidth(int c, int gi) {
+  const int rem = c - 64 * gi;
+  return rem > 32 ? 64 : (rem > 16 ? 32 : 16);
+}
+
+template <int W> struct WVec;
+template <> struct WVec<64> { using T = float4; static constexpr int N = 4; };
+template <> struct WVec<32> { using T = float2; static constexpr int N = 2; };
+template <> struct WVec<16> { using T = float;  static constexpr int N = 1; };
+__device__ __forceinline__ float wcomp(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+__device__ __forceinline__ float wcomp(const float2 &v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ float wcomp(const float &v, int) { return v; }
+
+template <int AW, int BW>
+__device__ __forceinline__ void wgrad_block(const Wgrad2Args &w, int a0, int b0, int beg, int end,
+                                            float *out, int lane) {
+  using AV = typename WVec<AW>::T;
+  using BV = typename WVec<BW>::T;
+  constexpr int NA = WVec<AW>::N, NB = WVec<BW>::N;
+  const int g = lane >> 4, l15 = lane & 15;
+  // per-lane channel offsets, clamped inside the row; out-of-range channels are zeroed by select
+  const int ac = a0 + NA * l15, bc = b0 + NB * l15;
+  const bool aok = ac + NA <= w.ca, bok = bc + NB <= w.cb;
+  const int acl = aok ? ac : 0, bcl = bok ? bc : 0;
+  f32x4 acc[NA][NB];
+#pragma unroll
+  for (int f = 0; f < NA; ++f)
+#pragma unroll
+    for (int h = 0; h < NB; ++h) acc[f][h] = (f32x4){0, 0, 0, 0};
+
+  struct Batch { AV a[4]; BV b[4]; };  // 16 pairs = 4 k-groups of 4 pairs
+  auto load_batch = [&](Batch &bt, int p0) {
+    // lane l15 fetches pair p0+l15 (clamped to the chunk), k-group j uses the pair held by lane 4j+g
+    int pi = p0 + l15;
+    pi = pi < end ? pi : end - 1;
+    const int2 pr = reinterpret_cast<const int2 *>(w.pairs)[pi];
+    const int ia = w.a_col ? pr.y : pr.x, ib = w.a_col ? pr.x : pr.y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ra = __shfl(ia, 4 * j + g, 64), rb = __shfl(ib, 4 * j + g, 64);
+      bt.a[j] = *reinterpret_cast<const AV *>(w.fa + (int64_t)ra * w.ca + acl);
+      bt.b[j] = *reinterpret_cast<const BV *>(w.fb + (int64_t)rb * w.cb + bcl);
+    }
+  };
+  auto mfma_batch = [&](const Batch &bt, int p0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool pv = aok && (p0 + 4 * j + g) < end;  // tail pairs / padded channels contribute 0
+#pragma unroll
+      for (int f = 0; f < NA; ++f) {
+        const float av = pv ? wcomp(bt.a[j], f) : 0.f;
+#pragma unroll
+        for (int h = 0; h < NB; ++h)
+          acc[f][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wcomp(bt.b[j], h), acc[f][h], 0, 0, 0);
+      }
+    }
+  };
+  Batch b0s, b1s;
+  load_batch(b0s, beg);
+  for (int p0 = beg; p0 < end; p0 += 32) {
+    const int p1 = p0 + 16 < end ? p0 + 16 : p0;  // clamped: a redundant batch is masked out below
+    load_batch(b1s, p1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_batch(b0s, p0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int p2 = p0 + 32 < end ? p0 + 32 : p0;
+    load_batch(b0s, p2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (p0 + 16 < end) mfma_batch(b1s, p0 + 16);  // wave-uniform
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // tile (f,h), register r: row a0 + 4*(4g+r) + f, column b0 + 4*l15 + h  -> NB-wide stores
+#pragma unroll
+  for (int f = 0; f < NA; ++f) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = a0 + NA * (4 * g + r) + f;
+      if (row < w.ca && bok) {
+        float *d = out + (int64_t)row * w.cb + bc;
+#pragma unroll
+        for (int h = 0; h < NB; ++h) d[h] = acc[f][h][r];
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256, 3) wgrad2_kernel(Wgrad2Args w) {
+  __shared__ int sh[3];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) find_split(w.koff, w.K, w.pch, blockIdx.x, &sh[0], &sh[1], &sh[2]);
+  __syncthreads();
+  const int beg = sh[1], end = sh[2];
+  const int blk = blockIdx.y * 4 + wid;  // output block of this wave
+  const int nag = wg_ngroups(w.ca);
+  if (beg >= end || blk >= nag * w.nbg) return;
+  const int ag = blk / w.nbg, bg = blk - ag * w.nbg;
+  const int aw = wg_gwidth(w.ca, ag), bw = wg_gwidth(w.cb, bg);
+  float *out = w.partial + (int64_t)blockIdx.x * w.ca * w.cb;
+  const int a0 = 64 * ag, b0 = 64 * bg;
+#define PCS_WG_CASE(A, B) if (aw == A && bw == B) { wgrad_block<A, B>(w, a0, b0, beg, end, out, lane); return; }
+  PCS_WG_CASE(64, 64) PCS_WG_CASE(64, 32) PCS_WG_CASE(64, 16)
+  PCS_WG_CASE(32, 64) PCS_WG_CASE(32, 32) PCS_WG_CASE(32, 16)
+  PCS_WG_CASE(16, 64) PCS_WG_CASE(16, 32) PCS_WG_CASE(16, 16)
+#undef PCS_WG_CASE
+}
+
+int wgrad_plan(const int32_t *koff_host, int K, int ca, int cb, int *pch_out) {
+  // ~3072 workgroups in total (each = 4 output blocks of one split), >= 64 pairs per split
+  const int nbq = (wg_ngroups(ca) * wg_ngroups(cb) + 3) / 4;
   int64_t P = koff_host[K] - koff_host[0];
-  int pch = (int)ceil_div(P > 0 ? P : 1, 2048);
-  pch = (int)(ceil_div(pch, WG_PB) * WG_PB);
-  if (pch < 256) pch = 256;
+  int64_t target = 3072 / nbq;
+  if (target < K) target = K;
+  int pch = (int)ceil_div(P > 0 ? P : 1, target);
+  pch = (int)(ceil_div(pch, 32) * 32);
+  if (pch < 64) pch = 64;
   int64_t ns = 0;
   for (int k = 0; k < K; ++k) ns += ceil_div((int64_t)koff_host[k + 1] - koff_host[k], pch);
   *pch_out = pch;
@@ -1033,7 +1163,7 @@ extern "C" size_t pcs_conv_wgrad_ws_bytes(const int32_t *koff_host, int32_t K, i
                                           int32_t cb) {
   if (!koff_host || K <= 0 || ca <= 0 || cb <= 0) return 0;
   int pch;
-  const int ns = wgrad_plan(koff_host, K, &pch);
+  const int ns = wgrad_plan(koff_host, K, ca, cb, &pch);
   return (size_t)(ns > 0 ? ns : 1) * ca * cb * sizeof(float);
 }
 
@@ -1047,7 +1177,7 @@ extern "C" int pcs_conv_wgrad_f32(const float *fa, int32_t ca, const float *fb, 
   }
   hipStream_t st = as_stream(stream);
   int pch;
-  const int ns = wgrad_plan(koff_host, K, &pch);
+  const int ns = wgrad_plan(koff_host, K, ca, cb, &pch);
   const int64_t cc = (int64_t)ca * cb;
   if (ns == 0) {
     if (hipMemsetAsync(gW, 0, (size_t)K * cc * 4, st) != hipSuccess) { set_error("pcs_conv_wgrad_f32: memset failed"); return PCS_ELAUNCH; }
@@ -1059,9 +1189,18 @@ extern "C" int pcs_conv_wgrad_f32(const float *fa, int32_t ca, const float *fb, 
   w.fa = fa; w.fb = fb; w.pairs = pairs; w.koff = koff_dev; w.partial = reinterpret_cast<float *>(ws);
   w.ca = ca; w.cb = cb; w.K = K; w.a_col = a_col; w.pch = pch;
   const bool vec = (ca % 4 == 0) && (cb % 4 == 0) && (((uintptr_t)fa | (uintptr_t)fb) & 15) == 0;
-  dim3 grid((unsigned)ns, (unsigned)ceil_div(ca, 128), (unsigned)ceil_div(cb, 128));
-  if (vec) hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(256), 0, st, w);
-  else hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(256), 0, st, w);
+  static const int use_v1 = getenv("PCS_WGRAD_V1") ? atoi(getenv("PCS_WGRAD_V1")) : 0;
+  if (vec && !use_v1) {
+    Wgrad2Args w2;
+    w2.fa = fa; w2.fb = fb; w2.pairs = pairs; w2.koff = koff_dev; w2.partial = reinterpret_cast<float *>(ws);
+    w2.ca = ca; w2.cb = cb; w2.K = K; w2.a_col = a_col; w2.pch = pch; w2.nbg = wg_ngroups(cb);
+    const int nblk = wg_ngroups(ca) * wg_ngroups(cb);
+    hipLaunchKernelGGL(wgrad2_kernel, dim3((unsigned)ns, (unsigned)ceil_div(nblk, 4)), dim3(256), 0, st, w2);
+  } else {
+    dim3 grid((unsigned)ns, (unsigned)ceil_div(ca, 128), (unsigned)ceil_div(cb, 128));
+    if (vec) hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(256), 0, st, w);
+    else hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(256), 0, st, w);
+  }
   int rc = check_launch("pcs_conv_wgrad_f32");
   if (rc) return rc;
   int gx = (int)ceil_div(cc, 256);

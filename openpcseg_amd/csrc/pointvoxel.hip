@@ -180,18 +180,44 @@ __global__ void __launch_bounds__(256) ti_weights_kernel(const float *__restrict
   }
 }
 
-}  // namespace
+// ---- K10, contention-free form: per-voxel segmented reduction over a CSR of the (point, corner)
+// entries. entries sorted by voxel: order[e] = flat index i*8+k into idx8/w8; rowptr (m+1).
+// One row of TX lanes per voxel; every gfeat row is written exactly once (no memset, no atomics,
+// deterministic). The reference's atomicAdd form (devoxelize_cuda.cu:37-57) serialises badly when
+// thousands of points share a coarse voxel (stride 16: ~250 entries per voxel).
+template <int V>
+__global__ void __launch_bounds__(256) devoxelize_bwd_csr_kernel(const float *__restrict__ gout,
+                                                                 const int64_t *__restrict__ order,
+                                                                 const int64_t *__restrict__ rowptr,
+                                                                 const float *__restrict__ w8,
+                                                                 int64_t m, int c, int cv,
+                                                                 float *__restrict__ gfeat) {
+  using VT = typename Vec<V>::T;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; v < m;
+       v += (int64_t)gridDim.x * blockDim.y) {
+    const int64_t e0 = rowptr[v], e1 = rowptr[v + 1];
+    VT *dst = reinterpret_cast<VT *>(gfeat + v * c);
+    for (int j = threadIdx.x; j < cv; j += blockDim.x) {
+      VT acc; vzero(acc);
+      int64_t e = e0;
+      for (; e + 1 < e1; e += 2) {  // two independent row loads in flight
+        const int64_t p0 = order[e], p1 = order[e + 1];
+        const float w0 = w8[p0], w1 = w8[p1];
+        const VT g0 = reinterpret_cast<const VT *>(gout + (p0 >> 3) * c)[j];
+        const VT g1 = reinterpret_cast<const VT *>(gout + (p1 >> 3) * c)[j];
+        acc = vfma(w0, g0, acc);
+        acc = vfma(w1, g1, acc);
+      }
+      if (e < e1) {
+        const int64_t p0 = order[e];
+        acc = vfma(w8[p0], reinterpret_cast<const VT *>(gout + (p0 >> 3) * c)[j], acc);
+      }
+      dst[j] = acc;
+    }
+  }
+}
 
-#define PV_DISPATCH(KERNEL, N_ROWS, C, ...)                                                  \
-  do {                                                                                       \
-    if (((C) & 3) == 0) {                                                                    \
-      RowLaunch rl = row_launch<4>((N_ROWS), (C));                                           \
-      hipLaunchKernelGGL(KERNEL<4>, rl.grid, rl.block, 0, st, __VA_ARGS__, rl.cv);           \
-    } else {                                                                                 \
-      RowLaunch rl = row_launch<1>((N_ROWS), (C));                                           \
-      hipLaunchKernelGGL(KERNEL<1>, rl.grid, rl.block, 0, st, __VA_ARGS__, rl.cv);           \
-    }                                                                                        \
-  } while (0)
+}  // namespace
 
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -279,4 +305,21 @@ extern "C" int pcs_ti_weights_f32(const float *coords, int32_t coord_ld, const i
   hipLaunchKernelGGL(ti_weights_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream),
                      coords, coord_ld, idx_query, n, scale, inv_s3, scaled, w);
   return check_launch("pcs_ti_weights");
+}
+
+extern "C" int pcs_devoxelize_bwd_csr_f32(const float *gout, const int64_t *order,
+                                          const int64_t *rowptr, const float *w8, int64_t m,
+                                          int32_t c, float *gfeat, void *stream) {
+  if (m < 0 || c <= 0) { set_error("pcs_devoxelize_bwd_csr: bad sizes"); return PCS_EINVAL; }
+  if (m == 0) return PCS_OK;
+  if (!gout || !order || !rowptr || !w8 || !gfeat) { set_error("pcs_devoxelize_bwd_csr: null pointer"); return PCS_EINVAL; }
+  hipStream_t st = as_stream(stream);
+  if ((c & 3) == 0 && aligned16(gout) && aligned16(gfeat)) {
+    RowLaunch rl = row_launch<4>(m, c);
+    hipLaunchKernelGGL(devoxelize_bwd_csr_kernel<4>, rl.grid, rl.block, 0, st, gout, order, rowptr, w8, m, c, rl.cv, gfeat);
+  } else {
+    RowLaunch rl = row_launch<1>(m, c);
+    hipLaunchKernelGGL(devoxelize_bwd_csr_kernel<1>, rl.grid, rl.block, 0, st, gout, order, rowptr, w8, m, c, rl.cv, gfeat);
+  }
+  return check_launch("pcs_devoxelize_bwd_csr");
 }

@@ -29,6 +29,7 @@ SIGNATURES = {
     "pcs_voxelize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P]),
     "pcs_devoxelize_fwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P]),
     "pcs_devoxelize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int64, c_int32, _P, _P]),
+    "pcs_devoxelize_bwd_csr_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, _P, _P]),
     "pcs_ti_weights_f32": (c_int32, [_P, c_int32, _P, c_int64, c_float, _P, _P]),
     "pcs_downsample_pack": (c_int32, [_P, c_int64, _P, c_int32, _P, c_int32, _P, _P, _P, _P]),
     "pcs_downsample_unpack": (c_int32, [_P, c_int64, _P, _P]),
@@ -208,6 +209,25 @@ class HipBackend:
         return out
 
     def devoxelize_bwd(self, gout, idx8, w8, m):
+        """gfeat[v] = sum over (point i, corner k) with idx8[i,k] == v of w8[i,k] * gout[i].
+        Contention-free: entries sorted by voxel once per idx8 tensor (cached on the tensor; the
+        same map serves every backward of one forward), then a segmented reduction."""
+        gout = _dev(gout, "grad_output", torch.float32)
+        n, c = gout.shape
+        csr = getattr(idx8, "_pcs_csr", None)
+        if csr is None or csr[2] != m:
+            flat = idx8.reshape(-1)
+            vals, order = torch.sort(flat)
+            rowptr = torch.searchsorted(vals, torch.arange(m + 1, device=flat.device, dtype=vals.dtype))
+            csr = (order.contiguous(), rowptr.contiguous(), m)
+            idx8._pcs_csr = csr
+        gfeat = torch.empty((m, c), dtype=torch.float32, device=gout.device)
+        _check(self.lib.pcs_devoxelize_bwd_csr_f32(_ptr(gout), _ptr(csr[0]), _ptr(csr[1]), _ptr(w8), m, c,
+                                                   _ptr(gfeat), _stream()), "pcs_devoxelize_bwd_csr_f32")
+        return gfeat
+
+    def devoxelize_bwd_atomic(self, gout, idx8, w8, m):
+        """The reference's literal K10 dataflow (fp32 atomics); kept for A/B measurements."""
         gout = _dev(gout, "grad_output", torch.float32)
         n, c = gout.shape
         gfeat = torch.empty((m, c), dtype=torch.float32, device=gout.device)
