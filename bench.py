@@ -53,7 +53,9 @@ class ConvMeter:
             out = self.orig(src, weight, kmap, bias, tile_rows)
             e1.record()
             k, cin, cout = weight.shape
-            self.records.append((e0, e1, 2.0 * kmap.num_pairs * cin * cout))
+            p = kmap.num_pairs
+            self.records.append((e0, e1, 2.0 * p * cin * cout,
+                                 4.0 * (src.shape[0] * cin + kmap.n_dst * cout) + 8.0 * p + 4.0 * k * cin * cout))
             return out
         self.be.conv_gather_gemm = wrapped
         return self
@@ -64,15 +66,22 @@ class ConvMeter:
     def summary(self):
         if not self.records:
             return None
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
-        flops = sum(f for _, _, f in self.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        flops = sum(r[2] for r in self.records)
+        abytes = sum(r[3] for r in self.records)
         n = len(self.records)
         achieved = flops / (ms * 1e-3) / 1e12
-        return {"kernel": "conv_os_kernel (pcs_conv_gather_gemm_f32: fwd + dgrad)", "bound": "mfma",
+        traffic = None  # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside bench.py)
+        tfile = os.path.join(ROOT, "profiles", "round1_conv_traffic.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        return {"kernel": "conv_os4_kernel (pcs_conv_gather_gemm_f32: fwd + dgrad)", "bound": "mfma",
                 "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, FETCH "
+                                "doubled per the gfx950 note), profiles/round1_conv_traffic.json",
                 "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
-                "flops_per_launch": round(flops / n)}
+                "flops_per_launch": round(flops / n), "algorithmic_bytes_per_launch": round(abytes / n)}
 
 
 def to_device(batch, dev):
@@ -86,33 +95,55 @@ def fresh(b):
     return {"lidar": SparseTensor(b["lidar"].F, b["lidar"].C), "targets": SparseTensor(b["targets"].F, b["targets"].C)}
 
 
-def cpu_baseline(n_points=8000):
-    """The reference's own compiled CPU backend (oracle/_ref) under the same MinkUNet-34
-    training step, on a bounded sample: ONE frame subsampled to n_points rays."""
+CPU_BASELINE_THREADS = 8      # the reference's CPU code forks an OpenMP team per row: more threads = slower
+CPU_BASELINE_POINTS = 4000    # bounded sample: ~10-20 s of CPU work
+CPU_BASELINE_TIMEOUT_S = 150  # hard cap; the default bench run must finish within minutes
+
+
+def _cpu_baseline_worker(n_points):
+    """Runs in a subprocess (OMP_NUM_THREADS fixed before any OpenMP runtime starts): the reference's own
+    compiled CPU backend (oracle/_ref) under the same MinkUNet-34 training step on ONE subsampled frame."""
+    torch.set_num_threads(CPU_BASELINE_THREADS)
     try:
         from oracle.adapter import RefBackend
-        ref = RefBackend()
-        kind = "reference"
+        ref, kind = RefBackend(), "reference"
     except Exception:
         from oracle.adapter import OracleBackend
         ref, kind = OracleBackend(), "port"
-    saved = native._BACKEND
     native._BACKEND = ref  # cpu_baseline leg only: the thing timed here IS the CPU reference
+    torch.manual_seed(0)
+    model = MinkUNet(num_class=20, num_layer=MK34_LAYERS, cr=1.0).train()
+    b = make_batch([0], n_points=n_points)
+    batch = {"lidar": SparseTensor(b["lidar"].F, b["lidar"].C), "targets": SparseTensor(b["targets"].F, b["targets"].C)}
+    t0 = time.perf_counter()
+    out = model(batch)
+    out["loss"].backward()
+    dt = time.perf_counter() - t0
+    cores = CPU_BASELINE_THREADS if kind == "reference" else 1
+    print(json.dumps({"value": round((n_points / POINTS_PER_FRAME) / dt, 5), "unit": "frames/s", "cores": cores,
+                      "kind": kind,
+                      "sample": "1 frame subsampled to %d of 120000 rays, MinkUNet-34 cr1.0 fwd+bwd once (%.1f s, "
+                                "%d OpenMP threads), scaled linearly in points to full-frame frames/s"
+                                % (n_points, dt, CPU_BASELINE_THREADS)}), flush=True)
+
+
+def cpu_baseline():
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS=str(CPU_BASELINE_THREADS), MKL_NUM_THREADS=str(CPU_BASELINE_THREADS),
+               HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
     try:
-        torch.manual_seed(0)
-        model = MinkUNet(num_class=20, num_layer=MK34_LAYERS, cr=1.0).train()
-        b = make_batch([0], n_points=n_points)
-        batch = {"lidar": SparseTensor(b["lidar"].F, b["lidar"].C), "targets": SparseTensor(b["targets"].F, b["targets"].C)}
-        t0 = time.perf_counter()
-        out = model(batch)
-        out["loss"].backward()
-        dt = time.perf_counter() - t0
-    finally:
-        native._BACKEND = saved
-    cores = torch.get_num_threads() if kind == "reference" else 1
-    return {"value": round((n_points / POINTS_PER_FRAME) / dt, 5), "unit": "frames/s", "cores": cores, "kind": kind,
-            "sample": "1 frame subsampled to %d of 120000 rays, MinkUNet-34 cr1.0 fwd+bwd once (%.1f s), "
-                      "scaled linearly in points to full-frame frames/s" % (n_points, dt)}
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(CPU_BASELINE_POINTS)],
+                           env=env, capture_output=True, text=True, timeout=CPU_BASELINE_TIMEOUT_S)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if line:
+            return json.loads(line[-1])
+        return {"value": None, "unit": "frames/s", "cores": CPU_BASELINE_THREADS, "kind": "reference",
+                "sample": "cpu baseline worker failed: " + (r.stderr.strip().splitlines() or ["?"])[-1][:200]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "frames/s", "cores": CPU_BASELINE_THREADS, "kind": "reference",
+                "sample": "cpu baseline exceeded the %d s cap on this host" % CPU_BASELINE_TIMEOUT_S}
 
 
 def main():
@@ -122,7 +153,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-gpu", type=int, default=12)  # BATCH_SIZE_PER_GPU of minkunet_mk34_cr10.yaml
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        _cpu_baseline_worker(args.cpu_baseline_worker)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -39,7 +39,7 @@ struct ConvArgs {
   const int32_t *seg;
   int64_t n_dst;
   int64_t ntiles;
-  int cin, cout, K, src_col, ncoltiles;
+  int cin, cout, K, src_col, ncoltiles, xcd_remap;
 };
 
 template <int CG, int RG, int T>
@@ -517,8 +517,16 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os4_kernel(ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
-  const int64_t tile = blockIdx.x / a.ncoltiles;
-  const int ctile = blockIdx.x % a.ncoltiles;
+  // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (observed dispatch order, speed only).
+  // Give every XCD one CONTIGUOUS range of tiles so that neighbouring tiles -- which gather
+  // overlapping src rows -- share that XCD's L2 (bijective remap for any grid size).
+  unsigned bid = blockIdx.x;
+  if (a.xcd_remap) {
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int64_t tile = bid / a.ncoltiles;
+  const int ctile = bid % a.ncoltiles;
   const int n0 = ctile * C::CT;
   const int64_t row0 = tile * T;
   const int64_t nt1 = a.ntiles + 1;
@@ -1097,6 +1105,8 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
   a.src = src; a.W = W; a.bias = bias; a.dst = dst; a.pairs = pairs; a.seg = seg;
   a.n_dst = n_dst; a.ntiles = ceil_div(n_dst, tile_rows);
   a.cin = cin; a.cout = cout; a.K = K; a.src_col = src_col;
+  static const int xcd = getenv("PCS_CONV_XCD") ? atoi(getenv("PCS_CONV_XCD")) : 1;
+  a.xcd_remap = xcd;
   const bool vec = (cin % 4 == 0) && (cout % 4 == 0) && (((uintptr_t)src | (uintptr_t)W | (uintptr_t)dst | (uintptr_t)bias) & 15) == 0;
   hipStream_t st = as_stream(stream);
   static const int use_v1 = getenv("PCS_CONV_V1") ? atoi(getenv("PCS_CONV_V1")) : 0;
