@@ -202,6 +202,35 @@ int pcs_conv_wgrad_f32(const float *fa, int32_t ca, const float *fb, int32_t cb,
                        const int32_t *koff_host, int32_t K, float *gW, void *ws,
                        size_t ws_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Cylindrical scatter: torch_scatter.scatter_max(src, index, dim=0) as called by the reference's
+ * cylinder front-end (R:tools/utils/common/seg_utils.py:178,
+ * R:pcseg/model/segmentor/voxel/cylinder3d/cylinder_ts.py:35). torch_scatter is a third-party,
+ * version-unpinned dependency that is not under /root/reference: PARITY UNPINNED (semantics
+ * restated: per-voxel channel-wise max, argmax saved for backward, empty voxel -> 0 / -1).
+ * Segmented form: order (E,) int64 = point ids sorted by voxel, rowptr (m+1,) int64.
+ * (scatter_mean of the same front-end is pcs_voxelize_fwd_f32 with the voxel counts.)
+ */
+int pcs_scatter_max_fwd_f32(const float *src, const int64_t *order, const int64_t *rowptr, int64_t m,
+                            int32_t c, float *out, int64_t *arg, void *stream);
+/* gsrc (n,c) is zeroed inside, then gsrc[arg[v,j], j] = gout[v,j]. */
+int pcs_scatter_max_bwd_f32(const float *gout, const int64_t *arg, int64_t m, int64_t n, int32_t c,
+                            float *gsrc, void *stream);
+
+/* K13  map_count_forward   RL:range_utils/src/map_count_gpu.cu:5-14 (RL = R:pcseg/model/segmentor/
+ *      fusion/rpvnet/range_lib/): out[b,py,px] += 1 for pxpy rows (b,px,py) inside the image
+ *      (the reference checks only px,py >= 0); out (B,H,W) int32 zeroed inside.
+ * K14  denselize_forward   RL:range_utils/src/denselize_gpu.cu:5-19: out[b,j,py,px] += feat[i,j] /
+ *      count[b,py,px]; out (B,C,H,W) fp32 zeroed inside.
+ * K15  denselize_backward  RL:range_utils/src/denselize_gpu.cu:21-34: gfeat[i,j] = gout[b,j,py,px] /
+ *      count (0 where the reference would divide by zero / read out of bounds). */
+int pcs_map_count(const int32_t *pxpy, int64_t n, int32_t B, int32_t H, int32_t W, int32_t *out,
+                  void *stream);
+int pcs_denselize_fwd_f32(const float *feat, const int32_t *count_map, const int32_t *pxpy, int64_t n,
+                          int32_t B, int32_t C, int32_t H, int32_t W, float *out, void *stream);
+int pcs_denselize_bwd_f32(const float *gout, const int32_t *count_map, const int32_t *pxpy, int64_t n,
+                          int32_t B, int32_t C, int32_t H, int32_t W, float *gfeat, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ def install_as_torchsparse(force=False):
         if getattr(existing, "__openpcseg_amd__", False):
             return existing
         raise RuntimeError("a different `torchsparse` is already imported")
+    from . import backend_shim
     from . import functional as Fn
     from . import hostdata, modules, sparse
 
@@ -45,13 +46,25 @@ def install_as_torchsparse(force=False):
     tensor = _module("torchsparse.tensor", SparseTensor=sparse.SparseTensor,
                      PointTensor=sparse.PointTensor)
     operators = _module("torchsparse.operators", cat=sparse.cat)
+    b_names = [n for n in dir(backend_shim) if n.endswith("_cuda")]
+    backend = _module("torchsparse.backend", **{n: getattr(backend_shim, n) for n in b_names})
     top = _module("torchsparse", SparseTensor=sparse.SparseTensor, PointTensor=sparse.PointTensor,
-                  cat=sparse.cat, nn=nn_mod, utils=utils, tensor=tensor, operators=operators,
+                  cat=sparse.cat, nn=nn_mod, utils=utils, tensor=tensor, operators=operators, backend=backend,
                   __version__=TORCHSPARSE_VERSION)
     top.__openpcseg_amd__ = True
     top.__path__ = []  # mark as package so `import torchsparse.nn` resolves through sys.modules
     for m in (nn_mod, utils):
         m.__path__ = []
-    for m in (top, nn_mod, functional, nn_utils, utils, quantize, collate, tensor, operators):
+    for m in (top, nn_mod, functional, nn_utils, utils, quantize, collate, tensor, operators, backend):
         sys.modules[m.__name__] = m
     return top
+
+
+def install_reference_aliases():
+    """Everything the reference's sparse segmentors import from outside its own tree, served by this package:
+    torchsparse (+ backend), torch_scatter (scatter_max / scatter_mean), range_utils (map_count / denselize)."""
+    from .rangelib import install_as_range_utils
+    from .scatter import install_as_torch_scatter
+    install_as_torchsparse()
+    install_as_torch_scatter()
+    install_as_range_utils()

@@ -43,6 +43,11 @@ SIGNATURES = {
     "pcs_conv_wgrad_ws_bytes": (c_size_t, [_P, c_int32, c_int32, c_int32]),
     "pcs_conv_wgrad_f32": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P,
                                      _P, c_size_t, _P]),
+    "pcs_scatter_max_fwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P, _P]),
+    "pcs_scatter_max_bwd_f32": (c_int32, [_P, _P, c_int64, c_int64, c_int32, _P, _P]),
+    "pcs_map_count": (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P]),
+    "pcs_denselize_fwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "pcs_denselize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P]),
 }
 
 _lib = None
@@ -348,6 +353,58 @@ class HipBackend:
                                            _ptr(kmap.koff), kmap._koff_c, kmap.K, _ptr(gw), _ptr(ws),
                                            ws_bytes, _stream()), "pcs_conv_wgrad_f32")
         return gw
+
+
+    # -- cylinder / range scatter ---------------------------------------------------------------
+    @staticmethod
+    def _csr(index, m):
+        vals, order = torch.sort(index.reshape(-1))
+        rowptr = torch.searchsorted(vals, torch.arange(m + 1, device=index.device, dtype=vals.dtype))
+        return order.contiguous(), rowptr.contiguous()
+
+    def scatter_max_fwd(self, src, index, m):
+        src = _dev(src, "src", torch.float32)
+        index = _dev(index, "index", torch.int64)
+        c = src.shape[1]
+        order, rowptr = self._csr(index, m)
+        out = torch.empty((m, c), dtype=torch.float32, device=src.device)
+        arg = torch.empty((m, c), dtype=torch.int64, device=src.device)
+        _check(self.lib.pcs_scatter_max_fwd_f32(_ptr(src), _ptr(order), _ptr(rowptr), m, c, _ptr(out), _ptr(arg),
+                                                _stream()), "pcs_scatter_max_fwd_f32")
+        return out, arg
+
+    def scatter_max_bwd(self, gout, arg, n):
+        gout = _dev(gout, "grad_output", torch.float32)
+        m, c = gout.shape
+        gsrc = torch.empty((n, c), dtype=torch.float32, device=gout.device)
+        _check(self.lib.pcs_scatter_max_bwd_f32(_ptr(gout), _ptr(arg), m, n, c, _ptr(gsrc), _stream()),
+               "pcs_scatter_max_bwd_f32")
+        return gsrc
+
+    def map_count(self, pxpy, b, h, w):
+        pxpy = _dev(pxpy, "pxpy", torch.int32)
+        out = torch.empty((b, h, w), dtype=torch.int32, device=pxpy.device)
+        _check(self.lib.pcs_map_count(_ptr(pxpy), pxpy.shape[0], b, h, w, _ptr(out), _stream()), "pcs_map_count")
+        return out
+
+    def denselize_fwd(self, feat, count_map, pxpy):
+        feat = _dev(feat, "feat", torch.float32)
+        count_map = _dev(count_map, "count_map", torch.int32)
+        pxpy = _dev(pxpy, "pxpy", torch.int32)
+        (b, h, w), c = count_map.shape, feat.shape[1]
+        out = torch.empty((b, c, h, w), dtype=torch.float32, device=feat.device)
+        _check(self.lib.pcs_denselize_fwd_f32(_ptr(feat), _ptr(count_map), _ptr(pxpy), feat.shape[0], b, c, h, w,
+                                              _ptr(out), _stream()), "pcs_denselize_fwd_f32")
+        return out
+
+    def denselize_bwd(self, gout, count_map, pxpy):
+        gout = _dev(gout, "top_grad", torch.float32)
+        b, c, h, w = gout.shape
+        n = pxpy.shape[0]
+        gfeat = torch.empty((n, c), dtype=torch.float32, device=gout.device)
+        _check(self.lib.pcs_denselize_bwd_f32(_ptr(gout), _ptr(count_map), _ptr(pxpy), n, b, c, h, w, _ptr(gfeat),
+                                              _stream()), "pcs_denselize_bwd_f32")
+        return gfeat
 
 
 _BACKEND = None

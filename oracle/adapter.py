@@ -107,6 +107,23 @@ class OracleBackend:
         return torch.from_numpy(gw)
 
 
+    def scatter_max_fwd(self, src, index, m):
+        out, arg = orc.scatter_max(_np(src), _np(index), m)
+        return torch.from_numpy(out), torch.from_numpy(arg)
+
+    def scatter_max_bwd(self, gout, arg, n):
+        return torch.from_numpy(orc.scatter_max_bwd(_np(gout), _np(arg), n))
+
+    def map_count(self, pxpy, b, h, w):
+        return torch.from_numpy(orc.map_count(_np(pxpy), b, h, w))
+
+    def denselize_fwd(self, feat, count_map, pxpy):
+        return torch.from_numpy(orc.denselize_fwd(_np(feat), _np(count_map), _np(pxpy)))
+
+    def denselize_bwd(self, gout, count_map, pxpy):
+        return torch.from_numpy(orc.denselize_bwd(_np(gout), _np(count_map), _np(pxpy)))
+
+
 class RefBackend(OracleBackend):
     """The reference's OWN compiled CPU functions (oracle/_ref) wherever its twin is sound
     (SURVEY.md section 8c); the restatement for kernel_hash (multi-batch bug, hash_cpu.cpp:29)

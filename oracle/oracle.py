@@ -220,3 +220,65 @@ def conv_bwd(feats, gout, weight, nbmaps, nbsizes, transposed=False):
     _c().orc_conv_bwd(_p(feats), _p(gin), _p(gout), _p(weight), _p(gw), _p(nbm), _p(nbs),
                       I64(feats.shape[0]), I32(cin), I32(cout), I32(k), I32(1 if transposed else 0))
     return gin, gw.reshape(wshape)
+
+
+# ---- cylinder scatter (torch_scatter semantics restated; PARITY UNPINNED) ----------------------------
+def scatter_max(src, index, m):
+    """torch_scatter.scatter_max(src, index, dim=0) as used at R:tools/utils/common/seg_utils.py:178:
+    per-voxel channel-wise max and the (first) arg-max point; empty voxel -> 0 / -1."""
+    src = _f32(src)
+    index = np.asarray(index, dtype=np.int64)
+    n, c = src.shape
+    out = np.zeros((m, c), dtype=np.float32)
+    arg = np.full((m, c), -1, dtype=np.int64)
+    for i in np.argsort(index, kind="stable"):
+        v = index[i]
+        upd = (arg[v] < 0) | (src[i] > out[v])
+        out[v][upd] = src[i][upd]
+        arg[v][upd] = i
+    return out, arg
+
+
+def scatter_max_bwd(gout, arg, n):
+    gout = _f32(gout)
+    m, c = gout.shape
+    g = np.zeros((n, c), dtype=np.float32)
+    vv, jj = np.nonzero(arg >= 0)
+    g[arg[vv, jj], jj] = gout[vv, jj]
+    return g
+
+
+# ---- range_lib (RL = R:pcseg/model/segmentor/fusion/rpvnet/range_lib/) ------------------------------
+def map_count(pxpy, b, h, w):
+    """RL:range_utils/src/map_count_gpu.cu:5-14 (+ upper-bound checks the reference lacks)."""
+    pxpy = np.asarray(pxpy, dtype=np.int64)
+    out = np.zeros((b, h, w), dtype=np.int32)
+    ok = (pxpy[:, 0] >= 0) & (pxpy[:, 0] < b) & (pxpy[:, 1] >= 0) & (pxpy[:, 1] < w) & (pxpy[:, 2] >= 0) & (pxpy[:, 2] < h)
+    np.add.at(out, (pxpy[ok, 0], pxpy[ok, 2], pxpy[ok, 1]), 1)
+    return out
+
+
+def denselize_fwd(feat, count_map, pxpy):
+    """RL:range_utils/src/denselize_gpu.cu:5-19: out[b, :, py, px] += feat[i] / count[b, py, px]."""
+    feat = _f32(feat)
+    pxpy = np.asarray(pxpy, dtype=np.int64)
+    b, h, w = count_map.shape
+    out = np.zeros((b, feat.shape[1], h, w), dtype=np.float64)
+    for i in range(feat.shape[0]):
+        bb, px, py = pxpy[i]
+        if 0 <= bb < b and 0 <= px < w and 0 <= py < h and count_map[bb, py, px] > 0:
+            out[bb, :, py, px] += feat[i] / np.float32(count_map[bb, py, px])
+    return out.astype(np.float32)
+
+
+def denselize_bwd(gout, count_map, pxpy):
+    """RL:range_utils/src/denselize_gpu.cu:21-34."""
+    gout = _f32(gout)
+    pxpy = np.asarray(pxpy, dtype=np.int64)
+    b, c, h, w = gout.shape
+    g = np.zeros((pxpy.shape[0], c), dtype=np.float32)
+    for i in range(pxpy.shape[0]):
+        bb, px, py = pxpy[i]
+        if 0 <= bb < b and 0 <= px < w and 0 <= py < h and count_map[bb, py, px] > 0:
+            g[i] = gout[bb, :, py, px] / np.float32(count_map[bb, py, px])
+    return g

@@ -1,0 +1,126 @@
+"""Cylinder scatter (torch_scatter semantics, PARITY UNPINNED -- restated) and range_lib K13-K15.
+CPU part: the restatement against closed-form expectations and the reference's only known-answer-ish
+artefact for this path (RL:example.py:10-24, pxpy = [[0,2,2],[0,2,2],[1,1,0]]), plus the import aliases.
+GPU part (-m gpu): HIP kernels vs the restatement, gradcheck-style adjoint identities."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+
+def test_rangelib_example_known_answer():
+    pxpy = np.array([[0, 2, 2], [0, 2, 2], [1, 1, 0]], dtype=np.int32)  # (batch, px, py), RL:example.py:12
+    cm = orc.map_count(pxpy, 2, 5, 4)
+    assert cm.shape == (2, 5, 4) and cm.sum() == 3 and cm[0, 2, 2] == 2 and cm[1, 0, 1] == 1
+    pf = np.array([[1, 1, 2], [1, 2, 2], [4, 4, 4]], dtype=np.float32)
+    fm = orc.denselize_fwd(pf, cm, pxpy)
+    assert fm.shape == (2, 3, 5, 4)
+    assert np.allclose(fm[0, :, 2, 2], [1.0, 1.5, 2.0]) and np.allclose(fm[1, :, 0, 1], [4, 4, 4])
+    g = np.random.default_rng(0).normal(size=fm.shape).astype(np.float32)
+    # adjoint: <denselize(f), g> == <f, denselize_bwd(g)>   (what the reference's gradcheck verifies)
+    assert np.isclose((fm * g).sum(), (pf * orc.denselize_bwd(g, cm, pxpy)).sum(), rtol=1e-5)
+
+
+def test_scatter_max_restatement():
+    rng = np.random.default_rng(1)
+    src = rng.normal(size=(500, 7)).astype(np.float32)
+    idx = rng.integers(0, 40, size=500)
+    out, arg = orc.scatter_max(src, idx, 41)
+    for v in range(41):
+        rows = src[idx == v]
+        if rows.size:
+            assert np.array_equal(out[v], rows.max(axis=0))
+            assert np.array_equal(src[arg[v], np.arange(7)], out[v])
+        else:
+            assert (out[v] == 0).all() and (arg[v] == -1).all()
+    t = torch.from_numpy(src).requires_grad_(True)
+    ref = torch.zeros(41, 7).scatter_reduce(0, torch.from_numpy(idx)[:, None].expand(-1, 7), t, "amax", include_self=False)
+    assert np.allclose(ref.detach().numpy()[:40], out[:40])
+
+
+def test_reference_aliases_resolve(oracle_backend):
+    import openpcseg_amd
+    openpcseg_amd.install_reference_aliases()
+    import range_utils.nn.functional as rnf
+    import torch_scatter
+    import torchsparse.backend as tb
+    src = torch.randn(50, 4, requires_grad=True)
+    idx = torch.randint(0, 9, (50,))
+    out, arg = torch_scatter.scatter_max(src, idx, dim=0)
+    out.sum().backward()
+    assert out.shape[1] == 4 and src.grad.sum().item() == pytest.approx(float((arg >= 0).sum()))
+    mean = torch_scatter.scatter_mean(src.detach(), idx, dim=0)
+    for v in range(mean.shape[0]):
+        if (idx == v).any():
+            assert torch.allclose(mean[v], src.detach()[idx == v].mean(0), atol=1e-6)
+    pxpy = torch.tensor([[0, 2, 2], [0, 2, 2], [1, 1, 0]], dtype=torch.int32)
+    cm = rnf.map_count(pxpy, 2, 5, 4)
+    pf = torch.tensor([[1., 1, 2], [1, 2, 2], [4, 4, 4]], requires_grad=True)
+    fm = rnf.denselize(pf, cm, pxpy)
+    fm.sum().backward()
+    assert torch.allclose(pf.grad, torch.tensor([[.5, .5, .5], [.5, .5, .5], [1, 1, 1]]))
+    assert len([n for n in dir(tb) if n.endswith("_cuda")]) == 10
+
+
+# ---- GPU ------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", [5, 32, 256])
+def test_hip_scatter_max(hip, c):
+    rng = np.random.default_rng(c)
+    n, m = 40000, 6000
+    src = rng.normal(size=(n, c)).astype(np.float32)
+    idx = rng.integers(0, m - 3, size=n)  # last voxels stay empty
+    out, arg = hip.scatter_max_fwd(torch.from_numpy(src).cuda(), torch.from_numpy(idx).cuda(), m)
+    eo, ea = orc.scatter_max(src, idx, m)
+    assert np.array_equal(out.cpu().numpy(), eo)
+    a = arg.cpu().numpy()
+    assert ((a >= 0) == (ea >= 0)).all()
+    vv, jj = np.nonzero(a >= 0)
+    assert np.array_equal(src[a[vv, jj], jj], eo[vv, jj])  # arg points at a maximal element (ties: any)
+    g = rng.normal(size=(m, c)).astype(np.float32)
+    gs = hip.scatter_max_bwd(torch.from_numpy(g).cuda(), arg, n).cpu().numpy()
+    assert np.allclose(gs, orc.scatter_max_bwd(g, a, n))
+
+
+@pytest.mark.gpu
+def test_hip_rangelib(hip):
+    rng = np.random.default_rng(3)
+    n, B, C, H, W = 50000, 3, 24, 16, 128
+    pxpy = np.stack([rng.integers(0, B, n), rng.integers(-2, W + 2, n), rng.integers(-1, H + 1, n)], 1).astype(np.int32)
+    feat = rng.normal(size=(n, C)).astype(np.float32)
+    tp, tf = torch.from_numpy(pxpy).cuda(), torch.from_numpy(feat).cuda()
+    cm = hip.map_count(tp, B, H, W)
+    ecm = orc.map_count(pxpy, B, H, W)
+    assert np.array_equal(cm.cpu().numpy(), ecm)
+    fm = hip.denselize_fwd(tf, cm, tp).cpu().numpy()
+    efm = orc.denselize_fwd(feat, ecm, pxpy)
+    assert np.abs(fm - efm).max() <= 1e-5 * np.abs(efm).max()
+    g = rng.normal(size=efm.shape).astype(np.float32)
+    gb = hip.denselize_bwd(torch.from_numpy(g).cuda(), cm, tp).cpu().numpy()
+    assert np.allclose(gb, orc.denselize_bwd(g, ecm, pxpy), rtol=1e-6, atol=1e-7)
+    ex = np.array([[0, 2, 2], [0, 2, 2], [1, 1, 0]], dtype=np.int32)  # RL:example.py
+    assert np.array_equal(hip.map_count(torch.from_numpy(ex).cuda(), 2, 5, 4).cpu().numpy(), orc.map_count(ex, 2, 5, 4))
+
+
+@pytest.mark.gpu
+def test_hip_backend_shim_matches_reference_golden(hip, golden):
+    """The `torchsparse.backend.*_cuda` surface (B-B) reproduces the reference's conv goldens, incl. the
+    transposed call that needs a per-offset re-sort of the caller's map."""
+    from openpcseg_amd import backend_shim as tb
+    dev = "cuda"
+    for tag, name, transposed in [("conv_k3s1_N", "k3s1", False), ("conv_k2s2_N", "k2s2", False), ("conv_k2s2_T", "k2s2", True)]:
+        nbmaps = torch.from_numpy(golden["kmap_%s_nbmaps" % name]).int().to(dev)
+        nbsizes = torch.from_numpy(golden["kmap_%s_nbsizes" % name]).int()  # on the CPU, like the reference passes it
+        x, w, gy = (torch.from_numpy(golden[tag + s]).to(dev) for s in ("_x", "_w", "_gy"))
+        y = torch.zeros(golden[tag + "_y"].shape, device=dev)
+        tb.convolution_forward_cuda(x, y, w, nbmaps, nbsizes, transposed)
+        assert np.abs(y.cpu().numpy() - golden[tag + "_y"]).max() <= 2e-5 * np.abs(golden[tag + "_y"]).max()
+        gx, gw = torch.zeros_like(x), torch.zeros_like(w)
+        tb.convolution_backward_cuda(x, gx, gy, w, gw, nbmaps, nbsizes, transposed)
+        assert np.abs(gx.cpu().numpy() - golden[tag + "_gx"]).max() <= 2e-5 * np.abs(golden[tag + "_gx"]).max()
+        assert np.abs(gw.cpu().numpy() - golden[tag + "_gw"]).max() <= 2e-5 * np.abs(golden[tag + "_gw"]).max()
+    h = tb.hash_cuda(torch.from_numpy(golden["scene_coords"]).to(dev))
+    q = torch.from_numpy(golden["query_q"]).to(dev)
+    r = tb.hash_query_cuda(q, h, torch.arange(h.numel(), device=dev)) - 1
+    assert np.array_equal(r.cpu().numpy(), golden["query_out"])
