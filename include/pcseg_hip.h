@@ -231,6 +231,34 @@ int pcs_denselize_fwd_f32(const float *feat, const int32_t *count_map, const int
 int pcs_denselize_bwd_f32(const float *gout, const int32_t *count_map, const int32_t *pxpy, int64_t n,
                           int32_t B, int32_t C, int32_t H, int32_t W, float *gfeat, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Block fusion above the op boundary: training-mode BatchNorm over (N,C)
+ * voxel features fused with the residual add and the ReLU that follow it in the reference's
+ * blocks (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:31-129: Conv3d -> (Sync)BatchNorm
+ * -> ReLU, and relu(net(x) + downsample(x))). Statistics are two-level and fixed-order
+ * (deterministic); `sums` (2c doubles: sum x | sum x^2) is the vector a data-parallel run
+ * all-reduces between the stats and the finalize call -- SyncBatchNorm semantics --, `sums2`
+ * (sum g | sum g*xhat) the one it all-reduces in backward.
+ *   forward : pcs_bn_stats_f32 -> [all-reduce sums, count] -> pcs_bn_finalize_f32 (stat = mean | invstd,
+ *             running stats updated with the unbiased variance like nn.BatchNorm1d)
+ *             -> pcs_bn_apply_f32: y = act((x - mean) * invstd * w + b [+ res])
+ *   backward: pcs_bn_bwd_stats_f32 (g = dy * [y > 0] when relu) -> [all-reduce sums2]
+ *             -> pcs_bn_bwd_apply_f32: dx = (g - sum_g/N - xhat * sum_gxhat/N) * invstd * w, dres = g
+ *             (dw = sums2[c:], db = sums2[:c]).
+ * partial_ws: pcs_bn_num_partials() * 2 * c floats.
+ */
+int32_t pcs_bn_num_partials(void);
+int pcs_bn_stats_f32(const float *x, int64_t n, int32_t c, float *partial_ws, double *sums, void *stream);
+int pcs_bn_finalize_f32(const double *sums, double count, int32_t c, double eps, double momentum,
+                        float *running_mean, float *running_var, double *stat, void *stream);
+int pcs_bn_apply_f32(const float *x, const float *res, const double *stat, const float *w, const float *b,
+                     int64_t n, int32_t c, int32_t relu, float *y, void *stream);
+int pcs_bn_bwd_stats_f32(const float *dy, const float *x, const float *y, const double *stat, int64_t n,
+                         int32_t c, int32_t relu, float *partial_ws, double *sums2, void *stream);
+int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const double *stat,
+                         const double *sums2, double count, const float *w, int64_t n, int32_t c,
+                         int32_t relu, float *dx, float *dres, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,245 @@
+// Fused training-mode BatchNorm (+ residual add + ReLU) over (N, C) voxel features -- gfx950, fp32, HBM-bound.
+// The reference runs nn.BatchNorm1d / SyncBatchNorm, a separate ReLU and a separate residual add through
+// fapply (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:23-129): 4 BN kernels + 2 ReLU + 2 add kernels per
+// block and direction. Here: forward = one statistics pass + one apply pass (normalise, +residual, ReLU,
+// single write); backward = one reduction pass + one apply pass producing dx and (optionally) the residual grad.
+// Statistics are two-level (per-workgroup partials, then a fixed-order reduction): deterministic, and the
+// (sum, sumsq) vector is what a multi-GPU run all-reduces between the two kernels (SyncBN semantics).
+#include "pcs_common.h"
+
+using namespace pcs;
+
+namespace {
+
+constexpr int kStatBlocks = 1024;  // partial rows; each workgroup strides over the feature rows
+
+// block = (TX lanes over channels, TY rows); partial[b][0][c] = sum x, partial[b][1][c] = sum x^2  (or dy / dy*xhat)
+template <bool BWD>
+__global__ void __launch_bounds__(256) bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                         const float *__restrict__ y, const double *__restrict__ stat,
+                                                         int64_t n, int c, int relu, float *__restrict__ partial) {
+  extern __shared__ float red[];  // [TY][2][TXC]  (TXC = channels handled per pass = blockDim.x)
+  const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
+  for (int c0 = 0; c0 < c; c0 += TX) {
+    const int ch = c0 + tx;
+    float s0 = 0.f, s1 = 0.f;
+    if (ch < c) {
+      float mean = 0.f, invstd = 0.f;
+      if (BWD) { mean = (float)stat[ch]; invstd = (float)stat[c + ch]; }
+      for (int64_t i = (int64_t)blockIdx.x * TY + ty; i < n; i += (int64_t)gridDim.x * TY) {
+        const float xv = x[i * c + ch];
+        if (BWD) {
+          float g = dy[i * c + ch];
+          if (relu && y[i * c + ch] <= 0.f) g = 0.f;
+          s0 += g;
+          s1 += g * ((xv - mean) * invstd);
+        } else {
+          s0 += xv;
+          s1 += xv * xv;
+        }
+      }
+    }
+    red[(ty * 2 + 0) * TX + tx] = s0;
+    red[(ty * 2 + 1) * TX + tx] = s1;
+    __syncthreads();
+    if (ty == 0 && ch < c) {
+      float a = 0.f, b = 0.f;
+      for (int r = 0; r < TY; ++r) { a += red[(r * 2 + 0) * TX + tx]; b += red[(r * 2 + 1) * TX + tx]; }
+      partial[((int64_t)blockIdx.x * 2 + 0) * c + ch] = a;
+      partial[((int64_t)blockIdx.x * 2 + 1) * c + ch] = b;
+    }
+    __syncthreads();
+  }
+}
+
+// sums[e] = sum over the nblk partial rows of partial[b][e], e in [0, 2c), accumulated in double in a FIXED
+// order (thread ty sums rows ty, ty+16, ...; then ty = 0..15 in order): deterministic, 64 x 16 threads per 64 columns.
+__global__ void __launch_bounds__(1024) bn_reduce_kernel(const float *__restrict__ partial, int nblk, int c,
+                                                         double *__restrict__ sums) {
+  __shared__ double red[16][64];
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  double s = 0.0;
+  if (e < 2 * c)
+    for (int b = threadIdx.y; b < nblk; b += 16) s += (double)partial[(int64_t)b * 2 * c + e];
+  red[threadIdx.y][threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.y == 0 && e < 2 * c) {
+    double t = 0.0;
+    for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
+    sums[e] = t;
+  }
+}
+
+// stat[0..c) = mean, stat[c..2c) = invstd; running stats updated like nn.BatchNorm1d (unbiased var, momentum)
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const double *__restrict__ sums, double count, int c,
+                                                          double eps, double momentum, float *running_mean,
+                                                          float *running_var, double *__restrict__ stat) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const double mean = sums[ch] / count;
+  double var = sums[c + ch] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stat[ch] = mean;
+  stat[c + ch] = 1.0 / sqrt(var + eps);
+  if (running_mean) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+    running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+  }
+}
+
+template <int V> struct NV;
+template <> struct NV<4> { using T = float4; };
+template <> struct NV<1> { using T = float; };
+__device__ __forceinline__ float comp(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+__device__ __forceinline__ float comp(const float &v, int) { return v; }
+__device__ __forceinline__ void setc(float4 &v, int i, float s) { if (i == 0) v.x = s; else if (i == 1) v.y = s; else if (i == 2) v.z = s; else v.w = s; }
+__device__ __forceinline__ void setc(float &v, int, float s) { v = s; }
+
+// y = act((x - mean) * invstd * w + b [+ res])
+template <int V>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ res,
+                                                       const double *__restrict__ stat, const float *__restrict__ w,
+                                                       const float *__restrict__ b, int64_t n, int c, int cv, int relu,
+                                                       float *__restrict__ y) {
+  using VT = typename NV<V>::T;
+  for (int j = threadIdx.x; j < cv; j += blockDim.x) {
+    float sc[V], sh[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const int ch = j * V + q;
+      const float invstd = (float)stat[c + ch], mean = (float)stat[ch];
+      sc[q] = invstd * (w ? w[ch] : 1.f);
+      sh[q] = (b ? b[ch] : 0.f) - mean * sc[q];
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; i < n; i += (int64_t)gridDim.x * blockDim.y) {
+      const VT xv = reinterpret_cast<const VT *>(x + i * c)[j];
+      VT rv; if (res) rv = reinterpret_cast<const VT *>(res + i * c)[j];
+      VT o;
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        float t = fmaf(comp(xv, q), sc[q], sh[q]);
+        if (res) t += comp(rv, q);
+        if (relu && t < 0.f) t = 0.f;
+        setc(o, q, t);
+      }
+      reinterpret_cast<VT *>(y + i * c)[j] = o;
+    }
+  }
+}
+
+// g = dy * [y > 0];  dx = (g - sum_g/N - xhat * sum_gxhat/N) * invstd * w ;  dres = g
+template <int V>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                           const float *__restrict__ y, const double *__restrict__ stat,
+                                                           const double *__restrict__ sums2, double count,
+                                                           const float *__restrict__ w, int64_t n, int c, int cv,
+                                                           int relu, float *__restrict__ dx, float *__restrict__ dres) {
+  using VT = typename NV<V>::T;
+  for (int j = threadIdx.x; j < cv; j += blockDim.x) {
+    float mean[V], invstd[V], k1[V], k2[V], ws[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const int ch = j * V + q;
+      mean[q] = (float)stat[ch]; invstd[q] = (float)stat[c + ch];
+      k1[q] = (float)(sums2[ch] / count);
+      k2[q] = (float)(sums2[c + ch] / count);
+      ws[q] = invstd[q] * (w ? w[ch] : 1.f);
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; i < n; i += (int64_t)gridDim.x * blockDim.y) {
+      const VT gv = reinterpret_cast<const VT *>(dy + i * c)[j];
+      const VT xv = reinterpret_cast<const VT *>(x + i * c)[j];
+      VT yv; if (relu) yv = reinterpret_cast<const VT *>(y + i * c)[j];
+      VT o, r;
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        float g = comp(gv, q);
+        if (relu && comp(yv, q) <= 0.f) g = 0.f;
+        const float xh = (comp(xv, q) - mean[q]) * invstd[q];
+        setc(o, q, (g - k1[q] - xh * k2[q]) * ws[q]);
+        setc(r, q, g);
+      }
+      reinterpret_cast<VT *>(dx + i * c)[j] = o;
+      if (dres) reinterpret_cast<VT *>(dres + i * c)[j] = r;
+    }
+  }
+}
+
+struct Geo { dim3 block, grid; int cv; };
+template <int V> Geo geo(int64_t n, int c) {
+  Geo g; g.cv = c / V;
+  int tx = 1; while (tx < g.cv && tx < 64) tx <<= 1;
+  g.block = dim3(tx, 256 / tx);
+  int64_t gr = ceil_div(n > 0 ? n : 1, (256 / tx) * 4);
+  if (gr > 2048) gr = 2048;
+  g.grid = dim3((unsigned)gr);
+  return g;
+}
+bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" int32_t pcs_bn_num_partials(void) { return kStatBlocks; }
+
+static int bn_partial(bool bwd, const float *x, const float *dy, const float *y, const double *stat, int64_t n, int c,
+                      int relu, float *partial, double *sums, hipStream_t st) {
+  int tx = 1; while (tx < c && tx < 64) tx <<= 1;
+  dim3 block(tx, 256 / tx);
+  const size_t lds = (size_t)(256 / tx) * 2 * tx * sizeof(float);
+  if (bwd) hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(kStatBlocks), block, lds, st, x, dy, y, stat, n, c, relu, partial);
+  else hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(kStatBlocks), block, lds, st, x, dy, y, stat, n, c, relu, partial);
+  hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)ceil_div(2 * c, 64)), dim3(64, 16), 0, st, partial, kStatBlocks, c, sums);
+  return check_launch("pcs_bn_partial");
+}
+
+extern "C" int pcs_bn_stats_f32(const float *x, int64_t n, int32_t c, float *partial_ws, double *sums, void *stream) {
+  if (n < 0 || c <= 0 || !x || !partial_ws || !sums) { set_error("pcs_bn_stats: bad args"); return PCS_EINVAL; }
+  return bn_partial(false, x, nullptr, nullptr, nullptr, n, c, 0, partial_ws, sums, as_stream(stream));
+}
+
+extern "C" int pcs_bn_finalize_f32(const double *sums, double count, int32_t c, double eps, double momentum,
+                                   float *running_mean, float *running_var, double *stat, void *stream) {
+  if (c <= 0 || count <= 0 || !sums || !stat) { set_error("pcs_bn_finalize: bad args"); return PCS_EINVAL; }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(c, 256)), dim3(256), 0, as_stream(stream), sums, count,
+                     c, eps, momentum, running_mean, running_var, stat);
+  return check_launch("pcs_bn_finalize");
+}
+
+extern "C" int pcs_bn_apply_f32(const float *x, const float *res, const double *stat, const float *w, const float *b,
+                                int64_t n, int32_t c, int32_t relu, float *y, void *stream) {
+  if (n < 0 || c <= 0) { set_error("pcs_bn_apply: bad sizes"); return PCS_EINVAL; }
+  if (n == 0) return PCS_OK;
+  if (!x || !stat || !y) { set_error("pcs_bn_apply: null pointer"); return PCS_EINVAL; }
+  hipStream_t st = as_stream(stream);
+  if ((c & 3) == 0 && al16(x) && al16(y) && al16(res)) {
+    Geo g = geo<4>(n, c);
+    hipLaunchKernelGGL(bn_apply_kernel<4>, g.grid, g.block, 0, st, x, res, stat, w, b, n, c, g.cv, relu, y);
+  } else {
+    Geo g = geo<1>(n, c);
+    hipLaunchKernelGGL(bn_apply_kernel<1>, g.grid, g.block, 0, st, x, res, stat, w, b, n, c, g.cv, relu, y);
+  }
+  return check_launch("pcs_bn_apply");
+}
+
+extern "C" int pcs_bn_bwd_stats_f32(const float *dy, const float *x, const float *y, const double *stat, int64_t n,
+                                    int32_t c, int32_t relu, float *partial_ws, double *sums2, void *stream) {
+  if (n < 0 || c <= 0 || !dy || !x || !stat || !partial_ws || !sums2 || (relu && !y)) { set_error("pcs_bn_bwd_stats: bad args"); return PCS_EINVAL; }
+  return bn_partial(true, x, dy, y, stat, n, c, relu, partial_ws, sums2, as_stream(stream));
+}
+
+extern "C" int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const double *stat,
+                                    const double *sums2, double count, const float *w, int64_t n, int32_t c,
+                                    int32_t relu, float *dx, float *dres, void *stream) {
+  if (n < 0 || c <= 0 || count <= 0) { set_error("pcs_bn_bwd_apply: bad sizes"); return PCS_EINVAL; }
+  if (n == 0) return PCS_OK;
+  if (!dy || !x || !stat || !sums2 || !dx || (relu && !y)) { set_error("pcs_bn_bwd_apply: null pointer"); return PCS_EINVAL; }
+  hipStream_t st = as_stream(stream);
+  if ((c & 3) == 0 && al16(dy) && al16(x) && al16(y) && al16(dx) && al16(dres)) {
+    Geo g = geo<4>(n, c);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, g.grid, g.block, 0, st, dy, x, y, stat, sums2, count, w, n, c, g.cv, relu, dx, dres);
+  } else {
+    Geo g = geo<1>(n, c);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, g.grid, g.block, 0, st, dy, x, y, stat, sums2, count, w, n, c, g.cv, relu, dx, dres);
+  }
+  return check_launch("pcs_bn_bwd_apply");
+}

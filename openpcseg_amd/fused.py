@@ -1,0 +1,86 @@
+"""Block fusion above the op boundary: BatchNorm + residual add + ReLU of the
+reference's conv blocks as ONE forward apply pass and ONE backward apply pass over the voxel features.
+
+`FusedBatchNorm` has the parameters / buffers / state_dict keys of nn.BatchNorm1d (and nn.SyncBatchNorm), so
+reference checkpoints load; `sync=True` all-reduces the (sum, sum^2, count) vector over the default process group
+between the statistics and the apply kernels -- SyncBatchNorm semantics, one small collective per layer and
+direction (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:23-25)."""
+import torch
+import torch.distributed as dist
+from torch import nn
+from torch.autograd import Function
+
+from . import native
+from .sparse import SparseTensor
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class _FusedBN(Function):
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, sync):
+        be = native.backend()
+        x = x.contiguous()
+        res = res.contiguous() if res is not None else None
+        n, c = x.shape
+        sums = be.bn_stats(x)
+        count = float(n)
+        if sync and _world() > 1:
+            pack = torch.cat([sums, sums.new_tensor([count])])
+            dist.all_reduce(pack)
+            sums, count = pack[:-1].contiguous(), float(pack[-1].item())
+        stat = be.bn_finalize(sums, count, eps, momentum, running_mean, running_var)
+        y = be.bn_apply(x, res, stat, weight, bias, relu)
+        ctx.save_for_backward(x, y if relu else None, stat, weight)
+        ctx.cfg = (count, relu, sync, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = native.backend()
+        x, y, stat, weight = ctx.saved_tensors
+        count, relu, sync, has_res = ctx.cfg
+        dy = dy.contiguous()
+        c = x.shape[1]
+        local = be.bn_bwd_stats(dy, x, y, stat, relu)
+        sums2 = local
+        if sync and _world() > 1:
+            sums2 = local.clone()
+            dist.all_reduce(sums2)
+        dx, dres = be.bn_bwd_apply(dy, x, y, stat, sums2, count, weight, relu, has_res)
+        dw = local[c:].float() if weight is not None else None   # local sums: DDP averages parameter grads
+        db = local[:c].float() if weight is not None else None
+        return dx, dres, dw, db, None, None, None, None, None, None
+
+
+class FusedBatchNorm(nn.Module):
+    """BatchNorm over SparseTensor features with optional fused residual add and ReLU:
+    `bn(x)`, `bn(x, relu=True)`, `bn(x, residual=r, relu=True)`."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, sync=False):
+        super().__init__()
+        self.num_features, self.eps, self.momentum, self.sync = num_features, eps, momentum, sync
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def extra_repr(self):
+        return "%d, eps=%g, momentum=%g, sync=%s" % (self.num_features, self.eps, self.momentum, self.sync)
+
+    def forward(self, input, residual=None, relu=False):
+        x = input.feats
+        r = residual.feats if isinstance(residual, SparseTensor) else residual
+        if self.training:
+            self.num_batches_tracked += 1
+            y = _FusedBN.apply(x, r, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                               self.momentum, relu, self.sync)
+        else:
+            inv = torch.rsqrt(self.running_var.double() + self.eps)
+            stat = torch.cat([self.running_mean.double(), inv]).contiguous()
+            y = native.backend().bn_apply(x.contiguous(), r.contiguous() if r is not None else None, stat,
+                                          self.weight, self.bias, relu)
+        return input._like(y)

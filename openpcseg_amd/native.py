@@ -6,7 +6,7 @@ There is NO CPU path: a missing library or a non-HIP tensor raises.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 import torch
 
@@ -48,6 +48,12 @@ SIGNATURES = {
     "pcs_map_count": (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_denselize_fwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_denselize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "pcs_bn_num_partials": (c_int32, []),
+    "pcs_bn_stats_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P]),
+    "pcs_bn_finalize_f32": (c_int32, [_P, c_double, c_int32, c_double, c_double, _P, _P, _P, _P]),
+    "pcs_bn_apply_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P]),
+    "pcs_bn_bwd_stats_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
+    "pcs_bn_bwd_apply_f32": (c_int32, [_P, _P, _P, _P, _P, c_double, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
 }
 
 _lib = None
@@ -405,6 +411,53 @@ class HipBackend:
         _check(self.lib.pcs_denselize_bwd_f32(_ptr(gout), _ptr(count_map), _ptr(pxpy), n, b, c, h, w, _ptr(gfeat),
                                               _stream()), "pcs_denselize_bwd_f32")
         return gfeat
+
+
+    # -- fused BatchNorm (+residual, +ReLU) -------------------------------------------------------
+    def bn_stats(self, x):
+        """-> sums (2c,) float64 = [sum x | sum x^2] (what SyncBN all-reduces)."""
+        x = _dev(x, "input", torch.float32)
+        n, c = x.shape
+        ws = torch.empty(self.lib.pcs_bn_num_partials() * 2 * c, dtype=torch.float32, device=x.device)
+        sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        _check(self.lib.pcs_bn_stats_f32(_ptr(x), n, c, _ptr(ws), _ptr(sums), _stream()), "pcs_bn_stats_f32")
+        return sums
+
+    def bn_finalize(self, sums, count, eps, momentum, running_mean, running_var):
+        c = sums.numel() // 2
+        stat = torch.empty(2 * c, dtype=torch.float64, device=sums.device)
+        _check(self.lib.pcs_bn_finalize_f32(_ptr(sums), float(count), c, float(eps), float(momentum),
+                                            _ptr(running_mean) if running_mean is not None else None,
+                                            _ptr(running_var) if running_var is not None else None, _ptr(stat),
+                                            _stream()), "pcs_bn_finalize_f32")
+        return stat
+
+    def bn_apply(self, x, res, stat, w, b, relu):
+        x = _dev(x, "input", torch.float32)
+        n, c = x.shape
+        y = torch.empty_like(x)
+        _check(self.lib.pcs_bn_apply_f32(_ptr(x), _ptr(res) if res is not None else None, _ptr(stat),
+                                         _ptr(w) if w is not None else None, _ptr(b) if b is not None else None,
+                                         n, c, int(relu), _ptr(y), _stream()), "pcs_bn_apply_f32")
+        return y
+
+    def bn_bwd_stats(self, dy, x, y, stat, relu):
+        n, c = x.shape
+        ws = torch.empty(self.lib.pcs_bn_num_partials() * 2 * c, dtype=torch.float32, device=x.device)
+        sums2 = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        _check(self.lib.pcs_bn_bwd_stats_f32(_ptr(dy), _ptr(x), _ptr(y) if relu else None, _ptr(stat), n, c, int(relu),
+                                             _ptr(ws), _ptr(sums2), _stream()), "pcs_bn_bwd_stats_f32")
+        return sums2
+
+    def bn_bwd_apply(self, dy, x, y, stat, sums2, count, w, relu, want_res):
+        n, c = x.shape
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if want_res else None
+        _check(self.lib.pcs_bn_bwd_apply_f32(_ptr(dy), _ptr(x), _ptr(y) if relu else None, _ptr(stat), _ptr(sums2),
+                                             float(count), _ptr(w) if w is not None else None, n, c, int(relu),
+                                             _ptr(dx), _ptr(dres) if want_res else None, _stream()),
+               "pcs_bn_bwd_apply_f32")
+        return dx, dres
 
 
 _BACKEND = None

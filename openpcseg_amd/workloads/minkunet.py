@@ -11,6 +11,7 @@ import torch
 from torch import nn
 
 from .. import modules as spnn
+from ..fused import FusedBatchNorm
 from ..sparse import PointTensor, cat, fapply
 from .losses import SegLoss
 from .pointvoxel import initial_voxelize, voxel_to_point
@@ -30,8 +31,23 @@ class _SyncBN(nn.SyncBatchNorm):
         return fapply(x, super().forward)
 
 
+FUSED = True  # BatchNorm + residual + ReLU as fused HIP passes (openpcseg_amd.fused); False = torch modules
+
+
 def _norm(c, dist):
+    if FUSED:
+        return FusedBatchNorm(c, sync=dist)
     return _SyncBN(c) if dist else _BN(c)
+
+
+def _bn_act(bn, x, residual=None, relu=True, act=None):
+    """BN (+residual) (+ReLU): one fused pass, or the reference's separate torch modules."""
+    if isinstance(bn, FusedBatchNorm):
+        return bn(x, residual=residual, relu=relu)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return act(y) if relu else y
 
 
 class ConvBlock(nn.Module):
@@ -43,7 +59,7 @@ class ConvBlock(nn.Module):
                                  _norm(cout, dist), spnn.ReLU(True))
 
     def forward(self, x):
-        return self.net(x)
+        return _bn_act(self.net[1], self.net[0](x), act=self.net[2])
 
 
 class ResBlock(nn.Module):
@@ -58,7 +74,12 @@ class ResBlock(nn.Module):
         self.relu = spnn.ReLU(True)
 
     def forward(self, x):
-        return self.relu(self.net(x) + self.downsample(x))
+        h = _bn_act(self.net[1], self.net[0](x), act=self.net[2])
+        if isinstance(self.downsample, nn.Identity):
+            r = x
+        else:
+            r = _bn_act(self.downsample[1], self.downsample[0](x), relu=False)
+        return _bn_act(self.net[4], self.net[3](h), residual=r, act=self.relu)
 
 
 def _res_stack(cin, cout, n, dist):
@@ -73,6 +94,8 @@ class MinkUNet(nn.Module):
         self.in_dim, self.pres, self.vres = in_dim, pres, vres
         self.stem = nn.Sequential(spnn.Conv3d(in_dim, cs[0], kernel_size=3), _norm(cs[0], dist), spnn.ReLU(True),
                                   spnn.Conv3d(cs[0], cs[0], kernel_size=3), _norm(cs[0], dist), spnn.ReLU(True))
+        self._stem = lambda x: _bn_act(self.stem[4], self.stem[3](_bn_act(self.stem[1], self.stem[0](x), act=self.stem[2])),
+                                       act=self.stem[5])
         enc_in = [cs[0], cs[1], cs[2], cs[3]]
         for i in range(4):
             setattr(self, "stage%d" % (i + 1), nn.Sequential(
@@ -93,7 +116,7 @@ class MinkUNet(nn.Module):
         """x: SparseTensor (feats (N,>=in_dim), coords (N,4) int) -> per-point logits (N, num_class)."""
         x.F = x.F[:, :self.in_dim]
         z = PointTensor(x.F, x.C.float())
-        x0 = self.stem(initial_voxelize(z, self.pres, self.vres))
+        x0 = self._stem(initial_voxelize(z, self.pres, self.vres))
         z0 = voxel_to_point(x0, z)
         x1 = self.stage1(x0)
         x2 = self.stage2(x1)

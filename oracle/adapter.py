@@ -124,6 +124,46 @@ class OracleBackend:
         return torch.from_numpy(orc.denselize_bwd(_np(gout), _np(count_map), _np(pxpy)))
 
 
+    # fused BatchNorm pieces restated with plain torch (nn.BatchNorm1d training semantics)
+    def bn_stats(self, x):
+        xd = x.double()
+        return torch.cat([xd.sum(0), (xd * xd).sum(0)])
+
+    def bn_finalize(self, sums, count, eps, momentum, running_mean, running_var):
+        c = sums.numel() // 2
+        mean = sums[:c] / count
+        var = (sums[c:] / count - mean * mean).clamp_(min=0)
+        if running_mean is not None:
+            unb = var * count / (count - 1.0) if count > 1 else var
+            running_mean.mul_(1 - momentum).add_((momentum * mean).float())
+            running_var.mul_(1 - momentum).add_((momentum * unb).float())
+        return torch.cat([mean, 1.0 / torch.sqrt(var + eps)])
+
+    def bn_apply(self, x, res, stat, w, b, relu):
+        c = x.shape[1]
+        y = (x - stat[:c].float()) * stat[c:].float()
+        if w is not None:
+            y = y * w + b
+        if res is not None:
+            y = y + res
+        return torch.relu(y) if relu else y
+
+    def bn_bwd_stats(self, dy, x, y, stat, relu):
+        c = x.shape[1]
+        g = (dy * (y > 0)) if relu else dy
+        xh = (x - stat[:c].float()) * stat[c:].float()
+        return torch.cat([g.double().sum(0), (g * xh).double().sum(0)])
+
+    def bn_bwd_apply(self, dy, x, y, stat, sums2, count, w, relu, want_res):
+        c = x.shape[1]
+        g = (dy * (y > 0)) if relu else dy
+        xh = (x - stat[:c].float()) * stat[c:].float()
+        dx = (g - (sums2[:c] / count).float() - xh * (sums2[c:] / count).float()) * stat[c:].float()
+        if w is not None:
+            dx = dx * w
+        return dx, (g.clone() if want_res else None)
+
+
 class RefBackend(OracleBackend):
     """The reference's OWN compiled CPU functions (oracle/_ref) wherever its twin is sound
     (SURVEY.md section 8c); the restatement for kernel_hash (multi-batch bug, hash_cpu.cpp:29)

@@ -311,3 +311,42 @@ def test_full_scan_properties(hip):
     lhs = (y1.double() * gy.double()).sum()
     rhs = (x1.double() * hip.conv_gather_gemm(gy, w.transpose(1, 2).contiguous(), entry.rev).double()).sum()
     assert abs(float(lhs - rhs)) <= 1e-4 * abs(float(lhs))
+
+
+# ---- fused BatchNorm + residual + ReLU (block fusion above the op boundary) -----------------------------
+@pytest.mark.parametrize("c,relu,with_res", [(32, True, False), (96, True, True), (256, False, False), (5, True, True)])
+def test_fused_batchnorm_matches_torch(hip, c, relu, with_res):
+    from openpcseg_amd.fused import FusedBatchNorm
+    from openpcseg_amd.sparse import SparseTensor
+    torch.manual_seed(c)
+    n = 70001
+    x = (torch.randn(n, c, device=DEV) * 1.7 + 0.3).requires_grad_(True)
+    r = torch.randn(n, c, device=DEV).requires_grad_(True) if with_res else None
+    coords = torch.zeros(n, 4, dtype=torch.int32, device=DEV)
+    bn = FusedBatchNorm(c).to(DEV).train()
+    ref = torch.nn.BatchNorm1d(c).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+        ref.weight.copy_(bn.weight); ref.bias.copy_(bn.bias)
+    y = bn(SparseTensor(x, coords), residual=SparseTensor(r, coords) if with_res else None, relu=relu).F
+    x2 = x.detach().clone().requires_grad_(True)
+    r2 = r.detach().clone().requires_grad_(True) if with_res else None
+    t = ref(x2)
+    if with_res:
+        t = t + r2
+    if relu:
+        t = torch.relu(t)
+    assert (y - t).abs().max() <= 2e-5 * t.abs().max()
+    g = torch.randn_like(y)
+    y.backward(g)
+    t.backward(g)
+    assert (x.grad - x2.grad).abs().max() <= 5e-5 * x2.grad.abs().max()
+    assert (bn.weight.grad - ref.weight.grad).abs().max() <= 1e-4 * ref.weight.grad.abs().max()
+    assert (bn.bias.grad - ref.bias.grad).abs().max() <= 1e-4 * ref.bias.grad.abs().max()
+    if with_res:
+        assert (r.grad - r2.grad).abs().max() <= 1e-6
+    assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-5) and torch.allclose(bn.running_var, ref.running_var, rtol=1e-4)
+    bn.eval(); ref.eval()
+    ye = bn(SparseTensor(x.detach(), coords), relu=relu).F
+    te = torch.relu(ref(x.detach())) if relu else ref(x.detach())
+    assert (ye - te).abs().max() <= 2e-5 * te.abs().max()
