@@ -19,6 +19,8 @@
 // bit-reproducible run to run.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pcs_common.h"
 
 using namespace pcs;
@@ -638,6 +640,16 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os4_kernel(ConvArgs a) {
     for (int t = 0; t < NCTT; ++t) acc[t] = (f32x4){0, 0, 0, 0};
     const bool valid = cur.valid;
     auto mfma_frag = [&](const Frag &f, int c0) {
+#if PCS_ABLATE == 2   /* debug build: consume the operands with one VALU op each, no MFMA */
+      float t = f.a.x + f.a.y + f.a.z + f.a.w;
+      for (int e = 0; e < 4; ++e) {
+        for (int q = 0; q < C::N4; ++q) t += f.b4[e][q].x + f.b4[e][q].y + f.b4[e][q].z + f.b4[e][q].w;
+        if (C::N2) t += f.b2[e].x + f.b2[e].y;
+        if (C::N1) t += f.b1[e];
+      }
+      acc[0][0] += t;
+      return;
+#endif
       const bool aok = valid && (c0 + 4 * g) <= cin4;
       const float ae[4] = {aok ? f.a.x : 0.f, aok ? f.a.y : 0.f, aok ? f.a.z : 0.f, aok ? f.a.w : 0.f};
 #pragma unroll
@@ -662,25 +674,38 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os4_kernel(ConvArgs a) {
       // sched_barrier pins "issue the next block's 9 loads, THEN this block's MFMAs" (left alone
       // the machine scheduler sinks each load next to its use and only 1-2 stay in flight);
       // no branch between a load and its use, so every wait is a counted vmcnt.
+      // PIPE(load next block, MFMAs of this block): both live in ONE scheduling region and a
+      // sched_group_barrier sequence interleaves them -- per contraction step e: the W loads of
+      // step e of the NEXT block, then the NCTT MFMAs of step e of THIS block -- so the VMEM issue
+      // and its address arithmetic sit in the shadow of the 32-cycle MFMAs instead of in a gap.
+#ifndef PCS_ABLATE
+#define PCS_ABLATE 0
+#endif
+#if PCS_ABLATE == 3   /* debug build: no operand loads inside the channel loop */
+#define PCS_PIPE(LOAD, MFMA) MFMA; __builtin_amdgcn_sched_barrier(0);
+#else
+#define PCS_PIPE(LOAD, MFMA)                                                                       \
+  LOAD; MFMA;                                                                                      \
+  __builtin_amdgcn_sched_group_barrier(0x020, 1 + C::N4 + C::N2 + C::N1, 0);                       \
+  __builtin_amdgcn_sched_group_barrier(0x008, NCTT, 0);                                            \
+  __builtin_amdgcn_sched_group_barrier(0x020, C::N4 + C::N2 + C::N1, 0);                           \
+  __builtin_amdgcn_sched_group_barrier(0x008, NCTT, 0);                                            \
+  __builtin_amdgcn_sched_group_barrier(0x020, C::N4 + C::N2 + C::N1, 0);                           \
+  __builtin_amdgcn_sched_group_barrier(0x008, NCTT, 0);                                            \
+  __builtin_amdgcn_sched_group_barrier(0x020, C::N4 + C::N2 + C::N1, 0);                           \
+  __builtin_amdgcn_sched_group_barrier(0x008, NCTT, 0);                                            \
+  __builtin_amdgcn_sched_barrier(0);
+#endif
       for (int c0 = 0; c0 < a.cin - 32; c0 += 32) {
-        load_frag(f1, cur, c0 + 16);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_frag(f0, c0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_frag(f0, cur, c0 + 32);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_frag(f1, c0 + 16);
-        __builtin_amdgcn_sched_barrier(0);
+        PCS_PIPE(load_frag(f1, cur, c0 + 16), mfma_frag(f0, c0))
+        PCS_PIPE(load_frag(f0, cur, c0 + 32), mfma_frag(f1, c0 + 16))
       }
-      load_frag(f1, cur, a.cin - 16);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_frag(f0, a.cin - 32);
-      __builtin_amdgcn_sched_barrier(0);
+      PCS_PIPE(load_frag(f1, cur, a.cin - 16), mfma_frag(f0, a.cin - 32))
       make_ctx(nxt, pr_n, valid_n, in);
-      load_frag(f0, nxt, 0);  // first block of the next row block, in flight during the commit
       __builtin_amdgcn_sched_barrier(0);
-      mfma_frag(f1, a.cin - 16);
-      __builtin_amdgcn_sched_barrier(0);
+      // first block of the next row block: in flight during the last MFMAs and the commit
+      PCS_PIPE(load_frag(f0, nxt, 0), mfma_frag(f1, a.cin - 16))
+#undef PCS_PIPE
     } else {
       for (int c0 = 0; c0 < a.cin; c0 += 32) {  // branches are wave-uniform (kernel args)
         const bool has1 = c0 + 16 < a.cin;
@@ -704,6 +729,11 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os4_kernel(ConvArgs a) {
     // row block of the tile has committed, plain ds_read/add/ds_write, publish. Row blocks are
     // numbered offset-major, hence every dst element is summed in ascending-offset order -- the
     // reference's order -- and the result is bit-reproducible.
+#if PCS_ABLATE == 1   /* debug build: keep one cheap use of the accumulators, skip the commit */
+    { float t = 0.f; for (int q = 0; q < NCTT; ++q) t += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+      if (t == 1.2345e30f) acc_l[lane] = t + (float)dloc; }
+    continue;
+#endif
     if (lane == 0) {
       while (__hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != rb)
         __builtin_amdgcn_s_sleep(1);
@@ -752,6 +782,8 @@ template <int NCTT, int T, int NW, int MINW>
 int launch_conv4_cfg(const ConvArgs &a, hipStream_t st) {
   using C = Conv4Cfg<NCTT, T, NW>;
   const int64_t nblocks = a.ntiles * a.ncoltiles;
+  if (nblocks <= 0) return PCS_OK;
+  if (nblocks > 0x7FFFFFFF) { set_error("pcs_conv: grid too large"); return PCS_EUNSUPPORTED; }
   const bool e32 = (a.cin % 32) == 0;
   auto kern = e32 ? conv_os4_kernel<NCTT, T, true, NW, MINW> : conv_os4_kernel<NCTT, T, false, NW, MINW>;
   static bool attr_set[2] = {false, false};
@@ -766,13 +798,300 @@ int launch_conv4_cfg(const ConvArgs &a, hipStream_t st) {
 
 template <int NCTT, int T>
 int launch_conv4(const ConvArgs &a, hipStream_t st) {
-  const int64_t nblocks = a.ntiles * a.ncoltiles;
-  if (nblocks <= 0) return PCS_OK;
-  if (nblocks > 0x7FFFFFFF) { set_error("pcs_conv: grid too large"); return PCS_EUNSUPPORTED; }
   // workgroup shape: 4 waves with <= 168 VGPRs (default: 3 workgroups / CU) or 8 waves
   static const int nw = getenv("PCS_CONV_NW") ? atoi(getenv("PCS_CONV_NW")) : 4;
   if (nw == 4) return launch_conv4_cfg<NCTT, T, 4, 3>(a, st);
+  if (nw == 84) return launch_conv4_cfg<NCTT, T, 8, 4>(a, st);  // 8 waves, <= 128 VGPRs: 2 workgroups = 16 waves / CU
   return launch_conv4_cfg<NCTT, T, 8, 2>(a, st);
+}
+
+// ================================================================================================
+// v5 = v4 + row-block GROUPS. Ablation of v4 (profiles/round1_conv_pmc.md): with the MFMAs removed the
+// kernel still needs 60-77 % of its time -- every 16-row block streams its own copy of W[k] (Cin x CT fp32,
+// 37-131 KB) out of L2: 16-19 GB per layer, 12-17 TB/s. 8 flop per W byte cannot be fed by the L2.
+// Here one wave applies each W operand block to a GROUP of up to R consecutive row blocks of the same
+// offset (R accumulator sets), so W traffic per compact row drops R-fold where an offset has >= R row
+// blocks in the tile; the workgroup shape / tile height are chosen per layer so that it usually does.
+// Everything else is v4: register-direct operands, interleaved column tiles, sched_group_barrier
+// software pipeline, cross-group prefetch, ticket-ordered commit. Requires cin % 32 == 0.
+// ================================================================================================
+template <int NCTT, int T, int NW_, int R_>
+struct Conv5Cfg {
+  static constexpr int NW = NW_;
+  static constexpr int R = R_;
+  static constexpr int NT = 64 * NW;
+  static constexpr int CT = 16 * NCTT;
+  static constexpr int ACS = CT + 4;
+  static constexpr int N4 = NCTT / 4;
+  static constexpr int N2 = (NCTT % 4) / 2;
+  static constexpr int N1 = NCTT % 2;
+  static constexpr int NWL = N4 + N2 + N1;  // W loads per contraction step
+  static constexpr size_t lds_bytes = (size_t)((T + 1) * ACS) * 4 + 4 * 32 * 4 + 32;
+};
+
+template <int NCTT, int T, int NW, int MINW, int R>
+__global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
+  using C = Conv5Cfg<NCTT, T, NW, R>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *acc_l = reinterpret_cast<float *>(smem);            // [T+1][ACS], row T = sink for padding rows
+  int *kl_k = reinterpret_cast<int *>(acc_l + (T + 1) * C::ACS);  // [32] offset id
+  int *kl_s = kl_k + 32;                                     // [32] first pair
+  int *kl_m = kl_s + 32;                                     // [32] #pairs
+  int *kl_g = kl_m + 32;                                     // [33] first group (prefix)
+  int *commit = kl_g + 33;
+  __shared__ int nk_s;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  unsigned bid = blockIdx.x;
+  if (a.xcd_remap) {
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int64_t tile = bid / a.ncoltiles;
+  const int ctile = bid % a.ncoltiles;
+  const int n0 = ctile * C::CT;
+  const int64_t row0 = tile * T;
+  const int64_t nt1 = a.ntiles + 1;
+
+  if (wid == 0) {  // non-empty offsets of this tile + prefix of their row-block groups
+    const int k = lane;
+    int s0 = 0, m = 0;
+    if (k < a.K) {
+      s0 = a.seg[(int64_t)k * nt1 + tile];
+      m = a.seg[(int64_t)k * nt1 + tile + 1] - s0;
+    }
+    const unsigned long long mask = __ballot(m > 0);
+    const int ngr = (((m + 15) >> 4) + R - 1) / R;
+    int incl = ngr;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (m > 0) {
+      const int pos = __popcll(mask & ((1ULL << lane) - 1ULL));
+      kl_k[pos] = k; kl_s[pos] = s0; kl_m[pos] = m; kl_g[pos] = incl - ngr;
+    }
+    const int total = __shfl(incl, 63, 64);
+    if (lane == 0) { nk_s = __popcll(mask); kl_g[__popcll(mask)] = total; *commit = 0; }
+  }
+  for (int i = tid; i < (T + 1) * C::ACS; i += C::NT) acc_l[i] = 0.f;
+  __syncthreads();
+  const int nk = nk_s;
+  const int total_grp = nk > 0 ? kl_g[nk] : 0;
+
+  const int cin4 = a.cin - 4;
+  int col4[C::N4 > 0 ? C::N4 : 1];
+#pragma unroll
+  for (int q = 0; q < C::N4; ++q) {
+    const int c = 64 * q + 4 * l15;
+    col4[q] = (n0 + c + 4 <= a.cout) ? c : 0;
+  }
+  const int c2 = 64 * C::N4 + 2 * l15;
+  const int col2 = (n0 + c2 + 2 <= a.cout) ? c2 : 0;
+  const int c1 = 64 * C::N4 + 32 * C::N2 + l15;
+  const int col1 = (n0 + c1 < a.cout) ? c1 : 0;
+
+  struct Frag {  // one 16-channel block: A pieces of the R row blocks + the shared W rows
+    float4 a[R];
+    float4 b4[4][C::N4 > 0 ? C::N4 : 1];
+    float2 b2[4];
+    float b1[4];
+  };
+  struct Ctx {  // one group: R row blocks of one offset
+    const float *srow0[R];
+    const float *Wk;
+    int dloc[R];
+    int nr;  // row blocks really present (1..R)
+    unsigned vmask;  // bit r: this lane's row of block r is a real pair
+  };
+  auto load_frag = [&](Frag &f, const Ctx &cx, int c0) {
+    const int ca = c0 + 4 * g;  // cin % 32 == 0: always inside the row
+#pragma unroll
+    for (int r = 0; r < R; ++r) f.a[r] = *reinterpret_cast<const float4 *>(cx.srow0[r] + ca);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float *wp = cx.Wk + (int64_t)(ca + e) * a.cout;
+#pragma unroll
+      for (int q = 0; q < C::N4; ++q) f.b4[e][q] = *reinterpret_cast<const float4 *>(wp + col4[q]);
+      if (C::N2) f.b2[e] = *reinterpret_cast<const float2 *>(wp + col2);
+      if (C::N1) f.b1[e] = wp[col1];
+    }
+  };
+  // group grp -> its offset entry (i_hint only moves forward), pair index of this lane per row block
+  auto locate = [&](int grp, int &i_hint, int *pidx, unsigned &vmask, int &nr) {
+    while (kl_g[i_hint + 1] <= grp) ++i_hint;
+    const int m = kl_m[i_hint];
+    const int rb0 = (grp - kl_g[i_hint]) * R;
+    const int nrb = (m + 15) >> 4;
+    nr = nrb - rb0 < R ? nrb - rb0 : R;
+    vmask = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int rk = (rb0 + r) * 16 + l15;
+      const bool v = rk < m;
+      vmask |= v ? (1u << r) : 0u;
+      pidx[r] = kl_s[i_hint] + (v ? rk : m - 1);  // padding rows re-read the slice's last pair
+    }
+  };
+  auto make_ctx = [&](Ctx &cx, const int2 *pr, unsigned vmask, int nr, int i_k) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      cx.srow0[r] = a.src + (int64_t)(a.src_col ? pr[r].y : pr[r].x) * a.cin;
+      cx.dloc[r] = ((vmask >> r) & 1u) ? (int)((a.src_col ? pr[r].x : pr[r].y) - row0) : T;
+    }
+    cx.vmask = vmask;
+    cx.nr = nr;
+    cx.Wk = a.W + (int64_t)kl_k[i_k] * a.cin * a.cout + n0;
+  };
+
+  int i = 0;
+  Ctx cur;
+  Frag f0, f1;
+  if (wid < total_grp) {
+    int pidx[R]; unsigned vm; int nr;
+    locate(wid, i, pidx, vm, nr);
+    int2 pr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) pr[r] = reinterpret_cast<const int2 *>(a.pairs)[pidx[r]];
+    make_ctx(cur, pr, vm, nr, i);
+    load_frag(f0, cur, 0);
+  }
+  for (int grp = wid; grp < total_grp; grp += C::NW) {  // wave-uniform loop, no barrier inside
+    const int grpn = grp + C::NW < total_grp ? grp + C::NW : grp;
+    int in = i, pidx_n[R], nr_n; unsigned vm_n;
+    locate(grpn, in, pidx_n, vm_n, nr_n);
+    int2 pr_n[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) pr_n[r] = reinterpret_cast<const int2 *>(a.pairs)[pidx_n[r]];
+
+    f32x4 acc[R][NCTT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int t = 0; t < NCTT; ++t) acc[r][t] = (f32x4){0, 0, 0, 0};
+    const unsigned vmask = cur.vmask;
+    const int nr = cur.nr;  // wave-uniform
+    // MFMAs of one 16-channel block for the first NR row blocks of the group (NR is wave-uniform)
+    auto mfma_frag = [&](const Frag &f, auto nr_tag) {
+      constexpr int NR = decltype(nr_tag)::value;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const bool ok = (vmask >> r) & 1u;
+          const float av = ok ? (e == 0 ? f.a[r].x : (e == 1 ? f.a[r].y : (e == 2 ? f.a[r].z : f.a[r].w))) : 0.f;
+#pragma unroll
+          for (int q = 0; q < C::N4; ++q) {
+            acc[r][4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, f.b4[e][q].x, acc[r][4 * q + 0], 0, 0, 0);
+            acc[r][4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, f.b4[e][q].y, acc[r][4 * q + 1], 0, 0, 0);
+            acc[r][4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, f.b4[e][q].z, acc[r][4 * q + 2], 0, 0, 0);
+            acc[r][4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, f.b4[e][q].w, acc[r][4 * q + 3], 0, 0, 0);
+          }
+          if (C::N2) {
+            acc[r][4 * C::N4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, f.b2[e].x, acc[r][4 * C::N4 + 0], 0, 0, 0);
+            acc[r][4 * C::N4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, f.b2[e].y, acc[r][4 * C::N4 + 1], 0, 0, 0);
+          }
+          if (C::N1) acc[r][NCTT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, f.b1[e], acc[r][NCTT - 1], 0, 0, 0);
+        }
+      }
+    };
+    Ctx nxt;
+    // one scheduling region per block: per contraction step e the W loads of the NEXT block (plus,
+    // first, its R A pieces), then this block's NR*NCTT MFMAs of step e
+#define PCS_PIPE5(LOAD, FR, NRV)                                                                   \
+  LOAD; mfma_frag(FR, std::integral_constant<int, NRV>{});                                         \
+  __builtin_amdgcn_sched_group_barrier(0x020, R + C::NWL, 0);                                      \
+  __builtin_amdgcn_sched_group_barrier(0x008, NRV * NCTT, 0);                                      \
+  __builtin_amdgcn_sched_group_barrier(0x020, C::NWL, 0);                                          \
+  __builtin_amdgcn_sched_group_barrier(0x008, NRV * NCTT, 0);                                      \
+  __builtin_amdgcn_sched_group_barrier(0x020, C::NWL, 0);                                          \
+  __builtin_amdgcn_sched_group_barrier(0x008, NRV * NCTT, 0);                                      \
+  __builtin_amdgcn_sched_group_barrier(0x020, C::NWL, 0);                                          \
+  __builtin_amdgcn_sched_group_barrier(0x008, NRV * NCTT, 0);                                      \
+  __builtin_amdgcn_sched_barrier(0);
+#define PCS_BODY5(NRV)                                                                             \
+  {                                                                                                \
+    for (int c0 = 0; c0 < a.cin - 32; c0 += 32) {                                                  \
+      PCS_PIPE5(load_frag(f1, cur, c0 + 16), f0, NRV)                                              \
+      PCS_PIPE5(load_frag(f0, cur, c0 + 32), f1, NRV)                                              \
+    }                                                                                              \
+    PCS_PIPE5(load_frag(f1, cur, a.cin - 16), f0, NRV)                                             \
+    make_ctx(nxt, pr_n, vm_n, nr_n, in);                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    PCS_PIPE5(load_frag(f0, nxt, 0), f1, NRV)                                                      \
+  }
+    if (R >= 4 && nr == 4) PCS_BODY5((R >= 4 ? 4 : 1))
+    else if (R >= 3 && nr == 3) PCS_BODY5((R >= 3 ? 3 : 1))
+    else if (R >= 2 && nr == 2) PCS_BODY5((R >= 2 ? 2 : 1))
+    else PCS_BODY5(1)
+#undef PCS_BODY5
+#undef PCS_PIPE5
+    // ---- in-order commit of the group's row blocks (see v4) --------------------------------------------
+    if (lane == 0) {
+      while (__hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != grp)
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r < nr) {  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int dr = __shfl(cur.dloc[r], 4 * g + j, 64);
+          float *d = acc_l + dr * C::ACS;
+#pragma unroll
+          for (int q = 0; q < C::N4; ++q) {
+            float4 *p4 = reinterpret_cast<float4 *>(d + 64 * q + 4 * l15);
+            float4 v = *p4;
+            v.x += acc[r][4 * q + 0][j]; v.y += acc[r][4 * q + 1][j]; v.z += acc[r][4 * q + 2][j]; v.w += acc[r][4 * q + 3][j];
+            *p4 = v;
+          }
+          if (C::N2) {
+            float2 *p2 = reinterpret_cast<float2 *>(d + 64 * C::N4 + 2 * l15);
+            float2 v = *p2;
+            v.x += acc[r][4 * C::N4 + 0][j]; v.y += acc[r][4 * C::N4 + 1][j];
+            *p2 = v;
+          }
+          if (C::N1) d[64 * C::N4 + 32 * C::N2 + l15] += acc[r][NCTT - 1][j];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(commit, grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    cur = nxt;
+    i = in;
+  }
+  __syncthreads();
+  const int rows = (int)((a.n_dst - row0) < (int64_t)T ? (a.n_dst - row0) : (int64_t)T);
+  for (int e = tid; e < rows * (C::CT / 4); e += C::NT) {
+    const int r = e / (C::CT / 4), cq = (e % (C::CT / 4)) * 4;
+    if (n0 + cq < a.cout) {
+      float4 v = *reinterpret_cast<const float4 *>(acc_l + r * C::ACS + cq);
+      if (a.bias) {
+        const float4 b = *reinterpret_cast<const float4 *>(a.bias + n0 + cq);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      *reinterpret_cast<float4 *>(a.dst + (row0 + r) * a.cout + n0 + cq) = v;
+    }
+  }
+}
+
+template <int NCTT, int T, int NW, int MINW, int R>
+int launch_conv5(const ConvArgs &a, hipStream_t st) {
+  using C = Conv5Cfg<NCTT, T, NW, R>;
+  const int64_t nblocks = a.ntiles * a.ncoltiles;
+  if (nblocks <= 0) return PCS_OK;
+  if (nblocks > 0x7FFFFFFF) { set_error("pcs_conv: grid too large"); return PCS_EUNSUPPORTED; }
+  auto kern = conv_os5_kernel<NCTT, T, NW, MINW, R>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(C::NT), C::lds_bytes, st, a);
+  return check_launch("pcs_conv_gather_gemm_f32(v5)");
 }
 
 // ================================================================================================
@@ -1100,7 +1419,9 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
   }
   if (n_dst == 0) return PCS_OK;
   if (!W || !seg || !dst || (n_src > 0 && !src)) { set_error("pcs_conv_gather_gemm_f32: null pointer"); return PCS_EINVAL; }
-  if (tile_rows != 64 && tile_rows != 128) { set_error("pcs_conv_gather_gemm_f32: tile_rows must be 64 or 128"); return PCS_EINVAL; }
+  if (tile_rows != 64 && tile_rows != 96 && tile_rows != 128 && tile_rows != 256) { set_error("pcs_conv_gather_gemm_f32: tile_rows must be 64, 96, 128 or 256"); return PCS_EINVAL; }
+  static const int use_v1_early = getenv("PCS_CONV_V1") ? atoi(getenv("PCS_CONV_V1")) : 0;
+  if ((tile_rows == 256 || tile_rows == 96) && (use_v1_early || K > 32 || cin % 4 || cout % 4)) { set_error("pcs_conv_gather_gemm_f32: tile_rows 96/256 need the v4 kernel"); return PCS_EUNSUPPORTED; }
   ConvArgs a;
   a.src = src; a.W = W; a.bias = bias; a.dst = dst; a.pairs = pairs; a.seg = seg;
   a.n_dst = n_dst; a.ntiles = ceil_div(n_dst, tile_rows);
@@ -1111,6 +1432,28 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
   hipStream_t st = as_stream(stream);
   static const int use_v1 = getenv("PCS_CONV_V1") ? atoi(getenv("PCS_CONV_V1")) : 0;
   static const int use_v3 = getenv("PCS_CONV_V3") ? atoi(getenv("PCS_CONV_V3")) : 0;
+  // v5 (row-block groups of 2 sharing each W operand block) where the contraction is long enough to
+  // profit (cin >= 64, measured +3..6 %); PCS_CONV_V5=0 forces v4, 3/4 select larger groups (debug)
+  static const int v5r = getenv("PCS_CONV_V5") ? atoi(getenv("PCS_CONV_V5")) : 2;
+  if (vec && !use_v1 && !use_v3 && K <= 32 && v5r > 0 && cin % 32 == 0 && cin >= 64 &&
+      (tile_rows == 128 || tile_rows == 256)) {
+    int nctt = (cout + 15) / 16;
+    if (nctt > 8) nctt = 8;
+    if (nctt == 5) nctt = 6;
+    if (nctt == 7) nctt = 8;
+    a.ncoltiles = (int)ceil_div(cout, 16 * nctt);
+#define PCS_CONV5_CASE(N)                                                                           \
+  case N:                                                                                           \
+    if (tile_rows == 256) return v5r >= 4 ? launch_conv5<N, 256, 8, 2, 4>(a, st) : launch_conv5<N, 256, 8, 2, 2>(a, st); \
+    return v5r >= 3 ? launch_conv5<N, 128, 4, 2, 3>(a, st) : launch_conv5<N, 128, 4, 2, 2>(a, st);
+    switch (nctt) {
+      PCS_CONV5_CASE(2)
+      PCS_CONV5_CASE(4)
+      PCS_CONV5_CASE(6)
+      PCS_CONV5_CASE(8)
+    }
+#undef PCS_CONV5_CASE
+  }
   if (vec && !use_v1 && !use_v3 && K <= 32) {
     int nctt = (cout + 15) / 16;
     if (nctt > 8) nctt = 8;
@@ -1119,6 +1462,8 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
     a.ncoltiles = (int)ceil_div(cout, 16 * nctt);
 #define PCS_CONV4_CASE(N)                                                             \
   case N:                                                                             \
+    if (tile_rows == 256) return launch_conv4_cfg<N, 256, 8, 2>(a, st);               \
+    if (tile_rows == 96) return launch_conv4<N, 96>(a, st);                           \
     return tile_rows == 128 ? launch_conv4<N, 128>(a, st) : launch_conv4<N, 64>(a, st);
     switch (nctt) {
       PCS_CONV4_CASE(1)

@@ -10,7 +10,8 @@ from ctypes import c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_vo
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpcseg_hip.so")
+_LIB_PATH = os.environ.get("PCS_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                          "libpcseg_hip.so")  # PCS_LIB_PATH: debug builds only
 
 # symbol -> (restype, argtypes); kept in one table so tests can check every symbol that
 # include/pcseg_hip.h declares is exported.
