@@ -163,16 +163,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PCS_BENCH_ONE_DEVICE=1 (test rigs with a single GPU): every rank uses cuda:0 and gloo carries the
+    # collectives, to exercise the N > 1 code path; real runs use one GPU per rank and RCCL.
+    one_dev = os.environ.get("PCS_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+        if one_dev:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
 
     torch.manual_seed(0)
     model = MinkUNet(num_class=20, num_layer=MK34_LAYERS, cr=1.0, dist=distributed).to(dev).train()
     if distributed:
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index])
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.SGD(params, lr=0.02 * args.frames_per_gpu * world / 8, momentum=0.9, weight_decay=1e-4,
                           nesterov=True)
@@ -222,7 +229,7 @@ def main():
             "config": {"workload": "MinkUNet-34 cr1.0 train step (fwd + CE/Lovasz + bwd + SGD), SemanticKITTI-shape "
                                    "synthetic scans (120k pts, 0.05 m voxels), fp32",
                        "frames_per_gpu": args.frames_per_gpu, "global_batch": args.frames_per_gpu * world,
-                       "voxels_per_gpu_batch": n_vox, "parallelism": "dp%d" % world, "loss": round(float(loss), 4)},
+                       "voxels_per_gpu_batch": n_vox, "parallelism": "dp%d" % world, "loss": round(float(loss.detach()), 4)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -88,3 +88,50 @@ def test_ddp_gradients_match_concatenated_batch(oracle_backend):
         # DDP averages over ranks; the concatenated loss is the SUM of the per-frame losses
         assert np.allclose(2.0 * g_ddp, p.grad.numpy(), rtol=1e-4, atol=1e-5)
 
+
+
+def _bn_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    _patch()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from openpcseg_amd.fused import FusedBatchNorm
+    from openpcseg_amd.sparse import SparseTensor
+    torch.manual_seed(5)
+    full = torch.randn(300, 6) * 2 + 1
+    res = torch.randn(300, 6)
+    lo, hi = (0, 120) if rank == 0 else (120, 300)          # ragged shards
+    x = full[lo:hi].clone().requires_grad_(True)
+    bn = FusedBatchNorm(6, sync=True).train()
+    y = bn(SparseTensor(x, torch.zeros(hi - lo, 4, dtype=torch.int32)), residual=res[lo:hi], relu=True).F
+    (y * torch.arange(1, 7)).sum().backward()
+    out = [torch.zeros(300, 6) for _ in range(2)]
+    q.put((rank, y.detach().numpy(), x.grad.numpy(), bn.weight.grad.numpy(), bn.running_var.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_fused_batchnorm_matches_global_batch(oracle_backend):
+    """SyncBN semantics of FusedBatchNorm(sync=True): two ragged shards == one BatchNorm1d over all rows."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    torch.manual_seed(5)
+    full = (torch.randn(300, 6) * 2 + 1).requires_grad_(True)
+    res = torch.randn(300, 6)
+    ref = torch.nn.BatchNorm1d(6).train()
+    y = torch.relu(ref(full) + res)
+    (y * torch.arange(1, 7)).sum().backward()
+    y_sh = np.concatenate([got[0][1], got[1][1]])
+    gx_sh = np.concatenate([got[0][2], got[1][2]])
+    assert np.allclose(y_sh, y.detach().numpy(), atol=1e-5)
+    assert np.allclose(gx_sh, full.grad.numpy(), atol=1e-5)
+    assert np.allclose(got[0][3] + got[1][3], ref.weight.grad.numpy(), atol=1e-4)   # local sums add up (DDP averages)
+    assert np.allclose(got[0][4], ref.running_var.numpy(), rtol=1e-5)
