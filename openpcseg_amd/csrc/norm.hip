@@ -13,40 +13,69 @@ namespace {
 
 constexpr int kStatBlocks = 1024;  // partial rows; each workgroup strides over the feature rows
 
-// block = (TX lanes over channels, TY rows); partial[b][0][c] = sum x, partial[b][1][c] = sum x^2  (or dy / dy*xhat)
-template <bool BWD>
+template <int V> struct NV;
+template <> struct NV<4> { using T = float4; };
+template <> struct NV<1> { using T = float; };
+__device__ __forceinline__ float comp(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+__device__ __forceinline__ float comp(const float &v, int) { return v; }
+__device__ __forceinline__ void setc(float4 &v, int i, float s) { if (i == 0) v.x = s; else if (i == 1) v.y = s; else if (i == 2) v.z = s; else v.w = s; }
+__device__ __forceinline__ void setc(float &v, int, float s) { v = s; }
+
+
+// block = (TX lanes over channel VECTORS, TY rows); partial[b][0][c] = sum x, partial[b][1][c] = sum x^2
+// (backward: sum g, sum g*xhat with g = dy * [y > 0]). V = 4: 16-byte loads.
+template <bool BWD, int V>
 __global__ void __launch_bounds__(256) bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                          const float *__restrict__ y, const double *__restrict__ stat,
-                                                         int64_t n, int c, int relu, float *__restrict__ partial) {
-  extern __shared__ float red[];  // [TY][2][TXC]  (TXC = channels handled per pass = blockDim.x)
+                                                         int64_t n, int c, int cv, int relu, float *__restrict__ partial) {
+  using VT = typename NV<V>::T;
+  extern __shared__ float red[];  // [TY][2][TX*V]
   const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
-  for (int c0 = 0; c0 < c; c0 += TX) {
-    const int ch = c0 + tx;
-    float s0 = 0.f, s1 = 0.f;
-    if (ch < c) {
-      float mean = 0.f, invstd = 0.f;
-      if (BWD) { mean = (float)stat[ch]; invstd = (float)stat[c + ch]; }
+  const int W = TX * V;
+  for (int j0 = 0; j0 < cv; j0 += TX) {
+    const int j = j0 + tx;
+    float s0[V], s1[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
+    if (j < cv) {
+      float mean[V], invstd[V];
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        mean[q] = BWD ? (float)stat[j * V + q] : 0.f;
+        invstd[q] = BWD ? (float)stat[c + j * V + q] : 0.f;
+      }
       for (int64_t i = (int64_t)blockIdx.x * TY + ty; i < n; i += (int64_t)gridDim.x * TY) {
-        const float xv = x[i * c + ch];
+        const VT xv = reinterpret_cast<const VT *>(x + i * c)[j];
         if (BWD) {
-          float g = dy[i * c + ch];
-          if (relu && y[i * c + ch] <= 0.f) g = 0.f;
-          s0 += g;
-          s1 += g * ((xv - mean) * invstd);
+          const VT gv = reinterpret_cast<const VT *>(dy + i * c)[j];
+          VT yv; if (relu) yv = reinterpret_cast<const VT *>(y + i * c)[j];
+#pragma unroll
+          for (int q = 0; q < V; ++q) {
+            float g = comp(gv, q);
+            if (relu && comp(yv, q) <= 0.f) g = 0.f;
+            s0[q] += g;
+            s1[q] += g * ((comp(xv, q) - mean[q]) * invstd[q]);
+          }
         } else {
-          s0 += xv;
-          s1 += xv * xv;
+#pragma unroll
+          for (int q = 0; q < V; ++q) { const float t = comp(xv, q); s0[q] += t; s1[q] += t * t; }
         }
       }
     }
-    red[(ty * 2 + 0) * TX + tx] = s0;
-    red[(ty * 2 + 1) * TX + tx] = s1;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      red[(ty * 2 + 0) * W + tx * V + q] = s0[q];
+      red[(ty * 2 + 1) * W + tx * V + q] = s1[q];
+    }
     __syncthreads();
-    if (ty == 0 && ch < c) {
-      float a = 0.f, b = 0.f;
-      for (int r = 0; r < TY; ++r) { a += red[(r * 2 + 0) * TX + tx]; b += red[(r * 2 + 1) * TX + tx]; }
-      partial[((int64_t)blockIdx.x * 2 + 0) * c + ch] = a;
-      partial[((int64_t)blockIdx.x * 2 + 1) * c + ch] = b;
+    if (ty == 0 && j < cv) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < TY; ++r) { a += red[(r * 2 + 0) * W + tx * V + q]; b += red[(r * 2 + 1) * W + tx * V + q]; }
+        partial[((int64_t)blockIdx.x * 2 + 0) * c + j * V + q] = a;
+        partial[((int64_t)blockIdx.x * 2 + 1) * c + j * V + q] = b;
+      }
     }
     __syncthreads();
   }
@@ -87,14 +116,6 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const double *__restri
     running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
   }
 }
-
-template <int V> struct NV;
-template <> struct NV<4> { using T = float4; };
-template <> struct NV<1> { using T = float; };
-__device__ __forceinline__ float comp(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
-__device__ __forceinline__ float comp(const float &v, int) { return v; }
-__device__ __forceinline__ void setc(float4 &v, int i, float s) { if (i == 0) v.x = s; else if (i == 1) v.y = s; else if (i == 2) v.z = s; else v.w = s; }
-__device__ __forceinline__ void setc(float &v, int, float s) { v = s; }
 
 // y = act((x - mean) * invstd * w + b [+ res])
 template <int V>
@@ -183,11 +204,18 @@ extern "C" int32_t pcs_bn_num_partials(void) { return kStatBlocks; }
 
 static int bn_partial(bool bwd, const float *x, const float *dy, const float *y, const double *stat, int64_t n, int c,
                       int relu, float *partial, double *sums, hipStream_t st) {
-  int tx = 1; while (tx < c && tx < 64) tx <<= 1;
+  const bool vec = (c & 3) == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)y) & 15) == 0;
+  const int V = vec ? 4 : 1, cv = c / V;
+  int tx = 1; while (tx < cv && tx < 64) tx <<= 1;
   dim3 block(tx, 256 / tx);
-  const size_t lds = (size_t)(256 / tx) * 2 * tx * sizeof(float);
-  if (bwd) hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(kStatBlocks), block, lds, st, x, dy, y, stat, n, c, relu, partial);
-  else hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(kStatBlocks), block, lds, st, x, dy, y, stat, n, c, relu, partial);
+  const size_t lds = (size_t)(256 / tx) * 2 * tx * V * sizeof(float);
+  if (vec) {
+    if (bwd) hipLaunchKernelGGL((bn_partial_kernel<true, 4>), dim3(kStatBlocks), block, lds, st, x, dy, y, stat, n, c, cv, relu, partial);
+    else hipLaunchKernelGGL((bn_partial_kernel<false, 4>), dim3(kStatBlocks), block, lds, st, x, dy, y, stat, n, c, cv, relu, partial);
+  } else {
+    if (bwd) hipLaunchKernelGGL((bn_partial_kernel<true, 1>), dim3(kStatBlocks), block, lds, st, x, dy, y, stat, n, c, cv, relu, partial);
+    else hipLaunchKernelGGL((bn_partial_kernel<false, 1>), dim3(kStatBlocks), block, lds, st, x, dy, y, stat, n, c, cv, relu, partial);
+  }
   hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)ceil_div(2 * c, 64)), dim3(64, 16), 0, st, partial, kStatBlocks, c, sums);
   return check_launch("pcs_bn_partial");
 }

@@ -178,6 +178,44 @@ class _SparseConv(Function):
         return grad_input, grad_weight, None, None
 
 
+def _identity_map(n, device, cache):
+    """K = 1 map (i, i): lets the split-reduction wgrad kernel compute x^T @ dy of a 1x1x1 convolution."""
+    key = ("_pcs_identity", n)
+    km = cache.get(key)
+    if km is None:
+        idx = torch.arange(n, dtype=torch.int32, device=device)
+        km = native.KernelMap(torch.stack([idx, idx], dim=1).contiguous(),
+                              torch.tensor([0, n], dtype=torch.int32, device=device), [0, n],
+                              torch.tensor([n], dtype=torch.int64, device=device), n, n)
+        cache[key] = km
+    return km
+
+
+class _PointwiseConv(Function):
+    """1x1x1 convolution = feats @ weight (TS:torchsparse/nn/functional/conv.py:135-140). Forward and dgrad stay
+    dense GEMMs (hipBLASLt through torch); the weight gradient x^T @ dy has a (Cin, Cout) output and a
+    million-row contraction, which hipBLASLt runs on ~12 workgroups -- the split-reduction wgrad kernel is used."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, feats, weight, cache):
+        ctx.save_for_backward(feats, weight)
+        ctx.cache = cache
+        return feats.matmul(weight)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_output):
+        feats, weight = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        gin = grad_output.matmul(weight.t()) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            km = _identity_map(feats.shape[0], feats.device, ctx.cache)
+            gw = _be().conv_wgrad(feats.contiguous(), grad_output, km, 0)[0]
+        return gin, gw, None
+
+
 def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transposed=False):
     kernel_size = make_ntuple(kernel_size, ndim=3)
     stride = make_ntuple(stride, ndim=3)
@@ -187,7 +225,10 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
     if kernel_size == ones and stride == ones and dilation == ones:
         output_stride = input.stride
         output_coords = input.coords
-        output_feats = input.feats.matmul(weight)
+        if input.feats.is_cuda and weight.dim() == 2:
+            output_feats = _PointwiseConv.apply(input.feats, weight, input.kmaps)
+        else:
+            output_feats = input.feats.matmul(weight)
     elif not transposed:
         output_stride = tuple(input.stride[k] * stride[k] for k in range(3))
         if output_stride in input.cmaps:
