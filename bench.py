@@ -75,7 +75,7 @@ class ConvMeter:
         tfile = os.path.join(ROOT, "profiles", "round1_conv_traffic.json")
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-        return {"kernel": "conv_os4_kernel (pcs_conv_gather_gemm_f32: fwd + dgrad)", "bound": "mfma",
+        return {"kernel": "conv_os5_kernel / conv_os4_kernel (pcs_conv_gather_gemm_f32: fwd + dgrad)", "bound": "mfma",
                 "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, FETCH "

@@ -1419,7 +1419,7 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
   }
   if (n_dst == 0) return PCS_OK;
   if (!W || !seg || !dst || (n_src > 0 && !src)) { set_error("pcs_conv_gather_gemm_f32: null pointer"); return PCS_EINVAL; }
-  if (tile_rows != 64 && tile_rows != 96 && tile_rows != 128 && tile_rows != 256) { set_error("pcs_conv_gather_gemm_f32: tile_rows must be 64, 96, 128 or 256"); return PCS_EINVAL; }
+  if (tile_rows != 64 && tile_rows != 96 && tile_rows != 128 && tile_rows != 256 && tile_rows != 384 && tile_rows != 512) { set_error("pcs_conv_gather_gemm_f32: unsupported tile_rows"); return PCS_EINVAL; }
   static const int use_v1_early = getenv("PCS_CONV_V1") ? atoi(getenv("PCS_CONV_V1")) : 0;
   if ((tile_rows == 256 || tile_rows == 96) && (use_v1_early || K > 32 || cin % 4 || cout % 4)) { set_error("pcs_conv_gather_gemm_f32: tile_rows 96/256 need the v4 kernel"); return PCS_EUNSUPPORTED; }
   ConvArgs a;
@@ -1434,6 +1434,20 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
   static const int use_v3 = getenv("PCS_CONV_V3") ? atoi(getenv("PCS_CONV_V3")) : 0;
   // v5 (row-block groups of 2 sharing each W operand block) where the contraction is long enough to
   // profit (cin >= 64, measured +3..6 %); PCS_CONV_V5=0 forces v4, 3/4 select larger groups (debug)
+  // experimental "tall-narrow" shape: 48/64-column tiles, 384/512-row tiles, groups of 4 row blocks
+  static const int tall = getenv("PCS_CONV_TALL") ? atoi(getenv("PCS_CONV_TALL")) : 0;
+  if (tall && vec && K <= 32 && cin % 32 == 0 && (tile_rows == 256 || tile_rows == 384 || tile_rows == 512)) {
+    const bool n3 = (cout % 48 == 0) && cout <= 96;
+    a.ncoltiles = (int)ceil_div(cout, n3 ? 48 : 64);
+    if (n3) {
+      if (tile_rows == 512) return launch_conv5<3, 512, 8, 2, 4>(a, st);
+      if (tile_rows == 384) return launch_conv5<3, 384, 8, 2, 4>(a, st);
+      return launch_conv5<3, 256, 8, 2, 4>(a, st);
+    }
+    if (tile_rows == 512) return launch_conv5<4, 512, 8, 2, 4>(a, st);
+    if (tile_rows == 384) return launch_conv5<4, 384, 8, 2, 4>(a, st);
+    return launch_conv5<4, 256, 8, 2, 4>(a, st);
+  }
   static const int v5r = getenv("PCS_CONV_V5") ? atoi(getenv("PCS_CONV_V5")) : 2;
   if (vec && !use_v1 && !use_v3 && K <= 32 && v5r > 0 && cin % 32 == 0 && cin >= 64 &&
       (tile_rows == 128 || tile_rows == 256)) {

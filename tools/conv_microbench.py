@@ -37,6 +37,10 @@ def main():
         be.conv_gather_gemm(x, w, entry.fwd, tile_rows=tile)
         be.conv_wgrad(x, gy, entry.fwd, 0)
     torch.cuda.synchronize()
+    if tile is not None:  # cross-check the selected tile shape against the default path
+        ref = be.conv_gather_gemm(x, w, entry.fwd, tile_rows=128)
+        got = be.conv_gather_gemm(x, w, entry.fwd, tile_rows=tile)
+        print("max rel diff vs tile 128: %.2e" % float((ref - got).abs().max() / ref.abs().max()))
     for name, fn in [("gemm", lambda: be.conv_gather_gemm(x, w, entry.fwd, tile_rows=tile)),
                      ("wgrad", lambda: be.conv_wgrad(x, gy, entry.fwd, 0))]:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
