@@ -217,5 +217,112 @@ def make_e2e(ts):
             "state_keys": np.array(sorted(model.state_dict().keys()))}
 
 
+def _cfg(**kw):
+    return _AttrDict(IGNORE_LABEL=0, DROPOUT_P=0.0, IF_DIST=False, **kw)
+
+
+def cylinder_inputs(seed=0, n_points=2500, grid=(120, 90, 16)):
+    """Small cylindrical partition of a synthetic scan, following the reference dataset transform
+    (R:pcseg/data/dataset/semantickitti/semantickitti_cylinder.py:19-22,144-160) on a reduced grid."""
+    from openpcseg_amd.workloads.synthetic import make_scan
+    pts = make_scan(seed, n_points)
+    xyz = pts[:, :3]
+    rho = np.sqrt(xyz[:, 0] ** 2 + xyz[:, 1] ** 2)
+    phi = np.arctan2(xyz[:, 1], xyz[:, 0])
+    pol = np.stack([rho, phi, xyz[:, 2]], axis=1)
+    lo, hi = np.array([0.0, -np.pi, -4.0]), np.array([50.0, np.pi, 2.0])
+    pol = np.clip(pol, lo, hi)
+    intervals = (hi - lo) / (np.array(grid) - 1)
+    gi = np.floor((pol - lo) / intervals).astype(np.int32)
+    centre = (gi.astype(np.float32) + 0.5) * intervals + lo
+    feat = np.concatenate([pol - centre, pol, xyz[:, :2], pts[:, 3:4]], axis=1).astype(np.float32)  # 9 dims
+    rng = np.random.default_rng(seed + 7)
+    plabel = rng.integers(0, 20, size=n_points).astype(np.int64)
+    pc = np.concatenate([gi, np.zeros((n_points, 1), np.int32)], axis=1)
+    vox, first = np.unique(pc, axis=0, return_index=True)
+    return {"point_feature": torch.from_numpy(feat), "point_coord": torch.from_numpy(pc),
+            "voxel_coord": torch.from_numpy(vox.astype(np.int32)), "voxel_label": torch.from_numpy(plabel[first]),
+            "point_label": torch.from_numpy(plabel), "offset": torch.tensor([n_points], dtype=torch.int32)}
+
+
+def import_reference_model(dotted):
+    import_reference_minkunet()  # installs the import stubs + sys.path
+    import importlib
+    return importlib.import_module(dotted)
+
+
+def run_reference_spvcnn():
+    from openpcseg_amd.workloads.synthetic import make_batch
+    mod = import_reference_model("pcseg.model.segmentor.fusion.spvcnn.spvcnn")
+    cfg = _cfg(NAME="SPVCNN", IN_FEATURE_DIM=4, BLOCK="ResBlock", NUM_LAYER=[2, 2, 2, 2, 2, 2, 2, 2],
+               PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96], cr=0.25, LABEL_SMOOTHING=0.1)
+    torch.manual_seed(0)
+    model = mod.SPVCNN(cfg, 20)
+    seeded_state(model)
+    model.train()
+    batch = make_batch([3], n_points=2000)
+    feats, coords = batch["lidar"].feats.clone(), batch["lidar"].coords.clone()
+    cap = {}
+    model.classifier.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", o.detach().clone()))
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        ret, _, _ = model(batch)
+    finally:
+        torch.Tensor.cuda = orig
+    return {"spv_feats": feats.numpy(), "spv_coords": coords.numpy(), "spv_labels": batch["targets"].feats.numpy(),
+            "spv_logits": cap["logits"].numpy(), "spv_loss": np.array(float(ret["loss"].detach()))}
+
+
+def run_reference_cylinder():
+    mod = import_reference_model("pcseg.model.segmentor.voxel.cylinder3d.cylinder_ts")
+    cfg = _cfg(NAME="Cylinder_TS", IN_FEATURE_DIM=9, LABEL_SMOOTHING=0.0, INIT_SIZE=8, POINT_REFINEMENT=True)
+    torch.manual_seed(0)
+    model = mod.Cylinder_TS(cfg, 20)
+    seeded_state(model)
+    model.train()
+    inp = cylinder_inputs()
+    cap = {}
+    model.logits.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", (o.F.detach().clone(), o.C.clone())))
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        ret = model({k: v.clone() for k, v in inp.items()})
+    finally:
+        torch.Tensor.cuda = orig
+    ret = ret[0] if isinstance(ret, tuple) else ret
+    out = {"cyl_" + k: v.numpy() for k, v in inp.items()}
+    out["cyl_logits"], out["cyl_logit_coords"] = cap["logits"][0].numpy(), cap["logits"][1].numpy()
+    out["cyl_loss"] = np.array(float(ret["loss"].detach()))
+    return out
+
+
+def main_models():
+    """SPVCNN (config 3) and Cylinder_TS (config 4): the reference's own model code on the reference backend."""
+    import_reference_torchsparse()
+    ts_mod = types.ModuleType("torch_scatter")  # not installed here: torch_scatter semantics via scatter_reduce
+
+    def scatter_max(src, index, dim=0):
+        m = int(index.max()) + 1
+        out = torch.zeros(m, src.shape[1]).scatter_reduce(0, index[:, None].expand(-1, src.shape[1]), src, "amax",
+                                                          include_self=False)
+        return out, None
+
+    def scatter_mean(src, index, dim=0):
+        m = int(index.max()) + 1
+        return torch.zeros(m, src.shape[1]).scatter_reduce(0, index[:, None].expand(-1, src.shape[1]), src, "mean",
+                                                           include_self=False)
+    ts_mod.scatter_max, ts_mod.scatter_mean = scatter_max, scatter_mean
+    sys.modules["torch_scatter"] = ts_mod
+    g = {}
+    g.update(run_reference_spvcnn())
+    g.update(run_reference_cylinder())
+    np.savez_compressed(os.path.join(OUT, "models_e2e_golden.npz"), **g)
+    print("wrote models_e2e_golden.npz:", {k: v.shape for k, v in g.items() if "logits" in k})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "models":
+        main_models()
+    else:
+        main()
