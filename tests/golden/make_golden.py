@@ -297,6 +297,78 @@ def run_reference_cylinder():
     return out
 
 
+def rpvnet_inputs(seed=5, n_points=2000, h=64, w=512):
+    """lidar batch + (5,H,W) range image + per-point (batch, px, py) in [-1,1], in the spirit of
+    R:pcseg/data/dataset/semantickitti/semantickitti_fusion.py:64-114 (spherical projection)."""
+    from openpcseg_amd.workloads.synthetic import make_batch, make_scan
+    batch = make_batch([seed], n_points=n_points)
+    pts = batch["lidar"].feats.numpy()
+    xyz = pts[:, :3]
+    depth = np.linalg.norm(xyz, axis=1) + 1e-6
+    yaw, pitch = -np.arctan2(xyz[:, 1], xyz[:, 0]), np.arcsin(xyz[:, 2] / depth)
+    fu, fd = np.deg2rad(3.0), np.deg2rad(-25.0)
+    px = 0.5 * (yaw / np.pi + 1.0)
+    py = 1.0 - (pitch - fd) / (fu - fd)
+    ix = np.clip(np.floor(px * w), 0, w - 1).astype(np.int64)
+    iy = np.clip(np.floor(py * h), 0, h - 1).astype(np.int64)
+    img = np.zeros((5, h, w), np.float32)
+    img[0, iy, ix], img[1, iy, ix] = depth, pts[:, 3]
+    img[2:, iy, ix] = xyz.T
+    pxpy = np.stack([np.zeros(len(px)), np.clip(px * 2 - 1, -1, 1), np.clip(py * 2 - 1, -1, 1)], 1).astype(np.float32)
+    batch["range_image"] = torch.from_numpy(img)[None]
+    batch["range_pxpy"] = torch.from_numpy(pxpy)
+    return batch
+
+
+def run_reference_rpvnet():
+    """RPVNet (config 5). range_lib has no CPU build in the reference: its two ops are served here by the
+    restatement of RL:range_utils/src/*.cu (oracle.map_count / denselize_fwd); everything else is the reference."""
+    from oracle import oracle as orc
+
+    class _Dense(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, feat, cm, pxpy):
+            return torch.from_numpy(orc.denselize_fwd(feat.detach().numpy(), cm.numpy(), pxpy.numpy()))
+
+    fn = types.ModuleType("range_utils.nn.functional")
+    fn.map_count = lambda pxpy, b, h, w: torch.from_numpy(orc.map_count(pxpy.numpy(), b, h, w))
+    fn.denselize = lambda feat, cm, pxpy: _Dense.apply(feat, cm, pxpy)
+    for name in ("range_utils", "range_utils.nn"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["range_utils.nn.functional"] = fn
+    sys.modules["range_utils.nn"].functional = fn
+    sys.modules["range_utils"].nn = sys.modules["range_utils.nn"]
+    mod = import_reference_model("pcseg.model.segmentor.fusion.rpvnet.rpvnet")
+    mod.rnf = fn
+    # the reference's IF_DIST=False variant is broken (rpvnet.py:574 applies the SparseTensor BatchNorm wrapper
+    # to plain tensors), so the shipped IF_DIST=True variant is used -- in eval mode, where nn.SyncBatchNorm
+    # runs on the CPU (running statistics), and the logits are captured at the classifier.
+    cfg = _cfg(NAME="RPVNet", IN_FEATURE_DIM=4, BLOCK="ResBlock", NUM_LAYER=[2] * 8,
+               PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96], cr=0.25, LABEL_SMOOTHING=0.1)
+    cfg["IF_DIST"] = True
+    torch.manual_seed(0)
+    model = mod.RPVNet(cfg, 20)
+    seeded_state(model)
+    model.eval()
+    batch = rpvnet_inputs()
+    keep = {"rpv_feats": batch["lidar"].feats.numpy().copy(), "rpv_coords": batch["lidar"].coords.numpy().copy(),
+            "rpv_labels": batch["targets"].feats.numpy().copy(), "rpv_range_image": batch["range_image"].numpy().copy(),
+            "rpv_range_pxpy": batch["range_pxpy"].numpy().copy()}
+    cap = {}
+    model.classifier.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", o.detach().clone()))
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with torch.no_grad():
+            model(batch)
+    except KeyError:
+        pass  # the eval branch wants dataset-only keys (inverse_map, ...) after the classifier ran
+    finally:
+        torch.Tensor.cuda = orig
+    keep["rpv_logits"] = cap["logits"].numpy()
+    return keep
+
+
 def main_models():
     """SPVCNN (config 3) and Cylinder_TS (config 4): the reference's own model code on the reference backend."""
     import_reference_torchsparse()
@@ -317,6 +389,7 @@ def main_models():
     g = {}
     g.update(run_reference_spvcnn())
     g.update(run_reference_cylinder())
+    g.update(run_reference_rpvnet())
     np.savez_compressed(os.path.join(OUT, "models_e2e_golden.npz"), **g)
     print("wrote models_e2e_golden.npz:", {k: v.shape for k, v in g.items() if "logits" in k})
 

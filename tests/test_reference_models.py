@@ -84,3 +84,38 @@ def test_reference_cylinder_on_our_api(gold, oracle_backend):
     assert np.abs(cap["out"][0].numpy() - gold["cyl_logits"]).max() < 1e-3
     assert abs(float(ret["loss"].detach()) - float(gold["cyl_loss"])) < 1e-3
     ret["loss"].backward()
+
+
+def test_reference_rpvnet_on_our_api(gold, oracle_backend):
+    """Config 5 (range-point-voxel fusion): adds range_utils.map_count / denselize (K13/K14) to the surface.
+    Eval mode with the shipped IF_DIST=True variant (the reference's IF_DIST=False RPVNet is broken,
+    rpvnet.py:574); logits captured at the classifier."""
+    from openpcseg_amd.sparse import SparseTensor
+    from seeded import seeded_state
+    mg, mod = _load("pcseg.model.segmentor.fusion.rpvnet.rpvnet")
+    mod.rnf = sys.modules["range_utils.nn.functional"]
+    cfg = mg._cfg(NAME="RPVNet", IN_FEATURE_DIM=4, BLOCK="ResBlock", NUM_LAYER=[2] * 8,
+                  PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96], cr=0.25, LABEL_SMOOTHING=0.1)
+    cfg["IF_DIST"] = True
+    model = mod.RPVNet(cfg, 20)
+    seeded_state(model)
+    model.eval()
+    coords = torch.from_numpy(gold["rpv_coords"])
+    batch = {"lidar": SparseTensor(torch.from_numpy(gold["rpv_feats"]), coords),
+             "targets": SparseTensor(torch.from_numpy(gold["rpv_labels"]), coords),
+             "range_image": torch.from_numpy(gold["rpv_range_image"]), "range_pxpy": torch.from_numpy(gold["rpv_range_pxpy"])}
+    cap = {}
+    model.classifier.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", o.detach()))
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with torch.no_grad():
+            model(batch)
+    except KeyError:
+        pass
+    finally:
+        torch.Tensor.cuda = orig
+    # eval-mode BatchNorm runs on its initial running stats (identity), so the seeded weights grow the logits to
+    # ~1e9: the bound is relative (fp32 summation order is the only difference)
+    ref = gold["rpv_logits"]
+    assert np.abs(cap["logits"].numpy() - ref).max() < 1e-5 * np.abs(ref).max()
