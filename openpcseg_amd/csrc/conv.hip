@@ -1258,6 +1258,60 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
   }
 }
 
+// Same sum for 16-byte-granular weight blocks, spread over the chip also when K is 1 or 8 (pointwise and
+// 2x2x2 layers have hundreds of splits per offset): a workgroup owns 64 consecutive elements of one offset;
+// its 16 split lanes each sum every 16th split (4 independent loads in flight), and the 16 partial sums are
+// combined in lane order through LDS, so the result does not depend on the launch.
+__global__ void __launch_bounds__(256) wgrad_reduce4_kernel(const float *__restrict__ partial,
+                                                            const int32_t *__restrict__ koff,
+                                                            int K, int pch, int64_t cc,
+                                                            float *__restrict__ gW) {
+  const int k = blockIdx.y;
+  __shared__ int sh[2];
+  __shared__ float4 red[16][16];
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int q = 0; q < k; ++q) acc += (koff[q + 1] - koff[q] + pch - 1) / pch;
+    sh[0] = acc;
+    sh[1] = (koff[k + 1] - koff[k] + pch - 1) / pch;
+  }
+  __syncthreads();
+  const int base = sh[0], ns = sh[1];
+  const int et = threadIdx.x & 15, ql = threadIdx.x >> 4;
+  const int64_t e = ((int64_t)blockIdx.x * 16 + et) * 4;
+  const bool ok = e < cc;
+  const float *p = partial + (int64_t)base * cc + (ok ? e : 0);
+  float4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
+  int q = ql;
+  for (; q + 48 < ns; q += 64) {
+    const float4 v0 = *reinterpret_cast<const float4 *>(p + (int64_t)q * cc);
+    const float4 v1 = *reinterpret_cast<const float4 *>(p + (int64_t)(q + 16) * cc);
+    const float4 v2 = *reinterpret_cast<const float4 *>(p + (int64_t)(q + 32) * cc);
+    const float4 v3 = *reinterpret_cast<const float4 *>(p + (int64_t)(q + 48) * cc);
+    s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+    s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+    s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
+    s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
+  }
+  for (; q < ns; q += 16) {
+    const float4 v0 = *reinterpret_cast<const float4 *>(p + (int64_t)q * cc);
+    s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+  }
+  s0.x += s1.x + (s2.x + s3.x); s0.y += s1.y + (s2.y + s3.y);
+  s0.z += s1.z + (s2.z + s3.z); s0.w += s1.w + (s2.w + s3.w);
+  red[ql][et] = s0;
+  __syncthreads();
+  if (ql == 0 && ok) {
+    float4 t = red[0][et];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      const float4 v = red[j][et];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(gW + (int64_t)k * cc + e) = t;
+  }
+}
+
 // ================================================================================================
 // wgrad v2: wave-autonomous, operands straight from HBM/L2 into MFMA layout, no LDS, no barrier.
 //   gW[k][a][b] = sum over the pairs p of offset k:  fa[ia_p][a] * fb[ib_p][b]
@@ -1389,7 +1443,8 @@ int wgrad_plan(const int32_t *koff_host, int K, int ca, int cb, int *pch_out) {
   // ~3072 workgroups in total (each = 4 output blocks of one split), >= 64 pairs per split
   const int nbq = (wg_ngroups(ca) * wg_ngroups(cb) + 3) / 4;
   int64_t P = koff_host[K] - koff_host[0];
-  int64_t target = 3072 / nbq;
+  static const int total = getenv("PCS_WGRAD_WGS") ? atoi(getenv("PCS_WGRAD_WGS")) : 3072;
+  int64_t target = total / nbq;
   if (target < K) target = K;
   int pch = (int)ceil_div(P > 0 ? P : 1, target);
   pch = (int)(ceil_div(pch, 32) * 32);
@@ -1572,9 +1627,14 @@ extern "C" int pcs_conv_wgrad_f32(const float *fa, int32_t ca, const float *fb, 
   }
   int rc = check_launch("pcs_conv_wgrad_f32");
   if (rc) return rc;
-  int gx = (int)ceil_div(cc, 256);
-  if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, K), dim3(256), 0, st,
-                     reinterpret_cast<const float *>(ws), koff_dev, (int)K, pch, cc, gW);
+  if (vec && (((uintptr_t)ws | (uintptr_t)gW) & 15) == 0) {
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)ceil_div(cc, 64), K), dim3(256), 0, st,
+                       reinterpret_cast<const float *>(ws), koff_dev, (int)K, pch, cc, gW);
+  } else {
+    int gx = (int)ceil_div(cc, 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, K), dim3(256), 0, st,
+                       reinterpret_cast<const float *>(ws), koff_dev, (int)K, pch, cc, gW);
+  }
   return check_launch("pcs_conv_wgrad_f32(reduce)");
 }

@@ -26,10 +26,11 @@ def lovasz_softmax(probas, labels, ignore=None):
     if probas.numel() == 0:
         return probas.sum() * 0.0
     losses = []
+    present = (torch.bincount(labels, minlength=probas.shape[1]) > 0).tolist()  # one host sync, not one per class
     for c in range(probas.shape[1]):
-        fg = (labels == c).float()
-        if fg.sum() == 0:
+        if not present[c]:
             continue
+        fg = (labels == c).float()
         err = (fg - probas[:, c]).abs()
         err_sorted, perm = torch.sort(err, 0, descending=True)
         losses.append(torch.dot(err_sorted, lovasz_grad(fg[perm])))
@@ -37,10 +38,21 @@ def lovasz_softmax(probas, labels, ignore=None):
 
 
 class SegLoss(torch.nn.Module):
+    """CrossEntropyLoss(ignore_index, label_smoothing) + Lovasz-softmax on one shared log-softmax. The CE terms are
+    written out (picked log-probability + smoothing term, masked mean) because torch's nll_loss reduction runs on a
+    single workgroup (1.3 ms forward + 1.3 ms backward for 1.2 M rows); same value as torch.nn.CrossEntropyLoss."""
+
     def __init__(self, ignore_index=0, label_smoothing=0.0):
         super().__init__()
         self.ignore_index = ignore_index
-        self.ce = torch.nn.CrossEntropyLoss(ignore_index=ignore_index, label_smoothing=label_smoothing)
+        self.label_smoothing = float(label_smoothing)
 
     def forward(self, logits, target):
-        return self.ce(logits, target) + lovasz_softmax(logits.softmax(dim=1), target, ignore=self.ignore_index)
+        logp = F.log_softmax(logits, dim=1)
+        keep = target != self.ignore_index
+        picked = logp.gather(1, target.clamp(0, logits.shape[1] - 1).unsqueeze(1)).squeeze(1)
+        per_row = -(1.0 - self.label_smoothing) * picked
+        if self.label_smoothing > 0:
+            per_row = per_row - self.label_smoothing * logp.mean(dim=1)
+        ce = (per_row * keep).sum() / keep.sum()
+        return ce + lovasz_softmax(logp.exp(), target, ignore=self.ignore_index)
