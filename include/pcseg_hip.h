@@ -182,9 +182,14 @@ int pcs_rulebook_tile_segments(const int32_t *pairs, const int32_t *koff, int32_
  *   src (n_src, cin), W (K, cin, cout), dst (n_dst, cout); pairs (P,2) with the src row in
  *   column src_col and the dst row in column 1-src_col, sorted k-major / dst ascending;
  *   seg from pcs_rulebook_tile_segments with the same tile_rows; bias (cout) or NULL.
- * pcs_conv_tile_rows returns the tile height this library uses for (cin, cout).
+ *   tile_rows: a multiple of 16 in [16, 512]; shapes outside the 16-byte-granular, cin >= 64 kernel
+ *   take 64 or 128 only (PCS_EUNSUPPORTED otherwise).
+ * pcs_conv_tile_rows returns the default tile height for (cin, cout); pcs_conv_pick_tile_rows the
+ * height for one layer call: with few dst rows (deep strides) the launch is only a few waves of
+ * workgroups over the CUs, and the height is chosen so that the last wave is full.
  */
 int32_t pcs_conv_tile_rows(int32_t cin, int32_t cout);
+int32_t pcs_conv_pick_tile_rows(int64_t n_dst, int64_t n_pairs, int32_t K, int32_t cin, int32_t cout);
 int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t cin, const float *W,
                              int32_t K, int32_t cout, const int32_t *pairs, int32_t src_col,
                              const int32_t *seg, int32_t tile_rows, int64_t n_dst,

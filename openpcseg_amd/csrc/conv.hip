@@ -41,8 +41,10 @@ struct ConvArgs {
   const int32_t *seg;
   int64_t n_dst;
   int64_t ntiles;
-  int cin, cout, K, src_col, ncoltiles, xcd_remap;
+  int cin, cout, K, src_col, ncoltiles, xcd_remap, tile_rows;
 };
+
+constexpr size_t kMaxDynLds = 160 * 1024 - 256;  // per-workgroup LDS ceiling of a gfx950 CU, minus the static part
 
 template <int CG, int RG, int T>
 struct ConvCfg {
@@ -212,267 +214,6 @@ int launch_conv(const ConvArgs &a, bool vec, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(C::NT), C::lds_bytes, st, a);
   return check_launch("pcs_conv_gather_gemm_f32");
-}
-
-// ================================================================================================
-// v2 of the same dataflow: software-pipelined.
-//   * steps = (non-empty offset k) x (cin chunk of 32); the (k, slice, m) list of the tile is
-//     compacted into LDS once, empty offsets cost nothing;
-//   * the gathered A rows, the W chunk and the NEXT offset's pair slice are prefetched into
-//     registers one step ahead (global loads in flight under the MFMAs), LDS tiles are double
-//     buffered -> ONE barrier per step instead of two;
-//   * MFMA work units are (16-row block, 16-col tile) pairs dealt round-robin to the 8 waves,
-//     so a 16-row compact tile still keeps every SIMD busy and a 128-row one is balanced.
-// Only for shapes with cin % 4 == 0 and cout % 4 == 0 (16-byte row granules); others use v1.
-// ================================================================================================
-// NU independent 16x16 output tiles (work units unit0, unit0+stride, ...) over one 32-deep chunk.
-template <int NCTT, int WS, int NU>
-__device__ __forceinline__ void mfma_group(const float *ab, const float *wb, f32x4 *acc, int unit0,
-                                           int stride, int lane) {
-  const int g = lane >> 4, l15 = lane & 15;
-  const float *ap[NU];
-  const float *bp[NU];
-#pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    const int unit = unit0 + u * stride;
-    const int rb = unit / NCTT, ct = unit - rb * NCTT;
-    ap[u] = ab + (rb * 16 + l15) * AS + g;
-    bp[u] = wb + g * WS + ct * 16 + l15;
-  }
-#pragma unroll
-  for (int kk = 0; kk < CK / 4; ++kk) {
-#pragma unroll
-    for (int u = 0; u < NU; ++u)
-      acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[u][kk * 4], bp[u][kk * 4 * WS], acc[u], 0, 0, 0);
-  }
-}
-
-template <int NCTT, int T>
-struct Conv2Cfg {
-  static constexpr int NW = 8;
-  static constexpr int NT = 64 * NW;
-  static constexpr int CT = 16 * NCTT;
-  static constexpr int ACS = CT + 4;
-  static constexpr int WS = (CT % 32 == 0) ? CT + 16 : CT + 32;  // == 16 (mod 32)
-  static constexpr int MAXU = ((T / 16) * NCTT + NW - 1) / NW;
-  static constexpr int UG = MAXU < 4 ? MAXU : 4;                    // units per MFMA group
-  static constexpr int AL = (T * (CK / 4) + NT - 1) / NT;          // float4 A granules / thread
-  static constexpr int WL = (CK * (CT / 4) + NT - 1) / NT;         // float4 W granules / thread
-  static constexpr int D = 3;                                       // steps of loads in flight
-  static constexpr int KMAX = 27;                                   // max kernel volume (v1 beyond)
-  static constexpr int PCAP = KMAX * T;                             // pairs of one tile
-  static constexpr int PL = (PCAP + NT - 1) / NT;
-  static constexpr size_t lds_bytes = (size_t)(T * ACS + 2 * T * AS + 2 * CK * WS) * 4 +
-                                      (size_t)PCAP * 4 + (size_t)PCAP + (size_t)3 * 32 * 4 + 16;
-};
-
-template <int NCTT, int T>
-__global__ void __launch_bounds__(512) conv_os2_kernel(ConvArgs a) {
-  using C = Conv2Cfg<NCTT, T>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float *acc_l = reinterpret_cast<float *>(smem);          // [T][ACS]
-  float *wbuf = acc_l + T * C::ACS;                        // [2][CK][WS]
-  float *abuf = wbuf + 2 * CK * C::WS;                     // [2][T][AS]
-  int *sidx = reinterpret_cast<int *>(abuf + 2 * T * AS);  // [PCAP] src row of every pair of the tile
-  int *kl_k = sidx + C::PCAP;                              // [32] offset id of the i-th non-empty offset
-  int *kl_o = kl_k + 32;                                   // [32] start of its slice inside sidx/drow
-  int *kl_s = kl_o + 32;                                   // [32] first pair (absolute)
-  unsigned char *drow = reinterpret_cast<unsigned char *>(kl_s + 32);  // [PCAP] local dst row
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int g = lane >> 4, l15 = lane & 15;
-  const int64_t tile = blockIdx.x / a.ncoltiles;
-  const int ctile = blockIdx.x % a.ncoltiles;
-  const int n0 = ctile * C::CT;
-  const int64_t row0 = tile * T;
-  const int64_t nt1 = a.ntiles + 1;
-  const int nchunks = (a.cin + CK - 1) / CK;
-
-  // ---- compact list of the non-empty offsets of this tile (wave 0, ballot + scan) ---------------
-  __shared__ int nk_s, np_s;
-  if (wid == 0) {
-    const int k = lane;
-    int s0 = 0, m = 0;
-    if (k < a.K) {
-      s0 = a.seg[(int64_t)k * nt1 + tile];
-      m = a.seg[(int64_t)k * nt1 + tile + 1] - s0;
-    }
-    const unsigned long long mask = __ballot(m > 0);
-    int incl = m;  // inclusive scan of m over the lanes
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
-    if (m > 0) {
-      const int pos = __popcll(mask & ((1ULL << lane) - 1ULL));
-      kl_k[pos] = k; kl_o[pos] = incl - m; kl_s[pos] = s0;
-    }
-    const int total = __shfl(incl, 63, 64);
-    if (lane == 0) { nk_s = __popcll(mask); np_s = total; kl_o[__popcll(mask)] = total; }
-  }
-  for (int i = tid; i < T * C::ACS; i += C::NT) acc_l[i] = 0.f;
-  __syncthreads();
-  const int nk = nk_s, np = np_s;
-  const int rows = (int)((a.n_dst - row0) < (int64_t)T ? (a.n_dst - row0) : (int64_t)T);
-
-  if (nk > 0) {
-    // ---- every pair of the tile -> LDS (src row as int32, local dst row as uint8) ---------------
-    {
-      int2 pr[C::PL];
-#pragma unroll
-      for (int q = 0; q < C::PL; ++q) {
-        const int e = tid + q * C::NT;
-        pr[q] = make_int2(0, 0);
-        if (e < np) {
-          int i = 0;
-          while (kl_o[i + 1] <= e) ++i;
-          pr[q] = reinterpret_cast<const int2 *>(a.pairs)[kl_s[i] + (e - kl_o[i])];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < C::PL; ++q) {
-        const int e = tid + q * C::NT;
-        if (e < np) {
-          sidx[e] = a.src_col ? pr[q].y : pr[q].x;
-          drow[e] = (unsigned char)((a.src_col ? pr[q].x : pr[q].y) - row0);
-        }
-      }
-    }
-    __syncthreads();
-
-    float4 areg[C::D][C::AL], wreg[C::D][C::WL];
-    const int total = nk * nchunks;
-    // All global loads are unconditional (clamped addresses); out-of-range values are replaced
-    // by zeros when the registers are written to LDS. A guarded load would make hipcc branch
-    // around it and wait vmcnt(0) at the join, i.e. a synchronous "prefetch".
-    auto load_step = [&](int st, float4 *ar, float4 *wr) {
-      const int i = st / nchunks;
-      const int c0 = (st - i * nchunks) * CK;
-      const int off = kl_o[i];
-      const int m = kl_o[i + 1] - off;
-#pragma unroll
-      for (int q = 0; q < C::AL; ++q) {
-        const int e = tid + q * C::NT;
-        const int r = e >> 3, c4 = c0 + (e & 7) * 4;
-        const int rr = r < m ? r : m - 1;
-        const int cc = c4 <= a.cin - 4 ? c4 : a.cin - 4;
-        ar[q] = *reinterpret_cast<const float4 *>(a.src + (int64_t)sidx[off + rr] * a.cin + cc);
-      }
-      const float *Wk = a.W + (int64_t)kl_k[i] * a.cin * a.cout;
-#pragma unroll
-      for (int q = 0; q < C::WL; ++q) {
-        const int e = tid + q * C::NT;
-        int kr = c0 + e / (C::CT / 4), cq = n0 + (e % (C::CT / 4)) * 4;
-        kr = kr < a.cin ? kr : a.cin - 1;
-        cq = cq <= a.cout - 4 ? cq : a.cout - 4;
-        wr[q] = *reinterpret_cast<const float4 *>(Wk + (int64_t)kr * a.cout + cq);
-      }
-    };
-
-    f32x4 acc[C::MAXU];
-#pragma unroll
-    for (int u = 0; u < C::MAXU; ++u) acc[u] = (f32x4){0, 0, 0, 0};
-
-#pragma unroll
-    for (int d = 0; d < C::D; ++d)
-      if (d < total) load_step(d, areg[d], wreg[d]);
-
-    for (int s0 = 0; s0 < total; s0 += C::D) {
-#pragma unroll
-      for (int d = 0; d < C::D; ++d) {
-        const int st = s0 + d;
-        if (st < total) {  // block-uniform
-          const int i = st / nchunks;
-          const int c = st - i * nchunks;
-          const int off = kl_o[i];
-          const int m = kl_o[i + 1] - off;
-          float *ab = abuf + (st & 1) * T * AS;
-          float *wb = wbuf + (st & 1) * CK * C::WS;
-          // ---- stage registers (loaded D steps ago) -> LDS ----------------------------------------
-#pragma unroll
-          for (int q = 0; q < C::AL; ++q) {
-            const int e = tid + q * C::NT;
-            const int r = e >> 3, c4 = (e & 7) * 4;
-            if (r < m) {
-              const bool ok = c * CK + c4 < a.cin;  // channels beyond cin contribute zeros
-              float2 *dd = reinterpret_cast<float2 *>(ab + r * AS + c4);
-              dd[0] = ok ? make_float2(areg[d][q].x, areg[d][q].y) : make_float2(0.f, 0.f);
-              dd[1] = ok ? make_float2(areg[d][q].z, areg[d][q].w) : make_float2(0.f, 0.f);
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < C::WL; ++q) {
-            const int e = tid + q * C::NT;
-            const int kr = e / (C::CT / 4), cq = (e % (C::CT / 4)) * 4;
-            if (kr < CK) {
-              const bool ok = c * CK + kr < a.cin && n0 + cq < a.cout;
-              *reinterpret_cast<float4 *>(wb + kr * C::WS + cq) = ok ? wreg[d][q] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-          }
-          __syncthreads();
-          // ---- refill this stage with step st + D (in flight under D steps of MFMAs) -------------
-          if (st + C::D < total) load_step(st + C::D, areg[d], wreg[d]);
-          // ---- MFMA over the compact tile ------------------------------------------------------------
-          const int nunits = ((m + 15) >> 4) * NCTT;
-#pragma unroll
-          for (int u0 = 0; u0 < C::MAXU; u0 += C::UG) {
-            const int nv = (nunits - wid - u0 * C::NW + C::NW - 1) / C::NW;  // valid units in the group
-            if (nv >= 4 && C::UG >= 4) mfma_group<NCTT, C::WS, 4>(ab, wb, acc + u0, wid + u0 * C::NW, C::NW, lane);
-            else if (nv == 3 && C::UG >= 3) mfma_group<NCTT, C::WS, 3>(ab, wb, acc + u0, wid + u0 * C::NW, C::NW, lane);
-            else if (nv == 2 && C::UG >= 2) mfma_group<NCTT, C::WS, 2>(ab, wb, acc + u0, wid + u0 * C::NW, C::NW, lane);
-            else if (nv >= 1) mfma_group<NCTT, C::WS, 1>(ab, wb, acc + u0, wid + u0 * C::NW, C::NW, lane);
-          }
-          // ---- end of an offset: add the compact rows into the accumulator tile --------------------
-          if (c == nchunks - 1) {
-            const unsigned char *dr = drow + off;
-#pragma unroll
-            for (int u = 0; u < C::MAXU; ++u) {
-              const int unit = wid + u * C::NW;
-              if (unit < nunits) {
-                const int rb = unit / NCTT, ct = unit - rb * NCTT;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  const int cr = rb * 16 + g * 4 + j;
-                  if (cr < m) acc_l[(int)dr[cr] * C::ACS + ct * 16 + l15] += acc[u][j];
-                }
-              }
-              acc[u] = (f32x4){0, 0, 0, 0};
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  // ---- epilogue ------------------------------------------------------------------------------------
-  for (int e = tid; e < rows * (C::CT / 4); e += C::NT) {
-    const int r = e / (C::CT / 4), cq = (e % (C::CT / 4)) * 4;
-    if (n0 + cq < a.cout) {
-      float4 v = *reinterpret_cast<const float4 *>(acc_l + r * C::ACS + cq);
-      if (a.bias) {
-        const float4 b = *reinterpret_cast<const float4 *>(a.bias + n0 + cq);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-      }
-      *reinterpret_cast<float4 *>(a.dst + (row0 + r) * a.cout + n0 + cq) = v;
-    }
-  }
-}
-
-template <int NCTT, int T>
-int launch_conv2(const ConvArgs &a, hipStream_t st) {
-  using C = Conv2Cfg<NCTT, T>;
-  const int64_t nblocks = a.ntiles * a.ncoltiles;
-  if (nblocks <= 0) return PCS_OK;
-  if (nblocks > 0x7FFFFFFF) { set_error("pcs_conv: grid too large"); return PCS_EUNSUPPORTED; }
-  auto kern = conv_os2_kernel<NCTT, T>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(C::NT), C::lds_bytes, st, a);
-  return check_launch("pcs_conv_gather_gemm_f32(v2)");
 }
 
 // ================================================================================================
@@ -815,7 +556,7 @@ int launch_conv4(const ConvArgs &a, hipStream_t st) {
 // Everything else is v4: register-direct operands, interleaved column tiles, sched_group_barrier
 // software pipeline, cross-group prefetch, ticket-ordered commit. Requires cin % 32 == 0.
 // ================================================================================================
-template <int NCTT, int T, int NW_, int R_>
+template <int NCTT, int NW_, int R_>
 struct Conv5Cfg {
   static constexpr int NW = NW_;
   static constexpr int R = R_;
@@ -826,12 +567,13 @@ struct Conv5Cfg {
   static constexpr int N2 = (NCTT % 4) / 2;
   static constexpr int N1 = NCTT % 2;
   static constexpr int NWL = N4 + N2 + N1;  // W loads per contraction step
-  static constexpr size_t lds_bytes = (size_t)((T + 1) * ACS) * 4 + 4 * 32 * 4 + 32;
+  static constexpr size_t lds_bytes(int T) { return (size_t)((T + 1) * ACS) * 4 + 4 * 32 * 4 + 32; }
 };
 
-template <int NCTT, int T, int NW, int MINW, int R>
+template <int NCTT, int NW, int MINW, int R>
 __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
-  using C = Conv5Cfg<NCTT, T, NW, R>;
+  using C = Conv5Cfg<NCTT, NW, R>;
+  const int T = a.tile_rows;  // any multiple of 16: the host picks it per layer (pcs_conv_pick_tile_rows)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *acc_l = reinterpret_cast<float *>(smem);            // [T+1][ACS], row T = sink for padding rows
   int *kl_k = reinterpret_cast<int *>(acc_l + (T + 1) * C::ACS);  // [32] offset id
@@ -1077,20 +819,22 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
   }
 }
 
-template <int NCTT, int T, int NW, int MINW, int R>
+template <int NCTT, int NW, int MINW, int R>
 int launch_conv5(const ConvArgs &a, hipStream_t st) {
-  using C = Conv5Cfg<NCTT, T, NW, R>;
+  using C = Conv5Cfg<NCTT, NW, R>;
   const int64_t nblocks = a.ntiles * a.ncoltiles;
   if (nblocks <= 0) return PCS_OK;
   if (nblocks > 0x7FFFFFFF) { set_error("pcs_conv: grid too large"); return PCS_EUNSUPPORTED; }
-  auto kern = conv_os5_kernel<NCTT, T, NW, MINW, R>;
+  auto kern = conv_os5_kernel<NCTT, NW, MINW, R>;
+  const size_t lds = C::lds_bytes(a.tile_rows);
+  if (lds > kMaxDynLds) { set_error("pcs_conv: tile_rows too large for this column tile"); return PCS_EUNSUPPORTED; }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(C::NT), C::lds_bytes, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(C::NT), lds, st, a);
   return check_launch("pcs_conv_gather_gemm_f32(v5)");
 }
 
@@ -1455,12 +1199,64 @@ int wgrad_plan(const int32_t *koff_host, int K, int ca, int cb, int *pch_out) {
   return (int)ns;
 }
 
+int conv_nctt(int cout) {  // 16-column MFMA tiles per column tile: 1, 2, 3, 4, 6 or 8
+  int nctt = (cout + 15) / 16;
+  if (nctt > 8) nctt = 8;
+  if (nctt == 5) nctt = 6;
+  if (nctt == 7) nctt = 8;
+  return nctt;
+}
+// v5 serves 16-byte-granular shapes with a contraction of at least two 32-channel steps and an even column tile
+bool conv5_applies(int cin, int cout, int K) {
+  return cin % 32 == 0 && cin >= 64 && cout % 4 == 0 && K <= 32 && conv_nctt(cout) % 2 == 0;
+}
+int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    else cus = 256;
+  }
+  return cus;
+}
+
 }  // namespace
 
 extern "C" int32_t pcs_conv_tile_rows(int32_t cin, int32_t cout) {
   (void)cin;
   (void)cout;
   return 128;
+}
+
+// Output tile height for one layer. The workgroups of a launch run in waves of (CUs x 2) -- two 4-wave
+// workgroups fit a CU -- so a launch of 1.1 waves takes as long as one of 2.0: with few output rows (strides
+// 8/16) a height is chosen that fills the last wave (s16 256->256: 66.9 -> 82.7 TFLOP/s). Model: waves(T) x (pairs per tile + padding of half a
+// 16-row block per offset); 128 unless another height is predicted >= 5 % faster.
+extern "C" int32_t pcs_conv_pick_tile_rows(int64_t n_dst, int64_t n_pairs, int32_t K, int32_t cin, int32_t cout) {
+  static const int fixed = getenv("PCS_CONV_TILE") ? atoi(getenv("PCS_CONV_TILE")) : 0;
+  if (n_dst <= 0 || K <= 0 || !conv5_applies(cin, cout, K)) return 128;
+  if (fixed > 0) return fixed;
+  const int nctt = conv_nctt(cout);
+  const int64_t ncol = ceil_div(cout, 16 * nctt);
+  const int64_t slots = (int64_t)device_cus() * 2;
+  const double ppr = (double)n_pairs / (double)n_dst;
+  auto cost = [&](int T) {
+    const int64_t wgs = ceil_div(n_dst, T) * ncol;
+    return (double)ceil_div(wgs, slots) * (T * ppr + 8.0 * K);
+  };
+  // measured: beyond ~4 waves the choice is within +-3 % either way -> keep the default there
+  if (ceil_div(n_dst, 128) * ncol >= 4 * slots) return 128;
+  int best = 128;
+  double best_cost = cost(128) * 0.95;
+  for (int T = 80; T <= 160; T += 16) {
+    if (T == 128) continue;
+    const size_t lds = (size_t)((T + 1) * (16 * nctt + 4)) * 4 + 4 * 32 * 4 + 32;
+    if (2 * (lds + 1024) > 160 * 1024) continue;  // keep two workgroups per CU
+    const double c = cost(T);
+    if (c < best_cost) { best = T; best_cost = c; }
+  }
+  return best;
 }
 
 extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t cin,
@@ -1474,65 +1270,35 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
   }
   if (n_dst == 0) return PCS_OK;
   if (!W || !seg || !dst || (n_src > 0 && !src)) { set_error("pcs_conv_gather_gemm_f32: null pointer"); return PCS_EINVAL; }
-  if (tile_rows != 64 && tile_rows != 96 && tile_rows != 128 && tile_rows != 256 && tile_rows != 384 && tile_rows != 512) { set_error("pcs_conv_gather_gemm_f32: unsupported tile_rows"); return PCS_EINVAL; }
-  static const int use_v1_early = getenv("PCS_CONV_V1") ? atoi(getenv("PCS_CONV_V1")) : 0;
-  if ((tile_rows == 256 || tile_rows == 96) && (use_v1_early || K > 32 || cin % 4 || cout % 4)) { set_error("pcs_conv_gather_gemm_f32: tile_rows 96/256 need the v4 kernel"); return PCS_EUNSUPPORTED; }
+  if (tile_rows < 16 || tile_rows > 512 || tile_rows % 16) { set_error("pcs_conv_gather_gemm_f32: tile_rows must be a multiple of 16 in [16, 512]"); return PCS_EINVAL; }
   ConvArgs a;
   a.src = src; a.W = W; a.bias = bias; a.dst = dst; a.pairs = pairs; a.seg = seg;
-  a.n_dst = n_dst; a.ntiles = ceil_div(n_dst, tile_rows);
+  a.n_dst = n_dst; a.ntiles = ceil_div(n_dst, tile_rows); a.tile_rows = tile_rows;
   a.cin = cin; a.cout = cout; a.K = K; a.src_col = src_col;
   static const int xcd = getenv("PCS_CONV_XCD") ? atoi(getenv("PCS_CONV_XCD")) : 1;
   a.xcd_remap = xcd;
   const bool vec = (cin % 4 == 0) && (cout % 4 == 0) && (((uintptr_t)src | (uintptr_t)W | (uintptr_t)dst | (uintptr_t)bias) & 15) == 0;
   hipStream_t st = as_stream(stream);
   static const int use_v1 = getenv("PCS_CONV_V1") ? atoi(getenv("PCS_CONV_V1")) : 0;
-  static const int use_v3 = getenv("PCS_CONV_V3") ? atoi(getenv("PCS_CONV_V3")) : 0;
   // v5 (row-block groups of 2 sharing each W operand block) where the contraction is long enough to
-  // profit (cin >= 64, measured +3..6 %); PCS_CONV_V5=0 forces v4, 3/4 select larger groups (debug)
-  // experimental "tall-narrow" shape: 48/64-column tiles, 384/512-row tiles, groups of 4 row blocks
-  static const int tall = getenv("PCS_CONV_TALL") ? atoi(getenv("PCS_CONV_TALL")) : 0;
-  if (tall && vec && K <= 32 && cin % 32 == 0 && (tile_rows == 256 || tile_rows == 384 || tile_rows == 512)) {
-    const bool n3 = (cout % 48 == 0) && cout <= 96;
-    a.ncoltiles = (int)ceil_div(cout, n3 ? 48 : 64);
-    if (n3) {
-      if (tile_rows == 512) return launch_conv5<3, 512, 8, 2, 4>(a, st);
-      if (tile_rows == 384) return launch_conv5<3, 384, 8, 2, 4>(a, st);
-      return launch_conv5<3, 256, 8, 2, 4>(a, st);
-    }
-    if (tile_rows == 512) return launch_conv5<4, 512, 8, 2, 4>(a, st);
-    if (tile_rows == 384) return launch_conv5<4, 384, 8, 2, 4>(a, st);
-    return launch_conv5<4, 256, 8, 2, 4>(a, st);
-  }
+  // profit (cin >= 64, measured +3..6 %); PCS_CONV_V5=0 forces v4 (debug)
   static const int v5r = getenv("PCS_CONV_V5") ? atoi(getenv("PCS_CONV_V5")) : 2;
-  if (vec && !use_v1 && !use_v3 && K <= 32 && v5r > 0 && cin % 32 == 0 && cin >= 64 &&
-      (tile_rows == 128 || tile_rows == 256)) {
-    int nctt = (cout + 15) / 16;
-    if (nctt > 8) nctt = 8;
-    if (nctt == 5) nctt = 6;
-    if (nctt == 7) nctt = 8;
+  if (vec && !use_v1 && v5r > 0 && conv5_applies(cin, cout, K)) {
+    const int nctt = conv_nctt(cout);
     a.ncoltiles = (int)ceil_div(cout, 16 * nctt);
-#define PCS_CONV5_CASE(N)                                                                           \
-  case N:                                                                                           \
-    if (tile_rows == 256) return v5r >= 4 ? launch_conv5<N, 256, 8, 2, 4>(a, st) : launch_conv5<N, 256, 8, 2, 2>(a, st); \
-    return v5r >= 3 ? launch_conv5<N, 128, 4, 2, 3>(a, st) : launch_conv5<N, 128, 4, 2, 2>(a, st);
     switch (nctt) {
-      PCS_CONV5_CASE(2)
-      PCS_CONV5_CASE(4)
-      PCS_CONV5_CASE(6)
-      PCS_CONV5_CASE(8)
+      case 2: return launch_conv5<2, 4, 2, 2>(a, st);
+      case 4: return launch_conv5<4, 4, 2, 2>(a, st);
+      case 6: return launch_conv5<6, 4, 2, 2>(a, st);
+      case 8: return launch_conv5<8, 4, 2, 2>(a, st);
     }
-#undef PCS_CONV5_CASE
   }
-  if (vec && !use_v1 && !use_v3 && K <= 32) {
-    int nctt = (cout + 15) / 16;
-    if (nctt > 8) nctt = 8;
-    if (nctt == 5) nctt = 6;
-    if (nctt == 7) nctt = 8;
+  if (tile_rows != 64 && tile_rows != 128) { set_error("pcs_conv_gather_gemm_f32: this shape takes tile_rows 64 or 128"); return PCS_EUNSUPPORTED; }
+  if (vec && !use_v1 && K <= 32) {
+    const int nctt = conv_nctt(cout);
     a.ncoltiles = (int)ceil_div(cout, 16 * nctt);
 #define PCS_CONV4_CASE(N)                                                             \
   case N:                                                                             \
-    if (tile_rows == 256) return launch_conv4_cfg<N, 256, 8, 2>(a, st);               \
-    if (tile_rows == 96) return launch_conv4<N, 96>(a, st);                           \
     return tile_rows == 128 ? launch_conv4<N, 128>(a, st) : launch_conv4<N, 64>(a, st);
     switch (nctt) {
       PCS_CONV4_CASE(1)
@@ -1543,26 +1309,6 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
       PCS_CONV4_CASE(8)
     }
 #undef PCS_CONV4_CASE
-  }
-  if (vec && !use_v1 && K <= 27) {
-    // v2: column tile = 16*NCTT, NCTT in 1..8; wider outputs take several column tiles
-    int nctt = (cout + 15) / 16;
-    if (nctt > 8) nctt = 8;
-    if (nctt == 5) nctt = 6;
-    if (nctt == 7) nctt = 8;
-    a.ncoltiles = (int)ceil_div(cout, 16 * nctt);
-#define PCS_CONV2_CASE(N)                                                             \
-  case N:                                                                             \
-    return tile_rows == 128 ? launch_conv2<N, 128>(a, st) : launch_conv2<N, 64>(a, st);
-    switch (nctt) {
-      PCS_CONV2_CASE(1)
-      PCS_CONV2_CASE(2)
-      PCS_CONV2_CASE(3)
-      PCS_CONV2_CASE(4)
-      PCS_CONV2_CASE(6)
-      PCS_CONV2_CASE(8)
-    }
-#undef PCS_CONV2_CASE
   }
   // column tile: 32*CG with CG in 1..4; wider outputs are covered by several column tiles
   int cg = (cout + 31) / 32;

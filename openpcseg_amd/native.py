@@ -39,6 +39,7 @@ SIGNATURES = {
     "pcs_rulebook_fill": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P]),
     "pcs_rulebook_tile_segments": (c_int32, [_P, _P, c_int32, c_int64, c_int32, c_int32, _P, _P]),
     "pcs_conv_tile_rows": (c_int32, [c_int32, c_int32]),
+    "pcs_conv_pick_tile_rows": (c_int32, [c_int64, c_int64, c_int32, c_int32, c_int32]),
     "pcs_conv_gather_gemm_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32,
                                            _P, c_int32, c_int64, _P, _P, _P]),
     "pcs_conv_wgrad_ws_bytes": (c_size_t, [_P, c_int32, c_int32, c_int32]),
@@ -313,8 +314,11 @@ class HipBackend:
                                           _stream()), "pcs_rulebook_fill")
         return KernelMap(pairs, koff, koff_host, nbsizes, ref_coords.shape[0], nq)
 
-    def tile_rows(self, cin, cout):
-        return self.lib.pcs_conv_tile_rows(cin, cout)
+    def tile_rows(self, cin, cout, kmap=None):
+        """Output tile height of one conv launch: the library default, or with a kernel map the per-layer pick."""
+        if kmap is None:
+            return self.lib.pcs_conv_tile_rows(cin, cout)
+        return self.lib.pcs_conv_pick_tile_rows(kmap.n_dst, kmap.num_pairs, kmap.K, cin, cout)
 
     def _segments(self, kmap, tile_rows):
         seg = kmap._seg.get(tile_rows)
@@ -339,7 +343,7 @@ class HipBackend:
             raise ValueError("kernel volume %d does not match the kernel map (%d)" % (k, kmap.K))
         if bias is not None:
             bias = _dev(bias, "bias", torch.float32)
-        t = tile_rows or self.tile_rows(cin, cout)
+        t = tile_rows or self.tile_rows(cin, cout, kmap)
         seg = self._segments(kmap, t)
         dst = torch.empty((kmap.n_dst, cout), dtype=torch.float32, device=src.device)
         _check(self.lib.pcs_conv_gather_gemm_f32(_ptr(src), src.shape[0], cin, _ptr(weight), k, cout,

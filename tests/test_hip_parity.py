@@ -198,6 +198,34 @@ def test_conv_forward_and_dgrad_kernel(hip, golden, cin, cout, tile):
     close(hip.conv_wgrad(t(x), t(gy), entry.fwd, 0), ogw, 2e-5)
 
 
+@pytest.mark.parametrize("cin,cout", [(96, 96), (128, 256), (64, 64)])
+@pytest.mark.parametrize("tile", [16, 80, 112, 144, 160])
+def test_conv_free_tile_heights(hip, golden, cin, cout, tile):
+    """cin >= 64 kernel: any multiple of 16 is a legal tile height (the per-layer pick uses 80..160); the ordered
+    commit makes the result independent of it bit for bit."""
+    entry, (nbmaps, nbsizes), n_in, n_out = _scene_maps(hip, golden, "k3s1")
+    rng = np.random.default_rng(cin + cout)
+    x = rng.normal(size=(n_in, cin)).astype(np.float32)
+    w = (rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32)
+    y = hip.conv_gather_gemm(t(x), t(w), entry.fwd, tile_rows=tile)
+    close(y, orc.conv_fwd(x, w, nbmaps, nbsizes, (n_in, n_out)), 2e-5)
+    assert torch.equal(y, hip.conv_gather_gemm(t(x), t(w), entry.fwd, tile_rows=128))
+
+
+def test_conv_tile_pick_and_errors(hip, golden):
+    lib = hip.lib
+    # many waves of workgroups: default height; 36k rows x 256 columns = 1.1 waves at 128 -> a taller tile
+    assert lib.pcs_conv_pick_tile_rows(1158864, 5112372, 27, 96, 96) == 128
+    assert lib.pcs_conv_pick_tile_rows(36068, 331722, 27, 256, 256) == 144
+    assert lib.pcs_conv_pick_tile_rows(36068, 331722, 27, 32, 32) == 128  # not the cin >= 64 kernel
+    entry, _, n_in, _ = _scene_maps(hip, golden, "k3s1")
+    x = torch.zeros((n_in, 32), device="cuda")
+    w = torch.zeros((27, 32, 32), device="cuda")
+    for bad in (8, 24, 1024, 144):  # 144 is legal only for the cin >= 64 kernel
+        with pytest.raises(RuntimeError):
+            hip.conv_gather_gemm(x, w, entry.fwd, tile_rows=bad)
+
+
 @pytest.mark.parametrize("cin,cout", [(32, 32), (64, 128), (256, 128), (96, 96)])
 def test_conv_strided_and_transposed(hip, golden, cin, cout):
     entry, (nbmaps, nbsizes), n_in, n_out = _scene_maps(hip, golden, "k2s2")
