@@ -264,6 +264,28 @@ int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const 
                          const double *sums2, double count, const float *w, int64_t n, int32_t c,
                          int32_t relu, float *dx, float *dres, void *stream);
 
+/* ---- device-side sparse_quantize ---------------------------------------------------------------
+ * Replaces the dataloader-side NumPy voxel dedup TS:torchsparse/utils/quantize.py:9-46
+ * (ravel_hash :9-21, sparse_quantize :24-46; called from R:pcseg/data/dataset/semantickitti/
+ * semantickitti_voxel.py:112-120) for scans that are already resident in HBM. Contract: voxel =
+ * floor(point / voxel_size) evaluated in double like NumPy does, one representative row per voxel =
+ * its FIRST occurrence, voxels ordered by ascending ravel hash (row-major index inside the bounding box).
+ *   floor: points (n, row_stride >= 3) float32 (is_float = 1) or int32 (0); voxel_size3 = 3 HOST doubles;
+ *          coords (n,3) int32 out; bbox = 6 DEVICE int32 {min xyz, max xyz}, preset by the caller to
+ *          {INT32_MAX x3, INT32_MIN x3}.
+ *   keys:  keys[i] = ((x - xmin) * ey + (y - ymin)) * ez + (z - zmin), int64.
+ *   the caller sorts (keys, row) STABLY, then  flags: 1 at the head of every run of equal keys;
+ *   the caller scans the flags inclusively (rank), then
+ *   emit:  vox (m,3) int32, index (m) int64 = representative row (may be NULL), inverse (n) int64 = voxel of
+ *          every row (may be NULL); m = rank[n-1].
+ */
+int pcs_quantize_floor(const void *points, int32_t is_float, int64_t n, int32_t row_stride,
+                       const double *voxel_size3, int32_t *coords, int32_t *bbox, void *stream);
+int pcs_quantize_keys(const int32_t *coords, int64_t n, const int32_t *bbox, int64_t *keys, void *stream);
+int pcs_quantize_flags(const int64_t *sorted_keys, int64_t n, int32_t *flags, void *stream);
+int pcs_quantize_emit(const int32_t *flags, const int64_t *rank, const int64_t *perm, const int32_t *coords,
+                      int64_t n, int32_t *vox, int64_t *index, int64_t *inverse, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

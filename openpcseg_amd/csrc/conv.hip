@@ -1286,12 +1286,18 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
   if (vec && !use_v1 && v5r > 0 && conv5_applies(cin, cout, K)) {
     const int nctt = conv_nctt(cout);
     a.ncoltiles = (int)ceil_div(cout, 16 * nctt);
+#define PCS_CONV5_CASE(N)                                                                           \
+  case N:                                                                                           \
+    if (v5r == 3) return launch_conv5<N, 4, 2, 3>(a, st);                                           \
+    if (v5r == 4) return launch_conv5<N, 4, 2, 4>(a, st);                                           \
+    return launch_conv5<N, 4, 2, 2>(a, st);
     switch (nctt) {
-      case 2: return launch_conv5<2, 4, 2, 2>(a, st);
-      case 4: return launch_conv5<4, 4, 2, 2>(a, st);
-      case 6: return launch_conv5<6, 4, 2, 2>(a, st);
-      case 8: return launch_conv5<8, 4, 2, 2>(a, st);
+      PCS_CONV5_CASE(2)
+      PCS_CONV5_CASE(4)
+      PCS_CONV5_CASE(6)
+      PCS_CONV5_CASE(8)
     }
+#undef PCS_CONV5_CASE
   }
   if (tile_rows != 64 && tile_rows != 128) { set_error("pcs_conv_gather_gemm_f32: this shape takes tile_rows 64 or 128"); return PCS_EUNSUPPORTED; }
   if (vec && !use_v1 && K <= 32) {

@@ -124,25 +124,32 @@ class KmapEntry(list):
       .rev  pairs (out_row, in_row), in ascending within an offset   (built on first use;
             needed by dgrad and by transposed convolutions)"""
 
-    def __init__(self, fwd, in_coords, out_coords, offsets):
+    def __init__(self, fwd, in_coords, out_coords, offsets, symmetric=False):
         super().__init__([fwd.pairs, fwd.nbsizes, (in_coords.shape[0], out_coords.shape[0])])
         self.fwd = fwd
         self._rev = None
         self._ctx = (in_coords, out_coords, offsets)
+        # submanifold map (same coordinate tensor on both sides) with point-symmetric offsets: the input-sorted
+        # map is a slice permutation of the forward map, no second probe pass
+        self._mirror = symmetric and in_coords is out_coords
 
     @property
     def rev(self):
         if self._rev is None:
             in_coords, out_coords, offsets = self._ctx
-            self._rev = _be().build_kmap(out_coords, in_coords, -offsets)
+            if self._mirror:
+                self._rev = self.fwd.mirror()
+            else:
+                self._rev = _be().build_kmap(out_coords, in_coords, -offsets)
         return self._rev
 
 
 def build_kernel_map(in_coords, out_coords, kernel_size, in_stride, dilation):
-    offsets = get_kernel_offsets(kernel_size, stride=in_stride, dilation=dilation,
-                                 device=in_coords.device)
+    offsets = get_kernel_offsets(kernel_size, stride=in_stride, dilation=dilation, device="cpu")
+    symmetric = bool(torch.equal(offsets.flip(0), -offsets))  # odd kernel sizes
+    offsets = offsets.to(in_coords.device)
     fwd = _be().build_kmap(in_coords, out_coords, offsets)
-    return KmapEntry(fwd, in_coords, out_coords, offsets)
+    return KmapEntry(fwd, in_coords, out_coords, offsets, symmetric)
 
 
 class _SparseConv(Function):

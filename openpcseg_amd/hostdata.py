@@ -1,7 +1,6 @@
-"""Host-side (NumPy, dataloader-worker) voxel dedup and batch collation.
-
-These run on the CPU in the reference too; a device version is a
-"next" row. Same signatures and ordering contract as
+"""Voxel dedup and batch collation: NumPy in the dataloader workers like the reference (SURVEY.md section 8
+a15), and -- for scans already resident in HBM (a device tensor in) -- on the MI355X through the pcs_quantize_*
+kernels (section 8 f1). Same signatures and ordering contract as
   sparse_quantize / ravel_hash   TS:torchsparse/utils/quantize.py:9-46
   sparse_collate(_fn)            TS:torchsparse/utils/collate.py:11-59
 """
@@ -34,6 +33,11 @@ def sparse_quantize(coords, voxel_size=1, *, return_index=False, return_inverse=
     if isinstance(voxel_size, (float, int)):
         voxel_size = tuple(repeat(voxel_size, 3))
     assert isinstance(voxel_size, tuple) and len(voxel_size) == 3
+    if isinstance(coords, torch.Tensor):  # device tensor in -> device tensors out (no CPU path for tensors)
+        from . import native
+        vox, index, inverse = native.backend().quantize(coords, voxel_size, return_index, return_inverse)
+        outputs = [vox] + ([index] if return_index else []) + ([inverse] if return_inverse else [])
+        return outputs[0] if len(outputs) == 1 else outputs
     coords = np.floor(coords / np.array(voxel_size)).astype(np.int32)
     _, indices, inverse = np.unique(ravel_hash(coords), return_index=True, return_inverse=True)
     outputs = [coords[indices]]

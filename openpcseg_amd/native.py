@@ -56,6 +56,10 @@ SIGNATURES = {
     "pcs_bn_apply_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P]),
     "pcs_bn_bwd_stats_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
     "pcs_bn_bwd_apply_f32": (c_int32, [_P, _P, _P, _P, _P, c_double, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
+    "pcs_quantize_floor": (c_int32, [_P, c_int32, c_int64, c_int32, _P, _P, _P, _P]),
+    "pcs_quantize_keys": (c_int32, [_P, c_int64, _P, _P, _P]),
+    "pcs_quantize_flags": (c_int32, [_P, c_int64, _P, _P]),
+    "pcs_quantize_emit": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
 }
 
 _lib = None
@@ -135,6 +139,18 @@ class KernelMap:
     @property
     def num_pairs(self):
         return self.koff_host[-1]
+
+    def mirror(self):
+        """The input-sorted map of a submanifold convolution with point-symmetric offsets (off[K-1-k] == -off[k]),
+        without probing: its offset-k slice IS the offset-(K-1-k) slice of this map (pairs (r, q) with
+        coord[r] = coord[q] - off[k], q ascending, r and q rows of the same coordinate set)."""
+        k, ko = self.K, self.koff_host
+        pairs = torch.cat([self.pairs[ko[k - 1 - j]:ko[k - j]] for j in range(k)], dim=0)
+        koff_host = [0]
+        for j in range(k):
+            koff_host.append(koff_host[-1] + ko[k - j] - ko[k - 1 - j])
+        koff = torch.tensor(koff_host, dtype=torch.int32).to(self.pairs.device, non_blocking=True)
+        return KernelMap(pairs, koff, koff_host, self.nbsizes.flip(0), self.n_dst, self.n_src)
 
 
 class HipBackend:
@@ -463,6 +479,37 @@ class HipBackend:
                                              _ptr(dx), _ptr(dres) if want_res else None, _stream()),
                "pcs_bn_bwd_apply_f32")
         return dx, dres
+
+    # -- device-side sparse_quantize --------------------------------------------------------------------
+    def quantize(self, points, voxel_size3, want_index, want_inverse):
+        """points (n, >=3) float32 / int32 on the device -> (vox (m,3) int32, index (m) int64 | None,
+        inverse (n) int64 | None); reference order and representative (TS:torchsparse/utils/quantize.py:24-46)."""
+        points = _dev(points, "coords")
+        if points.dtype not in (torch.float32, torch.int32):
+            points = points.float() if points.is_floating_point() else points.int()
+        points = points.contiguous()
+        n, stride = points.shape
+        dev = points.device
+        vox_size = (c_double * 3)(*[float(v) for v in voxel_size3])
+        coords = torch.empty((n, 3), dtype=torch.int32, device=dev)
+        i32 = torch.iinfo(torch.int32)
+        bbox = torch.tensor([i32.max] * 3 + [i32.min] * 3, dtype=torch.int32).to(dev, non_blocking=True)
+        _check(self.lib.pcs_quantize_floor(_ptr(points), int(points.is_floating_point()), n, stride, vox_size,
+                                           _ptr(coords), _ptr(bbox), _stream()), "pcs_quantize_floor")
+        keys = torch.empty(n, dtype=torch.int64, device=dev)
+        _check(self.lib.pcs_quantize_keys(_ptr(coords), n, _ptr(bbox), _ptr(keys), _stream()), "pcs_quantize_keys")
+        skeys, perm = torch.sort(keys, stable=True)  # rocPRIM radix sort: equal keys keep row order
+        flags = torch.empty(n, dtype=torch.int32, device=dev)
+        _check(self.lib.pcs_quantize_flags(_ptr(skeys), n, _ptr(flags), _stream()), "pcs_quantize_flags")
+        rank = torch.cumsum(flags, dim=0, dtype=torch.int64)
+        m = int(rank[-1].item()) if n else 0  # the one host sync: the number of voxels sizes the outputs
+        vox = torch.empty((m, 3), dtype=torch.int32, device=dev)
+        index = torch.empty(m, dtype=torch.int64, device=dev) if want_index else None
+        inverse = torch.empty(n, dtype=torch.int64, device=dev) if want_inverse else None
+        _check(self.lib.pcs_quantize_emit(_ptr(flags), _ptr(rank), _ptr(perm), _ptr(coords), n, _ptr(vox),
+                                          _ptr(index) if want_index else None,
+                                          _ptr(inverse) if want_inverse else None, _stream()), "pcs_quantize_emit")
+        return vox, index, inverse
 
 
 _BACKEND = None

@@ -32,6 +32,11 @@ class CpuKernelMap:
     def num_pairs(self):
         return self.koff_host[-1]
 
+    def mirror(self):  # same contract as native.KernelMap.mirror
+        k, ko = self.K, self.koff_host
+        pairs = np.concatenate([self.pairs.numpy()[ko[k - 1 - j]:ko[k - j]] for j in range(k)], axis=0).reshape(-1, 2)
+        return CpuKernelMap(pairs, self.nbsizes.numpy()[::-1].copy(), self.n_dst, self.n_src)
+
 
 class OracleBackend:
     """CPU restatement (oracle/pcs_oracle.c + oracle/oracle.py)."""
@@ -64,6 +69,11 @@ class OracleBackend:
 
     def ti_weights(self, coords, idx_query, scale):
         return torch.from_numpy(orc.calc_ti_weights(_np(coords), _np(idx_query), scale))
+
+    def quantize(self, points, voxel_size3, want_index, want_inverse):
+        vox, index, inverse = orc.sparse_quantize(_np(points), voxel_size3)
+        return (torch.from_numpy(vox), torch.from_numpy(index) if want_index else None,
+                torch.from_numpy(inverse) if want_inverse else None)
 
     def downsample(self, coords, sample_stride, offsets=None, coords_min=None):
         """TS:torchsparse/nn/functional/downsample.py:25-51 given the already-derived

@@ -282,3 +282,23 @@ def denselize_bwd(gout, count_map, pxpy):
         if 0 <= bb < b and 0 <= px < w and 0 <= py < h and count_map[bb, py, px] > 0:
             g[i] = gout[bb, :, py, px] / np.float32(count_map[bb, py, px])
     return g
+
+
+def sparse_quantize(points, voxel_size=(1, 1, 1)):
+    """TS:torchsparse/utils/quantize.py:9-46 restated without np.unique: voxel = floor(point / voxel_size) in float64
+    (NumPy promotes the float32 points against the float64 voxel-size array, :37), key = row-major index inside
+    the bounding box (ravel_hash :9-21), one representative per key = its first row, output ordered by key.
+    Returns (vox (m,3) int32, index (m) int64, inverse (n) int64)."""
+    pts = np.asarray(points)[:, :3].astype(np.float64)
+    c = np.floor(pts / np.asarray(voxel_size, dtype=np.float64)[None, :]).astype(np.int32)
+    rel = (c - c.min(axis=0)).astype(np.int64)
+    ext = rel.max(axis=0) + 1
+    key = (rel[:, 0] * ext[1] + rel[:, 1]) * ext[2] + rel[:, 2]
+    order = np.lexsort((np.arange(key.size), key))  # by key, ties by row
+    sk = key[order]
+    head = np.ones(sk.size, dtype=bool)
+    head[1:] = sk[1:] != sk[:-1]
+    index = order[head].astype(np.int64)
+    inverse = np.empty(key.size, dtype=np.int64)
+    inverse[order] = np.cumsum(head) - 1
+    return c[index], index, inverse

@@ -10,7 +10,7 @@ Needs /root/reference (so it cannot run on the GPU box; the .npz files are commi
 Known reference CPU-twin defects are worked around WITHOUT changing semantics:
   - kernel_hash_cpu uses row 0's batch index for every row (hash_cpu.cpp:29): called per batch;
   - devoxelize_backward_cpu is wrong (devoxelize_cpu.cpp:51-53): not used for goldens.
-Usage: python tests/golden/make_golden.py
+Usage: python tests/golden/make_golden.py [models | quantize]
 """
 import os
 import sys
@@ -394,8 +394,28 @@ def main_models():
     print("wrote models_e2e_golden.npz:", {k: v.shape for k, v in g.items() if "logits" in k})
 
 
+def main_quantize():
+    """sparse_quantize of the reference on float points / fractional voxel sizes / negative coordinates with
+    return_index + return_inverse (the device path's contract)."""
+    import_reference_torchsparse()
+    from torchsparse.utils.quantize import sparse_quantize
+    from openpcseg_amd.workloads.synthetic import make_scan
+    g = {}
+    cases = {"scan": (make_scan(seed=3, n_points=6000)[:, :3].astype(np.float32), 0.35),
+             "aniso": (make_scan(seed=4, n_points=3000)[:, :3].astype(np.float32), (0.1, 0.2, 0.4)),
+             "ints": (np.random.default_rng(11).integers(-40, 40, size=(5000, 3)).astype(np.int32), 3)}
+    for name, (pts, vs) in cases.items():
+        vox, idx, inv = sparse_quantize(pts, vs, return_index=True, return_inverse=True)
+        g[name + "_in"], g[name + "_vs"] = pts, np.asarray(vs, dtype=np.float64)
+        g[name + "_vox"], g[name + "_idx"], g[name + "_inv"] = vox, idx.astype(np.int64), inv.astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, "quantize_golden.npz"), **g)
+    print("wrote quantize_golden.npz:", {k: v.shape for k, v in g.items() if k.endswith("_vox")})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "models":
         main_models()
+    elif len(sys.argv) > 1 and sys.argv[1] == "quantize":
+        main_quantize()
     else:
         main()

@@ -212,6 +212,17 @@ def test_conv_free_tile_heights(hip, golden, cin, cout, tile):
     assert torch.equal(y, hip.conv_gather_gemm(t(x), t(w), entry.fwd, tile_rows=128))
 
 
+def test_submanifold_reverse_map_mirror_equals_probe(hip, golden):
+    from openpcseg_amd import functional as F
+    c = t(golden["scene_coords"])
+    entry = F.build_kernel_map(c, c, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    assert entry._mirror
+    built = hip.build_kmap(c, c, -entry._ctx[2])
+    assert torch.equal(entry.rev.pairs, built.pairs) and torch.equal(entry.rev.koff, built.koff)
+    assert entry.rev.koff_host == built.koff_host and torch.equal(entry.rev.nbsizes, built.nbsizes)
+    assert (entry.rev.n_src, entry.rev.n_dst) == (built.n_src, built.n_dst)
+
+
 def test_conv_tile_pick_and_errors(hip, golden):
     lib = hip.lib
     # many waves of workgroups: default height; 36k rows x 256 columns = 1.1 waves at 128 -> a taller tile
@@ -378,3 +389,46 @@ def test_fused_batchnorm_matches_torch(hip, c, relu, with_res):
     ye = bn(SparseTensor(x.detach(), coords), relu=relu).F
     te = torch.relu(ref(x.detach())) if relu else ref(x.detach())
     assert (ye - te).abs().max() <= 2e-5 * te.abs().max()
+
+
+# ---- device-side sparse_quantize ---------------------------------------------------------
+@pytest.mark.parametrize("case", ["scan", "aniso", "ints"])
+def test_device_sparse_quantize_matches_reference_golden(hip, case):
+    import os
+    from openpcseg_amd import hostdata
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "quantize_golden.npz"))
+    vs = g[case + "_vs"]
+    vs = tuple(float(v) for v in vs) if vs.ndim else float(vs)
+    vox, idx, inv = hostdata.sparse_quantize(t(g[case + "_in"]), vs, return_index=True, return_inverse=True)
+    assert vox.is_cuda and vox.dtype == torch.int32 and idx.dtype == torch.int64
+    assert np.array_equal(vox.cpu().numpy(), g[case + "_vox"])
+    assert np.array_equal(idx.cpu().numpy(), g[case + "_idx"]) and np.array_equal(inv.cpu().numpy(), g[case + "_inv"])
+    assert torch.equal(hostdata.sparse_quantize(t(g[case + "_in"]), vs), vox)
+
+
+def test_device_sparse_quantize_full_scan_properties(hip):
+    """120k-ray scan at 0.05 m like the dataset transform (semantickitti_voxel.py:112-120): == the oracle, and the
+    size-independent properties: keys strictly ascending, index = first row of its voxel, inverse consistent."""
+    from openpcseg_amd import hostdata
+    from openpcseg_amd.workloads.synthetic import make_scan
+    pts = make_scan(seed=1)[:, :3].astype(np.float32)
+    pc = np.round(pts / 0.05).astype(np.int32)
+    pc -= pc.min(0, keepdims=True)
+    vox, idx, inv = hostdata.sparse_quantize(t(pc), return_index=True, return_inverse=True)
+    ovox, oidx, oinv = orc.sparse_quantize(pc)
+    assert np.array_equal(vox.cpu().numpy(), ovox) and np.array_equal(idx.cpu().numpy(), oidx)
+    assert np.array_equal(inv.cpu().numpy(), oinv)
+    v = vox.long()
+    ext = v.max(0).values + 1
+    key = (v[:, 0] * ext[1] + v[:, 1]) * ext[2] + v[:, 2]
+    assert bool((key[1:] > key[:-1]).all())
+    pcd = t(pc)
+    assert torch.equal(pcd[idx], vox) and torch.equal(vox[inv], pcd)
+    first = torch.full((vox.shape[0],), pc.shape[0], dtype=torch.int64, device="cuda")
+    first.scatter_reduce_(0, inv, torch.arange(pc.shape[0], device="cuda"), reduce="amin")
+    assert torch.equal(first, idx)
+    # float points + metric voxel size, empty input
+    fv = hostdata.sparse_quantize(t(pts), 0.05)
+    assert np.array_equal(fv.cpu().numpy(), orc.sparse_quantize(pts, (0.05,) * 3)[0])
+    e = hostdata.sparse_quantize(torch.zeros((0, 3), device="cuda"), 0.05, return_index=True)
+    assert e[0].shape == (0, 3) and e[1].shape == (0,)

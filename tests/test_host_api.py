@@ -102,6 +102,17 @@ def test_sparse_quantize_matches_reference(golden):
     assert out["lidar"].C.tolist() == [[0, 0, 0, 0], [1, 1, 1, 0], [2, 2, 2, 1]] and out["n"] == [1, 2]
 
 
+def test_sparse_quantize_tensor_input_goes_to_the_backend(oracle_backend):
+    """torch tensor in -> tensors out through backend().quantize (HIP in the product; the oracle here)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "quantize_golden.npz"))
+    vox, idx, inv = hostdata.sparse_quantize(torch.from_numpy(g["scan_in"]), float(g["scan_vs"]), return_index=True,
+                                             return_inverse=True)
+    assert torch.equal(vox, torch.from_numpy(g["scan_vox"])) and torch.equal(idx, torch.from_numpy(g["scan_idx"]))
+    assert torch.equal(inv, torch.from_numpy(g["scan_inv"]))
+    only = hostdata.sparse_quantize(torch.from_numpy(g["ints_in"]), 3)
+    assert torch.equal(only, torch.from_numpy(g["ints_vox"]))
+
+
 # ---- dispatcher + autograd on the oracle backend vs the reference's outputs ---------------------------
 @pytest.mark.parametrize("tag,name,ks,stride,transposed", [
     ("conv_k3s1_N", "k3s1", 3, 1, False), ("conv_k2s2_N", "k2s2", 2, 2, False), ("conv_k2s2_T", "k2s2", 2, 2, True)])
@@ -132,6 +143,23 @@ def test_conv3d_dispatch_matches_reference(golden, oracle_backend, tag, name, ks
     assert np.allclose(x.grad.numpy(), golden[tag + "_gx"], rtol=1e-4, atol=1e-5)
     assert np.allclose(w.grad.numpy(), golden[tag + "_gw"], rtol=1e-4, atol=1e-4)
     assert out.kmaps is inp.kmaps and out.cmaps is inp.cmaps
+
+
+@pytest.mark.parametrize("ks", [3, (1, 3, 3), (3, 1, 3)])
+def test_submanifold_reverse_map_is_a_mirror(golden, oracle_backend, ks):
+    """Submanifold conv + point-symmetric offsets: the input-sorted map comes from the forward map's slices
+    (offset k <- offset K-1-k), and equals the map a second probe pass builds."""
+    from openpcseg_amd import functional as F
+    from openpcseg_amd.sparse import make_ntuple
+    c = torch.from_numpy(golden["scene_coords"])
+    entry = F.build_kernel_map(c, c, make_ntuple(ks, ndim=3), (1, 1, 1), (1, 1, 1))
+    assert entry._mirror
+    built = oracle_backend.build_kmap(c, c, -entry._ctx[2])
+    assert torch.equal(entry.rev.pairs, built.pairs) and torch.equal(entry.rev.nbsizes, built.nbsizes)
+    assert entry.rev.koff_host == built.koff_host
+    # a distinct coordinate tensor or an even kernel does not qualify
+    assert not F.build_kernel_map(c, c.clone(), (3, 3, 3), (1, 1, 1), (1, 1, 1))._mirror
+    assert not F.build_kernel_map(c, c, (2, 2, 2), (1, 1, 1), (1, 1, 1))._mirror
 
 
 def test_conv3d_channel_mismatch_raises(golden, oracle_backend):

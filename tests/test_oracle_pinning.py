@@ -7,6 +7,7 @@ Two anchors:
 Integer ops: bit-exact. Floating point: 1e-5 relative (fp32 summation order differs between
 a BLAS GEMM and the scalar restatement).
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -136,3 +137,12 @@ def test_live_reference_backend(ref_backend):
     ogx, ogw = orc.conv_bwd(x, gy, w, nbmaps, nbsizes)
     close(ogx, gin.numpy())
     close(ogw, gw.numpy())
+
+
+@pytest.mark.parametrize("case", ["scan", "aniso", "ints"])
+def test_sparse_quantize_restatement_matches_reference(case):
+    """oracle.sparse_quantize (no np.unique; float64 floor-divide) == the reference's sparse_quantize with
+    return_index / return_inverse on float points, anisotropic voxels and negative integer coordinates."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "quantize_golden.npz"))
+    vox, idx, inv = orc.sparse_quantize(g[case + "_in"], g[case + "_vs"] if g[case + "_vs"].ndim else (float(g[case + "_vs"]),) * 3)
+    assert np.array_equal(vox, g[case + "_vox"]) and np.array_equal(idx, g[case + "_idx"]) and np.array_equal(inv, g[case + "_inv"])
