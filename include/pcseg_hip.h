@@ -87,6 +87,10 @@ int pcs_count(const int32_t *idx, int64_t n, int32_t *out, int64_t s, void *stre
  */
 int pcs_voxelize_fwd_f32(const float *feats, const int32_t *idx, const int32_t *counts,
                          int64_t n, int64_t m, int32_t c, float *out, void *stream);
+/* contention-free forward: order (n_in_voxels) int64 = point rows sorted by voxel (points with idx < 0 first, skipped
+ * by rowptr[0]), rowptr (m+1) int64; every out row written once, deterministic summation order */
+int pcs_voxelize_fwd_csr_f32(const float *feats, const int64_t *order, const int64_t *rowptr,
+                             const int32_t *counts, int64_t m, int32_t c, float *out, void *stream);
 int pcs_voxelize_bwd_f32(const float *gout, const int32_t *idx, const int32_t *counts,
                          int64_t n, int32_t c, float *gin, void *stream);
 
@@ -217,9 +221,10 @@ int pcs_conv_wgrad_f32(const float *fa, int32_t ca, const float *fb, int32_t cb,
  * (scatter_mean of the same front-end is pcs_voxelize_fwd_f32 with the voxel counts.)
  */
 int pcs_scatter_max_fwd_f32(const float *src, const int64_t *order, const int64_t *rowptr, int64_t m,
-                            int32_t c, float *out, int64_t *arg, void *stream);
-/* gsrc (n,c) is zeroed inside, then gsrc[arg[v,j], j] = gout[v,j]. */
-int pcs_scatter_max_bwd_f32(const float *gout, const int64_t *arg, int64_t m, int64_t n, int32_t c,
+                            int32_t c, float *out, int32_t *arg, void *stream);
+/* gsrc (n,c) is zeroed inside, then gsrc[arg[v,j], j] = gout[v,j]. arg is int32 (point rows < 2^31): as int64 it
+ * would be half of the forward kernel's HBM traffic; the Python layer widens it only if the caller reads it. */
+int pcs_scatter_max_bwd_f32(const float *gout, const int32_t *arg, int64_t m, int64_t n, int32_t c,
                             float *gsrc, void *stream);
 
 /* K13  map_count_forward   RL:range_utils/src/map_count_gpu.cu:5-14 (RL = R:pcseg/model/segmentor/
@@ -233,6 +238,15 @@ int pcs_map_count(const int32_t *pxpy, int64_t n, int32_t B, int32_t H, int32_t 
                   void *stream);
 int pcs_denselize_fwd_f32(const float *feat, const int32_t *count_map, const int32_t *pxpy, int64_t n,
                           int32_t B, int32_t C, int32_t H, int32_t W, float *out, void *stream);
+/* contention-free forms (C % 4 == 0): order int64 = point rows sorted by pixel ((b*H + py)*W + px; out-of-range
+ * points first), rowptr (B*H*W + 1) int64. forward: every out element written once (no memset), NCHW stores in full
+ * lines, deterministic. backward: gout read in full lines, one 16-byte-vector row store per point (gfeat zeroed inside). */
+int pcs_denselize_fwd_csr_f32(const float *feat, const int64_t *order, const int64_t *rowptr,
+                              const int32_t *count_map, int32_t B, int32_t C, int32_t H, int32_t W,
+                              float *out, void *stream);
+int pcs_denselize_bwd_csr_f32(const float *gout, const int64_t *order, const int64_t *rowptr,
+                              const int32_t *count_map, int64_t n, int32_t B, int32_t C, int32_t H, int32_t W,
+                              float *gfeat, void *stream);
 int pcs_denselize_bwd_f32(const float *gout, const int32_t *count_map, const int32_t *pxpy, int64_t n,
                           int32_t B, int32_t C, int32_t H, int32_t W, float *gfeat, void *stream);
 

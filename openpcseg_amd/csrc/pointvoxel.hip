@@ -73,6 +73,40 @@ __global__ void __launch_bounds__(256) voxelize_fwd_kernel(const float *__restri
   }
 }
 
+// ---- K7, contention-free form: per-voxel segmented mean over a CSR of the points (order = point rows sorted by
+// voxel, rowptr (m+1)). Every output row is written exactly once: no memset, no atomics, deterministic; the
+// atomic form above runs at 0.55 TB/s on 1.4 M points (random voxel rows), this one at gather speed.
+template <int V>
+__global__ void __launch_bounds__(256) voxelize_fwd_csr_kernel(const float *__restrict__ feats,
+                                                               const int64_t *__restrict__ order,
+                                                               const int64_t *__restrict__ rowptr,
+                                                               const int32_t *__restrict__ counts,
+                                                               int64_t m, int c, int cv, float *__restrict__ out) {
+  using VT = typename Vec<V>::T;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; v < m;
+       v += (int64_t)gridDim.x * blockDim.y) {
+    const int64_t e0 = rowptr[v], e1 = rowptr[v + 1];
+    const int32_t cnt = counts[v];
+    const float fc = (float)(cnt > 0 ? cnt : 1);
+    VT *dst = reinterpret_cast<VT *>(out + v * c);
+    for (int j = threadIdx.x; j < cv; j += blockDim.x) {
+      VT acc; vzero(acc);
+      if (cnt != 0) {
+        int64_t e = e0;
+        for (; e + 1 < e1; e += 2) {  // two independent row loads in flight
+          const int64_t p0 = order[e], p1 = order[e + 1];
+          const VT f0 = vdiv(reinterpret_cast<const VT *>(feats + p0 * c)[j], fc);  // divide, then add
+          const VT f1 = vdiv(reinterpret_cast<const VT *>(feats + p1 * c)[j], fc);  // (voxelize_cuda.cu:27-29)
+          acc = vfma(1.f, f0, acc);
+          acc = vfma(1.f, f1, acc);
+        }
+        if (e < e1) acc = vfma(1.f, vdiv(reinterpret_cast<const VT *>(feats + order[e] * c)[j], fc), acc);
+      }
+      dst[j] = acc;
+    }
+  }
+}
+
 // ---- K8: gather back / count ------------------------------------------------------------------
 template <int V>
 __global__ void __launch_bounds__(256) voxelize_bwd_kernel(const float *__restrict__ gout,
@@ -240,6 +274,22 @@ extern "C" int pcs_voxelize_fwd_f32(const float *feats, const int32_t *idx,
     hipLaunchKernelGGL(voxelize_fwd_kernel<1>, rl.grid, rl.block, 0, st, feats, idx, counts, n, m, c, rl.cv, out);
   }
   return check_launch("pcs_voxelize_fwd");
+}
+
+extern "C" int pcs_voxelize_fwd_csr_f32(const float *feats, const int64_t *order, const int64_t *rowptr,
+                                        const int32_t *counts, int64_t m, int32_t c, float *out, void *stream) {
+  if (m < 0 || c <= 0) { set_error("pcs_voxelize_fwd_csr: bad sizes"); return PCS_EINVAL; }
+  if (m == 0) return PCS_OK;
+  if (!order || !rowptr || !counts || !out) { set_error("pcs_voxelize_fwd_csr: null pointer"); return PCS_EINVAL; }
+  hipStream_t st = as_stream(stream);
+  if ((c & 3) == 0 && aligned16(feats) && aligned16(out)) {
+    RowLaunch rl = row_launch<4>(m, c);
+    hipLaunchKernelGGL(voxelize_fwd_csr_kernel<4>, rl.grid, rl.block, 0, st, feats, order, rowptr, counts, m, c, rl.cv, out);
+  } else {
+    RowLaunch rl = row_launch<1>(m, c);
+    hipLaunchKernelGGL(voxelize_fwd_csr_kernel<1>, rl.grid, rl.block, 0, st, feats, order, rowptr, counts, m, c, rl.cv, out);
+  }
+  return check_launch("pcs_voxelize_fwd_csr");
 }
 
 extern "C" int pcs_voxelize_bwd_f32(const float *gout, const int32_t *idx, const int32_t *counts,

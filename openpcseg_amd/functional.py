@@ -59,8 +59,9 @@ class _Voxelize(Function):
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, feats, coords, counts):
         feats = feats.contiguous()
+        holder = coords  # the caller's tensor outlives this call (idx_query cache of point_to_voxel)
         coords = coords.contiguous().int()
-        out = _be().voxelize_fwd(feats, coords, counts)
+        out = _be().voxelize_fwd(feats, coords, counts, cache_on=holder)
         ctx.for_backwards = (coords, counts, feats.shape[0])
         return out
 

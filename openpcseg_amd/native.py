@@ -27,6 +27,7 @@ SIGNATURES = {
     "pcs_hashtable_query": (c_int32, [_P, c_int64, _P, c_int64, _P, _P]),
     "pcs_count": (c_int32, [_P, c_int64, _P, c_int64, _P]),
     "pcs_voxelize_fwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int64, c_int32, _P, _P]),
+    "pcs_voxelize_fwd_csr_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, _P, _P]),
     "pcs_voxelize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P]),
     "pcs_devoxelize_fwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P]),
     "pcs_devoxelize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int64, c_int32, _P, _P]),
@@ -49,6 +50,8 @@ SIGNATURES = {
     "pcs_scatter_max_bwd_f32": (c_int32, [_P, _P, c_int64, c_int64, c_int32, _P, _P]),
     "pcs_map_count": (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_denselize_fwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "pcs_denselize_fwd_csr_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "pcs_denselize_bwd_csr_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_denselize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_bn_num_partials": (c_int32, []),
     "pcs_bn_stats_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P]),
@@ -208,7 +211,28 @@ class HipBackend:
         return out
 
     # -- K7-K10 ---------------------------------------------------------------------------------
-    def voxelize_fwd(self, feats, idx, counts):
+    def voxelize_fwd(self, feats, idx, counts, cache_on=None):
+        """out[v] = sum over the points i of voxel v of feats[i] / counts[v]: segmented over the points sorted by
+        voxel (no atomics, deterministic). The sorted order is cached on `cache_on` (the caller's index tensor,
+        which point_to_voxel reuses at every stage) or on idx."""
+        feats = _dev(feats, "feats", torch.float32)
+        idx = _dev(idx, "coords", torch.int32)
+        counts = _dev(counts, "counts", torch.int32)
+        c = feats.shape[1]
+        m = counts.shape[0]
+        holder = cache_on if cache_on is not None else idx
+        csr = getattr(holder, "_pcs_vox_csr", None)
+        if csr is None or csr[2] != m or csr[3] != idx.shape[0]:
+            order, rowptr = self._csr(idx, m)
+            csr = (order, rowptr, m, idx.shape[0])
+            holder._pcs_vox_csr = csr
+        out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
+        _check(self.lib.pcs_voxelize_fwd_csr_f32(_ptr(feats), _ptr(csr[0]), _ptr(csr[1]), _ptr(counts), m, c,
+                                                 _ptr(out), _stream()), "pcs_voxelize_fwd_csr_f32")
+        return out
+
+    def voxelize_fwd_atomic(self, feats, idx, counts):
+        """The reference's literal K7 dataflow (fp32 atomics); kept for A/B measurements."""
         feats = _dev(feats, "feats", torch.float32)
         idx = _dev(idx, "coords", torch.int32)
         counts = _dev(counts, "counts", torch.int32)
@@ -393,9 +417,13 @@ class HipBackend:
         src = _dev(src, "src", torch.float32)
         index = _dev(index, "index", torch.int64)
         c = src.shape[1]
-        order, rowptr = self._csr(index, m)
+        csr = getattr(index, "_pcs_csr", None)  # the cylinder models scatter several tensors over one index
+        if csr is None or csr[2] != m:
+            csr = self._csr(index, m) + (m,)
+            index._pcs_csr = csr
+        order, rowptr = csr[0], csr[1]
         out = torch.empty((m, c), dtype=torch.float32, device=src.device)
-        arg = torch.empty((m, c), dtype=torch.int64, device=src.device)
+        arg = torch.empty((m, c), dtype=torch.int32, device=src.device)
         _check(self.lib.pcs_scatter_max_fwd_f32(_ptr(src), _ptr(order), _ptr(rowptr), m, c, _ptr(out), _ptr(arg),
                                                 _stream()), "pcs_scatter_max_fwd_f32")
         return out, arg
@@ -414,7 +442,35 @@ class HipBackend:
         _check(self.lib.pcs_map_count(_ptr(pxpy), pxpy.shape[0], b, h, w, _ptr(out), _stream()), "pcs_map_count")
         return out
 
+    def _pixel_csr(self, pxpy, b, h, w):
+        """Points sorted by pixel (out-of-image points first) + row pointers over the B*H*W pixels; cached on pxpy."""
+        csr = getattr(pxpy, "_pcs_px_csr", None)
+        if csr is None or csr[2] != (b, h, w):
+            pb, px, py = pxpy[:, 0].long(), pxpy[:, 1].long(), pxpy[:, 2].long()
+            ok = (pb >= 0) & (pb < b) & (px >= 0) & (px < w) & (py >= 0) & (py < h)
+            key = torch.where(ok, (pb * h + py) * w + px, torch.full_like(pb, -1))
+            order, rowptr = self._csr(key, b * h * w)
+            csr = (order, rowptr, (b, h, w))
+            pxpy._pcs_px_csr = csr
+        return csr
+
     def denselize_fwd(self, feat, count_map, pxpy):
+        """out[b, :, py, px] = mean of the feature rows of the points of pixel (b, py, px). C % 4 == 0: segmented over
+        the points sorted by pixel, NCHW stores in full lines, no atomics; otherwise the reference's atomic dataflow."""
+        feat = _dev(feat, "feat", torch.float32)
+        count_map = _dev(count_map, "count_map", torch.int32)
+        pxpy = _dev(pxpy, "pxpy", torch.int32)
+        (b, h, w), c = count_map.shape, feat.shape[1]
+        if c % 4:
+            return self.denselize_fwd_atomic(feat, count_map, pxpy)
+        csr = self._pixel_csr(pxpy, b, h, w)
+        out = torch.empty((b, c, h, w), dtype=torch.float32, device=feat.device)
+        _check(self.lib.pcs_denselize_fwd_csr_f32(_ptr(feat), _ptr(csr[0]), _ptr(csr[1]), _ptr(count_map), b, c, h, w,
+                                                  _ptr(out), _stream()), "pcs_denselize_fwd_csr_f32")
+        return out
+
+    def denselize_fwd_atomic(self, feat, count_map, pxpy):
+        """The reference's literal K14 dataflow (NCHW fp32 atomics): odd channel counts and A/B measurements."""
         feat = _dev(feat, "feat", torch.float32)
         count_map = _dev(count_map, "count_map", torch.int32)
         pxpy = _dev(pxpy, "pxpy", torch.int32)
@@ -429,10 +485,22 @@ class HipBackend:
         b, c, h, w = gout.shape
         n = pxpy.shape[0]
         gfeat = torch.empty((n, c), dtype=torch.float32, device=gout.device)
+        if c % 4:
+            return self.denselize_bwd_gather(gout, count_map, pxpy)
+        csr = self._pixel_csr(pxpy, b, h, w)
+        _check(self.lib.pcs_denselize_bwd_csr_f32(_ptr(gout), _ptr(csr[0]), _ptr(csr[1]), _ptr(count_map), n, b, c, h, w,
+                                                  _ptr(gfeat), _stream()), "pcs_denselize_bwd_csr_f32")
+        return gfeat
+
+    def denselize_bwd_gather(self, gout, count_map, pxpy):
+        """The reference's K15 dataflow (per-point strided NCHW gather): odd channel counts and A/B measurements."""
+        gout = _dev(gout, "top_grad", torch.float32)
+        b, c, h, w = gout.shape
+        n = pxpy.shape[0]
+        gfeat = torch.empty((n, c), dtype=torch.float32, device=gout.device)
         _check(self.lib.pcs_denselize_bwd_f32(_ptr(gout), _ptr(count_map), _ptr(pxpy), n, b, c, h, w, _ptr(gfeat),
                                               _stream()), "pcs_denselize_bwd_f32")
         return gfeat
-
 
     # -- fused BatchNorm (+residual, +ReLU) -------------------------------------------------------
     def bn_stats(self, x):

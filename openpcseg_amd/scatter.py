@@ -12,6 +12,29 @@ from torch.autograd import Function
 from . import native
 
 
+class ScatterMaxResult:
+    """(out, argmax) like torch_scatter's return value -- unpackable and indexable -- whose int64 argmax is only
+    materialised when read (the reference takes `[0]`; the kernel keeps an int32 argmax for backward)."""
+
+    def __init__(self, out, arg32):
+        self._out, self._arg32, self._arg64 = out, arg32, None
+
+    def _arg(self):
+        if self._arg64 is None:
+            self._arg64 = self._arg32.long()
+        return self._arg64
+
+    def __len__(self):
+        return 2
+
+    def __getitem__(self, i):
+        return (self._out, self._arg())[i] if i not in (0, -2) else self._out
+
+    def __iter__(self):
+        yield self._out
+        yield self._arg()
+
+
 class _ScatterMax(Function):
     @staticmethod
     def forward(ctx, src, index, dim_size):
@@ -30,7 +53,8 @@ def scatter_max(src, index, dim=0, out=None, dim_size=None):
     """-> (out (M,C), argmax (M,C)); only the dim=0, 2-D form used by the reference is provided."""
     assert dim == 0 and src.dim() == 2 and out is None
     m = int(dim_size) if dim_size is not None else int(index.max().item()) + 1
-    return _ScatterMax.apply(src, index, m)
+    out, arg32 = _ScatterMax.apply(src, index, m)
+    return ScatterMaxResult(out, arg32)
 
 
 def scatter_mean(src, index, dim=0, out=None, dim_size=None):

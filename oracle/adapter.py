@@ -55,7 +55,7 @@ class OracleBackend:
     def count(self, idx, num):
         return torch.from_numpy(orc.spcount(_np(idx), num))
 
-    def voxelize_fwd(self, feats, idx, counts):
+    def voxelize_fwd(self, feats, idx, counts, cache_on=None):
         return torch.from_numpy(orc.voxelize_fwd(_np(feats), _np(idx), _np(counts)))
 
     def voxelize_bwd(self, gout, idx, counts, n):
@@ -196,7 +196,7 @@ class RefBackend(OracleBackend):
     def count(self, idx, num):
         return self.ref.count_cpu(idx.contiguous(), int(num))
 
-    def voxelize_fwd(self, feats, idx, counts):
+    def voxelize_fwd(self, feats, idx, counts, cache_on=None):
         return self.ref.voxelize_forward_cpu(feats.contiguous(), idx.contiguous(), counts.contiguous())
 
     def voxelize_bwd(self, gout, idx, counts, n):

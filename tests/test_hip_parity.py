@@ -81,7 +81,12 @@ def test_voxelize(hip, c):
     idx[:17] = -1
     counts = orc.spcount(idx, m)
     feats = rng.normal(size=(n, c)).astype(np.float32)
-    close(hip.voxelize_fwd(t(feats), t(idx), t(counts)), orc.voxelize_fwd(feats, idx, counts), 1e-5)
+    want = orc.voxelize_fwd(feats, idx, counts)
+    di = t(idx)
+    out = hip.voxelize_fwd(t(feats), di, t(counts))  # segmented (sorted points), order cached on the index tensor
+    close(out, want, 1e-5)
+    assert di._pcs_vox_csr[2] == m and torch.equal(out, hip.voxelize_fwd(t(feats), di, t(counts)))  # deterministic
+    close(hip.voxelize_fwd_atomic(t(feats), t(idx), t(counts)), want, 1e-5)  # the reference's atomic dataflow
     gout = rng.normal(size=(m, c)).astype(np.float32)
     close(hip.voxelize_bwd(t(gout), t(idx), t(counts), n), orc.voxelize_bwd(gout, idx, counts, n), 1e-6)
 

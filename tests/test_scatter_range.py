@@ -84,21 +84,28 @@ def test_hip_scatter_max(hip, c):
 
 
 @pytest.mark.gpu
-def test_hip_rangelib(hip):
+@pytest.mark.parametrize("n,B,C,H,W", [(50000, 3, 24, 16, 128), (20000, 2, 80, 7, 100), (3000, 1, 5, 64, 512), (0, 1, 8, 4, 64)])
+def test_hip_rangelib(hip, n, B, C, H, W):
     rng = np.random.default_rng(3)
-    n, B, C, H, W = 50000, 3, 24, 16, 128
     pxpy = np.stack([rng.integers(0, B, n), rng.integers(-2, W + 2, n), rng.integers(-1, H + 1, n)], 1).astype(np.int32)
     feat = rng.normal(size=(n, C)).astype(np.float32)
     tp, tf = torch.from_numpy(pxpy).cuda(), torch.from_numpy(feat).cuda()
     cm = hip.map_count(tp, B, H, W)
     ecm = orc.map_count(pxpy, B, H, W)
     assert np.array_equal(cm.cpu().numpy(), ecm)
-    fm = hip.denselize_fwd(tf, cm, tp).cpu().numpy()
+    dfm = hip.denselize_fwd(tf, cm, tp)  # segmented over the points sorted by pixel; every element written once
+    fm = dfm.cpu().numpy()
     efm = orc.denselize_fwd(feat, ecm, pxpy)
-    assert np.abs(fm - efm).max() <= 1e-5 * np.abs(efm).max()
+    assert np.abs(fm - efm).max() <= 1e-5 * max(np.abs(efm).max(), 1e-30)
+    if C % 4 == 0:  # (odd channel counts take the atomic form)
+        assert torch.equal(dfm, hip.denselize_fwd(tf, cm, tp))  # deterministic
+    afm = hip.denselize_fwd_atomic(tf, cm, tp).cpu().numpy()  # the reference's atomic dataflow
+    assert np.abs(afm - efm).max() <= 1e-5 * max(np.abs(efm).max(), 1e-30)
     g = rng.normal(size=efm.shape).astype(np.float32)
+    egb = orc.denselize_bwd(g, ecm, pxpy)
     gb = hip.denselize_bwd(torch.from_numpy(g).cuda(), cm, tp).cpu().numpy()
-    assert np.allclose(gb, orc.denselize_bwd(g, ecm, pxpy), rtol=1e-6, atol=1e-7)
+    assert np.allclose(gb, egb, rtol=1e-6, atol=1e-7)
+    assert np.allclose(hip.denselize_bwd_gather(torch.from_numpy(g).cuda(), cm, tp).cpu().numpy(), egb, rtol=1e-6, atol=1e-7)
     ex = np.array([[0, 2, 2], [0, 2, 2], [1, 1, 0]], dtype=np.int32)  # RL:example.py
     assert np.array_equal(hip.map_count(torch.from_numpy(ex).cuda(), 2, 5, 4).cpu().numpy(), orc.map_count(ex, 2, 5, 4))
 

@@ -87,8 +87,11 @@ def main():
     counts = be.count(idx, m)
     for c in (4, 32, 96):
         f = torch.randn(n, c, device=dev)
-        add("spvoxelize C=%d" % c, "pcs_voxelize_fwd_f32", timed(lambda: be.voxelize_fwd(f, idx, counts), reps),
-            4 * c * (n + m) + 4 * n + 4 * m)
+        add("spvoxelize C=%d" % c, "pcs_voxelize_fwd_csr_f32", timed(lambda: be.voxelize_fwd(f, idx, counts), reps),
+            4 * c * (n + m) + 4 * n + 4 * m, "sorted point order cached on the index tensor")
+        if not DRY:
+            add("spvoxelize C=%d, atomic form" % c, "pcs_voxelize_fwd_f32", timed(lambda: be.voxelize_fwd_atomic(f, idx, counts), reps),
+                4 * c * (n + m) + 4 * n + 4 * m, "reference dataflow, kept for A/B")
         gv = torch.randn(m, c, device=dev)
         add("spvoxelize bwd C=%d" % c, "pcs_voxelize_bwd_f32", timed(lambda: be.voxelize_bwd(gv, idx, counts, n), reps),
             4 * c * (n + m) + 4 * n + 4 * m)
@@ -113,15 +116,24 @@ def main():
     idx64 = idx.long()
     be.scatter_max_fwd(f, idx64, m)
     add("scatter_max C=256", "pcs_scatter_max_fwd_f32", timed(lambda: be.scatter_max_fwd(f, idx64, m), reps),
-        4 * c * (n + m) + 8 * n, "CSR (argsort of the index) rebuilt per call")
+        4 * c * (n + m) + 8 * n, "sorted order cached on the index tensor")
     b, h, w_ = frames, 64, 2048
     pxpy = torch.stack([torch.randint(0, b, (n,), generator=g), torch.randint(0, w_, (n,), generator=g),
                         torch.randint(0, h, (n,), generator=g)], 1).int().to(dev)
     cm = be.map_count(pxpy, b, h, w_)
     add("range map_count", "pcs_map_count", timed(lambda: be.map_count(pxpy, b, h, w_), reps), 12 * n + 4 * b * h * w_)
     f32 = torch.randn(n, 32, device=dev)
-    add("range denselize C=32", "pcs_denselize_fwd_f32", timed(lambda: be.denselize_fwd(f32, cm, pxpy), reps),
-        4 * 32 * (n + b * h * w_) + 12 * n, "NCHW atomics (reference dataflow)")
+    add("range denselize C=32", "pcs_denselize_fwd_csr_f32", timed(lambda: be.denselize_fwd(f32, cm, pxpy), reps),
+        4 * 32 * (n + b * h * w_) + 12 * n, "sorted point order cached on the pxpy tensor")
+    if not DRY:
+        add("range denselize C=32, atomic form", "pcs_denselize_fwd_f32", timed(lambda: be.denselize_fwd_atomic(f32, cm, pxpy), reps),
+            4 * 32 * (n + b * h * w_) + 12 * n, "NCHW atomics (reference dataflow), kept for A/B")
+    g32 = torch.randn(b, 32, h, w_, device=dev)
+    add("range denselize bwd C=32", "pcs_denselize_bwd_csr_f32", timed(lambda: be.denselize_bwd(g32, cm, pxpy), reps),
+        4 * 32 * (n + b * h * w_) + 12 * n)
+    if not DRY:
+        add("range denselize bwd C=32, gather form", "pcs_denselize_bwd_f32", timed(lambda: be.denselize_bwd_gather(g32, cm, pxpy), reps),
+            4 * 32 * (n + b * h * w_) + 12 * n, "reference dataflow, kept for A/B")
 
     # ---- fused BatchNorm -------------------------------------------------------------------------------------
     for c in (32, 96, 256):
