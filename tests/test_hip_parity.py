@@ -206,15 +206,17 @@ def test_conv_forward_and_dgrad_kernel(hip, golden, cin, cout, tile):
 @pytest.mark.parametrize("cin,cout", [(96, 96), (128, 256), (64, 64)])
 @pytest.mark.parametrize("tile", [16, 80, 112, 144, 160])
 def test_conv_free_tile_heights(hip, golden, cin, cout, tile):
-    """cin >= 64 kernel: any multiple of 16 is a legal tile height (the per-layer pick uses 80..160); the ordered
-    commit makes the result independent of it bit for bit."""
+    """cin >= 64 kernel: any multiple of 16 is a legal tile height (the per-layer pick uses 80..160). The commit order
+    (full row-block groups, then partial ones) depends on the tile, so heights agree to rounding, and one height is
+    bit-reproducible run to run."""
     entry, (nbmaps, nbsizes), n_in, n_out = _scene_maps(hip, golden, "k3s1")
     rng = np.random.default_rng(cin + cout)
     x = rng.normal(size=(n_in, cin)).astype(np.float32)
     w = (rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32)
     y = hip.conv_gather_gemm(t(x), t(w), entry.fwd, tile_rows=tile)
     close(y, orc.conv_fwd(x, w, nbmaps, nbsizes, (n_in, n_out)), 2e-5)
-    assert torch.equal(y, hip.conv_gather_gemm(t(x), t(w), entry.fwd, tile_rows=128))
+    close(y, hip.conv_gather_gemm(t(x), t(w), entry.fwd, tile_rows=128).cpu().numpy(), 1e-6)
+    assert torch.equal(y, hip.conv_gather_gemm(t(x), t(w), entry.fwd, tile_rows=tile))
 
 
 def test_submanifold_reverse_map_mirror_equals_probe(hip, golden):

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Where a fused-conv launch spends its wall time, per wave: needs the debug library built with -DPCS_TRACE=1
+(openpcseg_amd/lib/dbg/trace.so, see profiles/round1_conv_pmc.md) through PCS_LIB_PATH.
+Usage: PCS_LIB_PATH=$PWD/openpcseg_amd/lib/dbg/trace.so python tools/conv_trace.py <level 0..4> <cin> <cout> [frames]
+Phases (wall clock, 10 ns ticks): entry->start = LDS zero-fill + offset list + first operand loads; per group:
+loop = channel loop (operand loads + MFMAs), ticket = waiting for the earlier groups to commit, commit = LDS RMW;
+other = locate/pair loads between groups; end->exit = final barrier + tile write-back."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from openpcseg_amd import functional as F  # noqa: E402
+from openpcseg_amd import native  # noqa: E402
+from openpcseg_amd.workloads.synthetic import make_batch  # noqa: E402
+
+
+def main():
+    level, cin, cout = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    frames = int(sys.argv[4]) if len(sys.argv) > 4 else 12
+    dev = torch.device("cuda:0")
+    coords = make_batch(list(range(frames)))["lidar"].C.to(dev)
+    coords = coords[torch.argsort(F.sphash(coords))].contiguous()
+    ts = 1
+    for _ in range(level):
+        coords = F.spdownsample(coords, 2, 2, ts)
+        ts *= 2
+    entry = F.build_kernel_map(coords, coords, (3, 3, 3), (ts,) * 3, (1, 1, 1))
+    be = native.backend()
+    x = torch.randn(coords.shape[0], cin, device=dev)
+    w = torch.randn(27, cin, cout, device=dev) * 0.05
+    for _ in range(3):
+        be.conv_gather_gemm(x, w, entry.fwd)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    be.conv_gather_gemm(x, w, entry.fwd)
+    e1.record()
+    torch.cuda.synchronize()
+    buf = np.zeros(8192 * 64, dtype=np.int64)
+    fn = be.lib.pcs_debug_conv_trace
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
+    assert fn(buf.ctypes.data) == 0
+    t = buf.reshape(8192, 8, 8)
+    t = t[t[:, :, 7] > 0]                      # waves that ran
+    tick = 0.01                                 # us
+    life = (t[:, 7] - t[:, 0]) * tick
+    k0, k1 = t[:, 0].min(), t[:, 7].max()
+    print("launch %.0f us by events; traced waves %d; first entry -> last exit %.0f us" % (e0.elapsed_time(e1) * 1e3, len(t), (k1 - k0) * tick))
+    tot = life.sum()
+    pre = ((t[:, 1] - t[:, 0]) * tick).sum()
+    loop, ticket, commit = (t[:, 3] * tick).sum(), (t[:, 4] * tick).sum(), (t[:, 5] * tick).sum()
+    main_ = ((t[:, 2] - t[:, 1]) * tick).sum()
+    post = ((t[:, 7] - t[:, 2]) * tick).sum()
+    print("wave lifetime: mean %.1f us, groups/wave mean %.1f" % (life.mean(), t[:, 6].mean()))
+    for name, v in [("prologue (zero-fill, offset list, first loads)", pre), ("channel loops", loop), ("ticket wait", ticket),
+                    ("commit", commit), ("between groups", main_ - loop - ticket - commit), ("final barrier + write-back", post)]:
+        print("  %-48s %5.1f %%" % (name, 100 * v / tot))
+    # occupancy over time: how many traced waves are alive
+    span = (k1 - k0) * tick
+    alive = life.sum() / span
+    print("mean traced waves alive %.0f (of %d wave slots at 2 workgroups/CU)" % (alive, 256 * 8))
+    # timeline: waves alive in 20 equal time bins (a long thin tail = load imbalance between workgroups)
+    edges = np.linspace(k0, k1, 21)
+    occ = [float(np.clip(np.minimum(t[:, 7], hi) - np.maximum(t[:, 0], lo), 0, None).sum() / (hi - lo)) for lo, hi in zip(edges[:-1], edges[1:])]
+    print("alive per 5 % time bin:", " ".join("%4.0f" % o for o in occ))
+    wg = t[:, 7] - t[:, 0]
+    print("wave lifetime percentiles (us): p10 %.0f p50 %.0f p90 %.0f max %.0f" % tuple(np.percentile(wg, [10, 50, 90, 100]) * tick))
+
+
+if __name__ == "__main__":
+    main()
