@@ -1214,11 +1214,14 @@ __device__ __forceinline__ void wgrad_block(const Wgrad2Args &w, int a0, int b0,
     for (int h = 0; h < NB; ++h) acc[f][h] = (f32x4){0, 0, 0, 0};
 
   struct Batch { AV a[4]; BV b[4]; };  // 16 pairs = 4 k-groups of 4 pairs
-  auto load_batch = [&](Batch &bt, int p0) {
-    // lane l15 fetches pair p0+l15 (clamped to the chunk), k-group j uses the pair held by lane 4j+g
+  // lane l15 fetches pair p0+l15 (clamped to the chunk); the pair indices run ONE batch ahead of the row loads, so
+  // the dependent chain (pair -> row address -> row) never sits inside one pipeline stage
+  auto load_pairs = [&](int p0) {
     int pi = p0 + l15;
     pi = pi < end ? pi : end - 1;
-    const int2 pr = reinterpret_cast<const int2 *>(w.pairs)[pi];
+    return reinterpret_cast<const int2 *>(w.pairs)[pi];
+  };
+  auto load_rows = [&](Batch &bt, const int2 pr) {  // k-group j uses the pair held by lane 4j+g
     const int ia = w.a_col ? pr.y : pr.x, ib = w.a_col ? pr.x : pr.y;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1241,15 +1244,18 @@ __device__ __forceinline__ void wgrad_block(const Wgrad2Args &w, int a0, int b0,
     }
   };
   Batch b0s, b1s;
-  load_batch(b0s, beg);
+  load_rows(b0s, load_pairs(beg));
+  int2 prn = load_pairs(beg + 16 < end ? beg + 16 : beg);  // pairs of the batch after the one in flight
   for (int p0 = beg; p0 < end; p0 += 32) {
-    const int p1 = p0 + 16 < end ? p0 + 16 : p0;  // clamped: a redundant batch is masked out below
-    load_batch(b1s, p1);
+    const int p2 = p0 + 32 < end ? p0 + 32 : p0;  // clamped: a redundant batch is masked out in mfma_batch
+    const int p3 = p0 + 48 < end ? p0 + 48 : p0;
+    load_rows(b1s, prn);
+    prn = load_pairs(p2);
     __builtin_amdgcn_sched_barrier(0);
     mfma_batch(b0s, p0);
     __builtin_amdgcn_sched_barrier(0);
-    const int p2 = p0 + 32 < end ? p0 + 32 : p0;
-    load_batch(b0s, p2);
+    load_rows(b0s, prn);
+    prn = load_pairs(p3);
     __builtin_amdgcn_sched_barrier(0);
     if (p0 + 16 < end) mfma_batch(b1s, p0 + 16);  // wave-uniform
     __builtin_amdgcn_sched_barrier(0);
@@ -1360,7 +1366,11 @@ extern "C" int32_t pcs_conv_pick_tile_rows(int64_t n_dst, int64_t n_pairs, int32
     const int64_t wgs = ceil_div(n_dst, T) * ncol;
     return (double)ceil_div(wgs, slots) * (T * ppr + 8.0 * K);
   };
-  // measured: beyond ~4 waves the choice is within +-3 % either way -> keep the default there
+  // many waves of workgroups and few pairs per row (strides 1/2: 4-5.5 pairs per row, 1.28-1.36x MFMA padding at
+  // 128 rows): one 8-wave workgroup per CU on 256-row tiles pads 1.15-1.17x (measured +3..4.5 %)
+  if (ceil_div(n_dst, 128) * ncol >= 8 * slots && ppr < 6.5 &&
+      (size_t)(257 * (16 * nctt + 4)) * 4 + 1024 <= kMaxDynLds) return 256;
+  // measured: beyond ~4 waves the choice among 96..160 is within +-3 % either way -> keep the default there
   if (ceil_div(n_dst, 128) * ncol >= 4 * slots) return 128;
   int best = 128;
   double best_cost = cost(128) * 0.95;
@@ -1405,6 +1415,7 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
   case N:                                                                                           \
     if (v5r == 3) return launch_conv5<N, 4, 2, 3>(a, st);                                           \
     if (v5r == 4) return launch_conv5<N, 4, 2, 4>(a, st);                                           \
+    if (a.tile_rows > 160) return launch_conv5<N, 8, 2, 2>(a, st); /* one 8-wave workgroup per CU */ \
     return launch_conv5<N, 4, 2, 2>(a, st);
     switch (nctt) {
       PCS_CONV5_CASE(2)

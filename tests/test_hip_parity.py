@@ -204,7 +204,7 @@ def test_conv_forward_and_dgrad_kernel(hip, golden, cin, cout, tile):
 
 
 @pytest.mark.parametrize("cin,cout", [(96, 96), (128, 256), (64, 64)])
-@pytest.mark.parametrize("tile", [16, 80, 112, 144, 160])
+@pytest.mark.parametrize("tile", [16, 80, 112, 144, 160, 256])
 def test_conv_free_tile_heights(hip, golden, cin, cout, tile):
     """cin >= 64 kernel: any multiple of 16 is a legal tile height (the per-layer pick uses 80..160). The commit order
     (full row-block groups, then partial ones) depends on the tile, so heights agree to rounding, and one height is
@@ -232,8 +232,10 @@ def test_submanifold_reverse_map_mirror_equals_probe(hip, golden):
 
 def test_conv_tile_pick_and_errors(hip, golden):
     lib = hip.lib
-    # many waves of workgroups: default height; 36k rows x 256 columns = 1.1 waves at 128 -> a taller tile
-    assert lib.pcs_conv_pick_tile_rows(1158864, 5112372, 27, 96, 96) == 128
+    # many waves + few pairs per row (stride 1): 256-row tiles (one 8-wave workgroup per CU, less MFMA padding);
+    # many waves, dense: default height; 36k rows x 256 columns = 1.1 waves at 128 -> a taller tile
+    assert lib.pcs_conv_pick_tile_rows(1158864, 5112372, 27, 96, 96) == 256
+    assert lib.pcs_conv_pick_tile_rows(329421, 2752033, 27, 128, 128) == 128
     assert lib.pcs_conv_pick_tile_rows(36068, 331722, 27, 256, 256) == 144
     assert lib.pcs_conv_pick_tile_rows(36068, 331722, 27, 32, 32) == 128  # not the cin >= 64 kernel
     entry, _, n_in, _ = _scene_maps(hip, golden, "k3s1")
