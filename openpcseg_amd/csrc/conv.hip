@@ -1182,17 +1182,21 @@ struct Wgrad2Args {
 };
 
 __host__ __device__ inline int wg_ngroups(int c) { return (c + 63) / 64; }
-// width class of group gi (0-based) of a c-channel operand: 64, 32 or 16 columns of MFMA tiles
-__host__ __device__ inline int wg_gwidth(int c, int gi) {
-  const int rem = c - 64 * gi;
-  return rem > 32 ? 64 : (rem > 16 ? 32 : 16);
+// width of the channel groups of a c-channel operand: c is cut into ceil(c/64) EQUAL groups of 16, 32, 48 or 64
+// channels (96 -> 48 + 48, not 64 + 32: the four waves of a workgroup own one output block each, and unequal blocks
+// leave three SIMDs waiting for the 64x64 one -- 96-channel layers ran at 55 % of the 256-channel rate)
+__host__ __device__ inline int wg_gwidth(int c) {
+  const int per = (c + wg_ngroups(c) - 1) / wg_ngroups(c);
+  return (per + 15) / 16 * 16;
 }
 
 template <int W> struct WVec;
 template <> struct WVec<64> { using T = float4; static constexpr int N = 4; };
+template <> struct WVec<48> { using T = float3; static constexpr int N = 3; };
 template <> struct WVec<32> { using T = float2; static constexpr int N = 2; };
 template <> struct WVec<16> { using T = float;  static constexpr int N = 1; };
 __device__ __forceinline__ float wcomp(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+__device__ __forceinline__ float wcomp(const float3 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 __device__ __forceinline__ float wcomp(const float2 &v, int i) { return i == 0 ? v.x : v.y; }
 __device__ __forceinline__ float wcomp(const float &v, int) { return v; }
 
@@ -1285,13 +1289,14 @@ __global__ void __launch_bounds__(256, 3) wgrad2_kernel(Wgrad2Args w) {
   const int nag = wg_ngroups(w.ca);
   if (beg >= end || blk >= nag * w.nbg) return;
   const int ag = blk / w.nbg, bg = blk - ag * w.nbg;
-  const int aw = wg_gwidth(w.ca, ag), bw = wg_gwidth(w.cb, bg);
+  const int aw = wg_gwidth(w.ca), bw = wg_gwidth(w.cb);
   float *out = w.partial + (int64_t)blockIdx.x * w.ca * w.cb;
-  const int a0 = 64 * ag, b0 = 64 * bg;
+  const int a0 = aw * ag, b0 = bw * bg;
 #define PCS_WG_CASE(A, B) if (aw == A && bw == B) { wgrad_block<A, B>(w, a0, b0, beg, end, out, lane); return; }
-  PCS_WG_CASE(64, 64) PCS_WG_CASE(64, 32) PCS_WG_CASE(64, 16)
-  PCS_WG_CASE(32, 64) PCS_WG_CASE(32, 32) PCS_WG_CASE(32, 16)
-  PCS_WG_CASE(16, 64) PCS_WG_CASE(16, 32) PCS_WG_CASE(16, 16)
+  PCS_WG_CASE(64, 64) PCS_WG_CASE(64, 48) PCS_WG_CASE(64, 32) PCS_WG_CASE(64, 16)
+  PCS_WG_CASE(48, 64) PCS_WG_CASE(48, 48) PCS_WG_CASE(48, 32) PCS_WG_CASE(48, 16)
+  PCS_WG_CASE(32, 64) PCS_WG_CASE(32, 48) PCS_WG_CASE(32, 32) PCS_WG_CASE(32, 16)
+  PCS_WG_CASE(16, 64) PCS_WG_CASE(16, 48) PCS_WG_CASE(16, 32) PCS_WG_CASE(16, 16)
 #undef PCS_WG_CASE
 }
 
