@@ -265,16 +265,18 @@ int pcs_denselize_bwd_f32(const float *gout, const int32_t *count_map, const int
  *             -> pcs_bn_bwd_apply_f32: dx = (g - sum_g/N - xhat * sum_gxhat/N) * invstd * w, dres = g
  *             (dw = sums2[c:], db = sums2[:c]).
  * partial_ws: pcs_bn_num_partials() * 2 * c floats.
+ * mask (optional, c % 32 == 0): n * c/32 words written by the apply pass, bit = [y > 0]; handed to the two backward
+ *   passes instead of y (then y may be NULL) -- the ReLU gate costs 1/32 of a tensor read instead of a whole one.
  */
 int32_t pcs_bn_num_partials(void);
 int pcs_bn_stats_f32(const float *x, int64_t n, int32_t c, float *partial_ws, double *sums, void *stream);
 int pcs_bn_finalize_f32(const double *sums, double count, int32_t c, double eps, double momentum,
                         float *running_mean, float *running_var, double *stat, void *stream);
 int pcs_bn_apply_f32(const float *x, const float *res, const double *stat, const float *w, const float *b,
-                     int64_t n, int32_t c, int32_t relu, float *y, void *stream);
-int pcs_bn_bwd_stats_f32(const float *dy, const float *x, const float *y, const double *stat, int64_t n,
-                         int32_t c, int32_t relu, float *partial_ws, double *sums2, void *stream);
-int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const double *stat,
+                     int64_t n, int32_t c, int32_t relu, float *y, uint32_t *mask, void *stream);
+int pcs_bn_bwd_stats_f32(const float *dy, const float *x, const float *y, const uint32_t *mask, const double *stat,
+                         int64_t n, int32_t c, int32_t relu, float *partial_ws, double *sums2, void *stream);
+int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const uint32_t *mask, const double *stat,
                          const double *sums2, double count, const float *w, int64_t n, int32_t c,
                          int32_t relu, float *dx, float *dres, void *stream);
 

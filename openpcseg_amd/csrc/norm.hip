@@ -26,7 +26,8 @@ __device__ __forceinline__ void setc(float &v, int, float s) { v = s; }
 // (backward: sum g, sum g*xhat with g = dy * [y > 0]). V = 4: 16-byte loads.
 template <bool BWD, int V>
 __global__ void __launch_bounds__(256) bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
-                                                         const float *__restrict__ y, const double *__restrict__ stat,
+                                                         const float *__restrict__ y, const uint32_t *__restrict__ mask,
+                                                         const double *__restrict__ stat,
                                                          int64_t n, int c, int cv, int relu, float *__restrict__ partial) {
   using VT = typename NV<V>::T;
   extern __shared__ float red[];  // [TY][2][TX*V]
@@ -48,11 +49,15 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float *__restrict
         const VT xv = reinterpret_cast<const VT *>(x + i * c)[j];
         if (BWD) {
           const VT gv = reinterpret_cast<const VT *>(dy + i * c)[j];
-          VT yv; if (relu) yv = reinterpret_cast<const VT *>(y + i * c)[j];
+          VT yv; unsigned bits = 0xFu;
+          if (relu) {
+            if (V == 4 && mask) bits = (mask[i * (c >> 5) + (j >> 3)] >> (4 * (j & 7))) & 0xFu;
+            else yv = reinterpret_cast<const VT *>(y + i * c)[j];
+          }
 #pragma unroll
           for (int q = 0; q < V; ++q) {
             float g = comp(gv, q);
-            if (relu && comp(yv, q) <= 0.f) g = 0.f;
+            if (relu && ((V == 4 && mask) ? !((bits >> q) & 1u) : comp(yv, q) <= 0.f)) g = 0.f;
             s0[q] += g;
             s1[q] += g * ((comp(xv, q) - mean[q]) * invstd[q]);
           }
@@ -122,7 +127,7 @@ template <int V>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ res,
                                                        const double *__restrict__ stat, const float *__restrict__ w,
                                                        const float *__restrict__ b, int64_t n, int c, int cv, int relu,
-                                                       float *__restrict__ y) {
+                                                       float *__restrict__ y, uint32_t *__restrict__ mask) {
   using VT = typename NV<V>::T;
   for (int j = threadIdx.x; j < cv; j += blockDim.x) {
     float sc[V], sh[V];
@@ -137,14 +142,21 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__
       const VT xv = reinterpret_cast<const VT *>(x + i * c)[j];
       VT rv; if (res) rv = reinterpret_cast<const VT *>(res + i * c)[j];
       VT o;
+      unsigned bits = 0;
 #pragma unroll
       for (int q = 0; q < V; ++q) {
         float t = fmaf(comp(xv, q), sc[q], sh[q]);
         if (res) t += comp(rv, q);
         if (relu && t < 0.f) t = 0.f;
+        bits |= (t > 0.f ? 1u : 0u) << q;
         setc(o, q, t);
       }
       reinterpret_cast<VT *>(y + i * c)[j] = o;
+      if (V == 4 && mask) {  // c % 32 == 0: 8 consecutive lanes (4 channels each) of one row make one word
+        unsigned m = bits << (4 * (j & 7));
+        m |= __shfl_xor(m, 1, 64); m |= __shfl_xor(m, 2, 64); m |= __shfl_xor(m, 4, 64);
+        if ((j & 7) == 0) mask[i * (c >> 5) + (j >> 3)] = m;
+      }
     }
   }
 }
@@ -152,7 +164,8 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__
 // g = dy * [y > 0];  dx = (g - sum_g/N - xhat * sum_gxhat/N) * invstd * w ;  dres = g
 template <int V>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
-                                                           const float *__restrict__ y, const double *__restrict__ stat,
+                                                           const float *__restrict__ y, const uint32_t *__restrict__ mask,
+                                                           const double *__restrict__ stat,
                                                            const double *__restrict__ sums2, double count,
                                                            const float *__restrict__ w, int64_t n, int c, int cv,
                                                            int relu, float *__restrict__ dx, float *__restrict__ dres) {
@@ -170,12 +183,16 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *__restri
     for (int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; i < n; i += (int64_t)gridDim.x * blockDim.y) {
       const VT gv = reinterpret_cast<const VT *>(dy + i * c)[j];
       const VT xv = reinterpret_cast<const VT *>(x + i * c)[j];
-      VT yv; if (relu) yv = reinterpret_cast<const VT *>(y + i * c)[j];
+      VT yv; unsigned bits = 0xFu;
+      if (relu) {
+        if (V == 4 && mask) bits = (mask[i * (c >> 5) + (j >> 3)] >> (4 * (j & 7))) & 0xFu;
+        else yv = reinterpret_cast<const VT *>(y + i * c)[j];
+      }
       VT o, r;
 #pragma unroll
       for (int q = 0; q < V; ++q) {
         float g = comp(gv, q);
-        if (relu && comp(yv, q) <= 0.f) g = 0.f;
+        if (relu && ((V == 4 && mask) ? !((bits >> q) & 1u) : comp(yv, q) <= 0.f)) g = 0.f;
         const float xh = (comp(xv, q) - mean[q]) * invstd[q];
         setc(o, q, (g - k1[q] - xh * k2[q]) * ws[q]);
         setc(r, q, g);
@@ -202,19 +219,20 @@ bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int32_t pcs_bn_num_partials(void) { return kStatBlocks; }
 
-static int bn_partial(bool bwd, const float *x, const float *dy, const float *y, const double *stat, int64_t n, int c,
-                      int relu, float *partial, double *sums, hipStream_t st) {
+static int bn_partial(bool bwd, const float *x, const float *dy, const float *y, const uint32_t *mask, const double *stat,
+                      int64_t n, int c, int relu, float *partial, double *sums, hipStream_t st) {
   const bool vec = (c & 3) == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)y) & 15) == 0;
+  if (mask && (!vec || (c & 31))) { set_error("pcs_bn: the ReLU bit mask needs c % 32 == 0 and 16-byte aligned rows"); return PCS_EUNSUPPORTED; }
   const int V = vec ? 4 : 1, cv = c / V;
   int tx = 1; while (tx < cv && tx < 64) tx <<= 1;
   dim3 block(tx, 256 / tx);
   const size_t lds = (size_t)(256 / tx) * 2 * tx * V * sizeof(float);
   if (vec) {
-    if (bwd) hipLaunchKernelGGL((bn_partial_kernel<true, 4>), dim3(kStatBlocks), block, lds, st, x, dy, y, stat, n, c, cv, relu, partial);
-    else hipLaunchKernelGGL((bn_partial_kernel<false, 4>), dim3(kStatBlocks), block, lds, st, x, dy, y, stat, n, c, cv, relu, partial);
+    if (bwd) hipLaunchKernelGGL((bn_partial_kernel<true, 4>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial);
+    else hipLaunchKernelGGL((bn_partial_kernel<false, 4>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial);
   } else {
-    if (bwd) hipLaunchKernelGGL((bn_partial_kernel<true, 1>), dim3(kStatBlocks), block, lds, st, x, dy, y, stat, n, c, cv, relu, partial);
-    else hipLaunchKernelGGL((bn_partial_kernel<false, 1>), dim3(kStatBlocks), block, lds, st, x, dy, y, stat, n, c, cv, relu, partial);
+    if (bwd) hipLaunchKernelGGL((bn_partial_kernel<true, 1>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial);
+    else hipLaunchKernelGGL((bn_partial_kernel<false, 1>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial);
   }
   hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)ceil_div(2 * c, 64)), dim3(64, 16), 0, st, partial, kStatBlocks, c, sums);
   return check_launch("pcs_bn_partial");
@@ -222,7 +240,7 @@ static int bn_partial(bool bwd, const float *x, const float *dy, const float *y,
 
 extern "C" int pcs_bn_stats_f32(const float *x, int64_t n, int32_t c, float *partial_ws, double *sums, void *stream) {
   if (n < 0 || c <= 0 || !x || !partial_ws || !sums) { set_error("pcs_bn_stats: bad args"); return PCS_EINVAL; }
-  return bn_partial(false, x, nullptr, nullptr, nullptr, n, c, 0, partial_ws, sums, as_stream(stream));
+  return bn_partial(false, x, nullptr, nullptr, nullptr, nullptr, n, c, 0, partial_ws, sums, as_stream(stream));
 }
 
 extern "C" int pcs_bn_finalize_f32(const double *sums, double count, int32_t c, double eps, double momentum,
@@ -234,40 +252,45 @@ extern "C" int pcs_bn_finalize_f32(const double *sums, double count, int32_t c, 
 }
 
 extern "C" int pcs_bn_apply_f32(const float *x, const float *res, const double *stat, const float *w, const float *b,
-                                int64_t n, int32_t c, int32_t relu, float *y, void *stream) {
+                                int64_t n, int32_t c, int32_t relu, float *y, uint32_t *mask, void *stream) {
   if (n < 0 || c <= 0) { set_error("pcs_bn_apply: bad sizes"); return PCS_EINVAL; }
   if (n == 0) return PCS_OK;
   if (!x || !stat || !y) { set_error("pcs_bn_apply: null pointer"); return PCS_EINVAL; }
   hipStream_t st = as_stream(stream);
-  if ((c & 3) == 0 && al16(x) && al16(y) && al16(res)) {
+  const bool vec = (c & 3) == 0 && al16(x) && al16(y) && al16(res);
+  if (mask && (!vec || (c & 31))) { set_error("pcs_bn_apply: the ReLU bit mask needs c % 32 == 0 and 16-byte aligned rows"); return PCS_EUNSUPPORTED; }
+  if (vec) {
     Geo g = geo<4>(n, c);
-    hipLaunchKernelGGL(bn_apply_kernel<4>, g.grid, g.block, 0, st, x, res, stat, w, b, n, c, g.cv, relu, y);
+    hipLaunchKernelGGL(bn_apply_kernel<4>, g.grid, g.block, 0, st, x, res, stat, w, b, n, c, g.cv, relu, y, mask);
   } else {
     Geo g = geo<1>(n, c);
-    hipLaunchKernelGGL(bn_apply_kernel<1>, g.grid, g.block, 0, st, x, res, stat, w, b, n, c, g.cv, relu, y);
+    hipLaunchKernelGGL(bn_apply_kernel<1>, g.grid, g.block, 0, st, x, res, stat, w, b, n, c, g.cv, relu, y, mask);
   }
   return check_launch("pcs_bn_apply");
 }
 
-extern "C" int pcs_bn_bwd_stats_f32(const float *dy, const float *x, const float *y, const double *stat, int64_t n,
-                                    int32_t c, int32_t relu, float *partial_ws, double *sums2, void *stream) {
-  if (n < 0 || c <= 0 || !dy || !x || !stat || !partial_ws || !sums2 || (relu && !y)) { set_error("pcs_bn_bwd_stats: bad args"); return PCS_EINVAL; }
-  return bn_partial(true, x, dy, y, stat, n, c, relu, partial_ws, sums2, as_stream(stream));
+extern "C" int pcs_bn_bwd_stats_f32(const float *dy, const float *x, const float *y, const uint32_t *mask,
+                                    const double *stat, int64_t n, int32_t c, int32_t relu, float *partial_ws,
+                                    double *sums2, void *stream) {
+  if (n < 0 || c <= 0 || !dy || !x || !stat || !partial_ws || !sums2 || (relu && !y && !mask)) { set_error("pcs_bn_bwd_stats: bad args"); return PCS_EINVAL; }
+  return bn_partial(true, x, dy, y, mask, stat, n, c, relu, partial_ws, sums2, as_stream(stream));
 }
 
-extern "C" int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const double *stat,
-                                    const double *sums2, double count, const float *w, int64_t n, int32_t c,
-                                    int32_t relu, float *dx, float *dres, void *stream) {
+extern "C" int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const uint32_t *mask,
+                                    const double *stat, const double *sums2, double count, const float *w, int64_t n,
+                                    int32_t c, int32_t relu, float *dx, float *dres, void *stream) {
   if (n < 0 || c <= 0 || count <= 0) { set_error("pcs_bn_bwd_apply: bad sizes"); return PCS_EINVAL; }
   if (n == 0) return PCS_OK;
-  if (!dy || !x || !stat || !sums2 || !dx || (relu && !y)) { set_error("pcs_bn_bwd_apply: null pointer"); return PCS_EINVAL; }
+  if (!dy || !x || !stat || !sums2 || !dx || (relu && !y && !mask)) { set_error("pcs_bn_bwd_apply: null pointer"); return PCS_EINVAL; }
   hipStream_t st = as_stream(stream);
-  if ((c & 3) == 0 && al16(dy) && al16(x) && al16(y) && al16(dx) && al16(dres)) {
+  const bool vec = (c & 3) == 0 && al16(dy) && al16(x) && al16(y) && al16(dx) && al16(dres);
+  if (mask && (!vec || (c & 31))) { set_error("pcs_bn_bwd_apply: the ReLU bit mask needs c % 32 == 0 and 16-byte aligned rows"); return PCS_EUNSUPPORTED; }
+  if (vec) {
     Geo g = geo<4>(n, c);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, g.grid, g.block, 0, st, dy, x, y, stat, sums2, count, w, n, c, g.cv, relu, dx, dres);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, w, n, c, g.cv, relu, dx, dres);
   } else {
     Geo g = geo<1>(n, c);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, g.grid, g.block, 0, st, dy, x, y, stat, sums2, count, w, n, c, g.cv, relu, dx, dres);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, w, n, c, g.cv, relu, dx, dres);
   }
   return check_launch("pcs_bn_bwd_apply");
 }

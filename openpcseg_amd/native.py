@@ -56,9 +56,9 @@ SIGNATURES = {
     "pcs_bn_num_partials": (c_int32, []),
     "pcs_bn_stats_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P]),
     "pcs_bn_finalize_f32": (c_int32, [_P, c_double, c_int32, c_double, c_double, _P, _P, _P, _P]),
-    "pcs_bn_apply_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P]),
-    "pcs_bn_bwd_stats_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
-    "pcs_bn_bwd_apply_f32": (c_int32, [_P, _P, _P, _P, _P, c_double, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
+    "pcs_bn_apply_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
+    "pcs_bn_bwd_stats_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
+    "pcs_bn_bwd_apply_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_double, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
     "pcs_quantize_floor": (c_int32, [_P, c_int32, c_int64, c_int32, _P, _P, _P, _P]),
     "pcs_quantize_keys": (c_int32, [_P, c_int64, _P, _P, _P]),
     "pcs_quantize_flags": (c_int32, [_P, c_int64, _P, _P]),
@@ -521,28 +521,43 @@ class HipBackend:
                                             _stream()), "pcs_bn_finalize_f32")
         return stat
 
-    def bn_apply(self, x, res, stat, w, b, relu):
+    def bn_apply(self, x, res, stat, w, b, relu, want_mask=False):
+        """y = act((x - mean) * invstd * w + b [+ res]). want_mask (c % 32 == 0): also the ReLU gate as n x c/32 int32
+        words (bit ch % 32 of word ch / 32 = [y > 0]) -- what the backward passes read instead of y."""
         x = _dev(x, "input", torch.float32)
         n, c = x.shape
+        if want_mask and c % 32:
+            raise RuntimeError("openpcseg_amd: the ReLU bit mask needs a channel count that is a multiple of 32")
         y = torch.empty_like(x)
+        mask = torch.empty((n, c // 32), dtype=torch.int32, device=x.device) if want_mask else None
         _check(self.lib.pcs_bn_apply_f32(_ptr(x), _ptr(res) if res is not None else None, _ptr(stat),
                                          _ptr(w) if w is not None else None, _ptr(b) if b is not None else None,
-                                         n, c, int(relu), _ptr(y), _stream()), "pcs_bn_apply_f32")
-        return y
+                                         n, c, int(relu), _ptr(y), _ptr(mask) if want_mask else None, _stream()),
+               "pcs_bn_apply_f32")
+        return (y, mask) if want_mask else y
 
-    def bn_bwd_stats(self, dy, x, y, stat, relu):
+    @staticmethod
+    def _gate(gate, relu):
+        """(y pointer, mask pointer) of the ReLU gate: the output tensor (float32) or its bit mask (int32)."""
+        if not relu or gate is None:
+            return None, None
+        return (None, _ptr(gate)) if gate.dtype == torch.int32 else (_ptr(gate), None)
+
+    def bn_bwd_stats(self, dy, x, gate, stat, relu):
         n, c = x.shape
         ws = torch.empty(self.lib.pcs_bn_num_partials() * 2 * c, dtype=torch.float32, device=x.device)
         sums2 = torch.empty(2 * c, dtype=torch.float64, device=x.device)
-        _check(self.lib.pcs_bn_bwd_stats_f32(_ptr(dy), _ptr(x), _ptr(y) if relu else None, _ptr(stat), n, c, int(relu),
+        yp, mp = self._gate(gate, relu)
+        _check(self.lib.pcs_bn_bwd_stats_f32(_ptr(dy), _ptr(x), yp, mp, _ptr(stat), n, c, int(relu),
                                              _ptr(ws), _ptr(sums2), _stream()), "pcs_bn_bwd_stats_f32")
         return sums2
 
-    def bn_bwd_apply(self, dy, x, y, stat, sums2, count, w, relu, want_res):
+    def bn_bwd_apply(self, dy, x, gate, stat, sums2, count, w, relu, want_res):
         n, c = x.shape
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if want_res else None
-        _check(self.lib.pcs_bn_bwd_apply_f32(_ptr(dy), _ptr(x), _ptr(y) if relu else None, _ptr(stat), _ptr(sums2),
+        yp, mp = self._gate(gate, relu)
+        _check(self.lib.pcs_bn_bwd_apply_f32(_ptr(dy), _ptr(x), yp, mp, _ptr(stat), _ptr(sums2),
                                              float(count), _ptr(w) if w is not None else None, n, c, int(relu),
                                              _ptr(dx), _ptr(dres) if want_res else None, _stream()),
                "pcs_bn_bwd_apply_f32")

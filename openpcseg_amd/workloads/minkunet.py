@@ -11,7 +11,7 @@ import torch
 from torch import nn
 
 from .. import modules as spnn
-from ..fused import FusedBatchNorm
+from ..fused import FusedBatchNorm, FusedLinear
 from ..sparse import PointTensor, cat, fapply
 from .losses import SegLoss
 from .pointvoxel import initial_voxelize, voxel_to_point
@@ -108,7 +108,7 @@ class MinkUNet(nn.Module):
                 ConvBlock(cin, cout, 2, 2, dist, transposed=True),
                 nn.Sequential(*_res_stack(cout + skip[i], cout, num_layer[4 + i], dist))]))
             cin = cout
-        self.classifier = nn.Sequential(nn.Linear(cs[4] + cs[6] + cs[8], num_class))
+        self.classifier = nn.Sequential((FusedLinear if FUSED else nn.Linear)(cs[4] + cs[6] + cs[8], num_class))
         self.dropout = nn.Dropout(dropout, True)
         self.criterion = SegLoss(ignore_index=ignore_label, label_smoothing=label_smoothing)
 

@@ -149,24 +149,35 @@ class OracleBackend:
             running_var.mul_(1 - momentum).add_((momentum * unb).float())
         return torch.cat([mean, 1.0 / torch.sqrt(var + eps)])
 
-    def bn_apply(self, x, res, stat, w, b, relu):
+    def bn_apply(self, x, res, stat, w, b, relu, want_mask=False):
         c = x.shape[1]
         y = (x - stat[:c].float()) * stat[c:].float()
         if w is not None:
             y = y * w + b
         if res is not None:
             y = y + res
-        return torch.relu(y) if relu else y
+        y = torch.relu(y) if relu else y
+        if not want_mask:
+            return y
+        bits = (y > 0).reshape(y.shape[0], c // 32, 32).long() << torch.arange(32)
+        words = bits.sum(-1)
+        return y, torch.where(words >= 2 ** 31, words - 2 ** 32, words).int()  # bit ch % 32 of word ch / 32
 
-    def bn_bwd_stats(self, dy, x, y, stat, relu):
+    @staticmethod
+    def _gate(gate, c):
+        if gate.dtype != torch.int32:
+            return gate > 0
+        return (((gate.long().unsqueeze(-1) >> torch.arange(32)) & 1) > 0).reshape(gate.shape[0], c)
+
+    def bn_bwd_stats(self, dy, x, gate, stat, relu):
         c = x.shape[1]
-        g = (dy * (y > 0)) if relu else dy
+        g = (dy * self._gate(gate, c)) if relu else dy
         xh = (x - stat[:c].float()) * stat[c:].float()
         return torch.cat([g.double().sum(0), (g * xh).double().sum(0)])
 
-    def bn_bwd_apply(self, dy, x, y, stat, sums2, count, w, relu, want_res):
+    def bn_bwd_apply(self, dy, x, gate, stat, sums2, count, w, relu, want_res):
         c = x.shape[1]
-        g = (dy * (y > 0)) if relu else dy
+        g = (dy * self._gate(gate, c)) if relu else dy
         xh = (x - stat[:c].float()) * stat[c:].float()
         dx = (g - (sums2[:c] / count).float() - xh * (sums2[c:] / count).float()) * stat[c:].float()
         if w is not None:

@@ -362,7 +362,32 @@ def test_full_scan_properties(hip):
 
 
 # ---- fused BatchNorm + residual + ReLU (block fusion above the op boundary) -----------------------------
-@pytest.mark.parametrize("c,relu,with_res", [(32, True, False), (96, True, True), (256, False, False), (5, True, True)])
+@pytest.mark.parametrize("c", [32, 96, 384])
+def test_bn_relu_gate_bitmask(hip, c):
+    """The apply pass packs [y > 0] into n x c/32 words; both backward passes give the same result from the mask as
+    from y itself (bit-identical: the gate is the only thing read from either)."""
+    torch.manual_seed(c)
+    n = 33333
+    x = torch.randn(n, c, device=DEV)
+    res = torch.randn(n, c, device=DEV)
+    w, b = torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV)
+    stat = hip.bn_finalize(hip.bn_stats(x), float(n), 1e-5, 0.1, None, None)
+    y, mask = hip.bn_apply(x, res, stat, w, b, True, want_mask=True)
+    assert torch.equal(y, hip.bn_apply(x, res, stat, w, b, True))
+    bits = ((mask.long().unsqueeze(-1) >> torch.arange(32, device=DEV)) & 1).reshape(n, c).bool()
+    assert torch.equal(bits, y > 0)
+    dy = torch.randn(n, c, device=DEV)
+    s_y, s_m = hip.bn_bwd_stats(dy, x, y, stat, True), hip.bn_bwd_stats(dy, x, mask, stat, True)
+    assert torch.equal(s_y, s_m)
+    for a, bb in zip(hip.bn_bwd_apply(dy, x, y, stat, s_y, float(n), w, True, True),
+                     hip.bn_bwd_apply(dy, x, mask, stat, s_y, float(n), w, True, True)):
+        assert torch.equal(a, bb)
+    with pytest.raises(RuntimeError):  # the mask needs whole 32-channel words
+        hip.bn_apply(x[:, :20].contiguous(), None, stat, None, None, True, want_mask=True)
+
+
+@pytest.mark.parametrize("c,relu,with_res", [(32, True, False), (96, True, True), (256, False, False), (5, True, True),
+                                             (384, True, True), (20, True, False)])
 def test_fused_batchnorm_matches_torch(hip, c, relu, with_res):
     from openpcseg_amd.fused import FusedBatchNorm
     from openpcseg_amd.sparse import SparseTensor
@@ -398,6 +423,28 @@ def test_fused_batchnorm_matches_torch(hip, c, relu, with_res):
     ye = bn(SparseTensor(x.detach(), coords), relu=relu).F
     te = torch.relu(ref(x.detach())) if relu else ref(x.detach())
     assert (ye - te).abs().max() <= 2e-5 * te.abs().max()
+
+
+def test_fused_linear_matches_torch(hip):
+    """The classifier (480 -> 20 over ~1e5..1e6 rows) on the fused conv kernels == nn.Linear, values and gradients."""
+    from openpcseg_amd.fused import FusedLinear
+    torch.manual_seed(3)
+    n = 50021
+    lin = FusedLinear(480, 20).to(DEV)
+    ref = torch.nn.Linear(480, 20).to(DEV)
+    ref.load_state_dict(lin.state_dict())
+    x = torch.randn(n, 480, device=DEV, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    y, t = lin(x), ref(x2)
+    assert (y - t).abs().max() <= 2e-5 * t.abs().max()
+    g = torch.randn_like(y)
+    y.backward(g)
+    t.backward(g)
+    assert (x.grad - x2.grad).abs().max() <= 2e-5 * x2.grad.abs().max()
+    assert (lin.weight.grad - ref.weight.grad).abs().max() <= 2e-5 * ref.weight.grad.abs().max()
+    assert (lin.bias.grad - ref.bias.grad).abs().max() <= 2e-5 * ref.bias.grad.abs().max()
+    small = torch.randn(100, 480, device=DEV)  # few rows: plain nn.Linear path
+    assert torch.allclose(lin(small), ref(small), atol=1e-5)
 
 
 # ---- device-side sparse_quantize (SURVEY 8 f1) ---------------------------------------------------------

@@ -146,13 +146,14 @@ def main():
         stat = be.bn_finalize(sums, float(rows_n), 1e-5, 0.1, None, None)
         add("BN apply+res+ReLU C=%d" % c, "pcs_bn_apply_f32", timed(lambda: be.bn_apply(x, res, stat, wgt, bias, True), reps),
             3 * 4 * c * rows_n)
-        y = be.bn_apply(x, res, stat, wgt, bias, True)
+        y, gate = be.bn_apply(x, res, stat, wgt, bias, True, want_mask=True)  # the ReLU gate as a bit mask
         dy = torch.randn(rows_n, c, device=dev)
-        add("BN bwd stats C=%d" % c, "pcs_bn_bwd_stats_f32", timed(lambda: be.bn_bwd_stats(dy, x, y, stat, True), reps),
-            3 * 4 * c * rows_n)
-        s2 = be.bn_bwd_stats(dy, x, y, stat, True)
+        add("BN bwd stats C=%d" % c, "pcs_bn_bwd_stats_f32", timed(lambda: be.bn_bwd_stats(dy, x, gate, stat, True), reps),
+            2 * 4 * c * rows_n, "gate read as bits")
+        s2 = be.bn_bwd_stats(dy, x, gate, stat, True)
         add("BN bwd apply C=%d" % c, "pcs_bn_bwd_apply_f32",
-            timed(lambda: be.bn_bwd_apply(dy, x, y, stat, s2, float(rows_n), wgt, True, True), reps), 5 * 4 * c * rows_n)
+            timed(lambda: be.bn_bwd_apply(dy, x, gate, stat, s2, float(rows_n), wgt, True, True), reps), 4 * 4 * c * rows_n,
+            "gate read as bits; writes dx and dres")
 
     print("%d frames: %d voxels, %d points, k3 rulebook %d pairs; peak %.0f GB/s\n" % (frames, m, n, p, PEAK))
     print("| op | C-ABI entry | us / call | algorithmic MB | GB/s | of HBM peak | note |")
