@@ -86,20 +86,32 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float *__restrict
   }
 }
 
-// sums[e] = sum over the nblk partial rows of partial[b][e], e in [0, 2c), accumulated in double in a FIXED
-// order (thread ty sums rows ty, ty+16, ...; then ty = 0..15 in order): deterministic, 64 x 16 threads per 64 columns.
+// sums[e] = sum over the nblk partial rows of partial[b][e], e in [0, 2c), accumulated in double in a FIXED order
+// (thread ty sums rows ty, ty+64, ...; then ty = 0..63 in order): deterministic. 16 columns x 64 row lanes per
+// workgroup: the kernel is pure latency (a few MB once per BatchNorm pass, 378 launches per training step), so the
+// rows are spread over as many lanes as a workgroup holds and each lane keeps its 16 loads in flight together.
 __global__ void __launch_bounds__(1024) bn_reduce_kernel(const float *__restrict__ partial, int nblk, int c,
                                                          double *__restrict__ sums) {
-  __shared__ double red[16][64];
-  const int e = blockIdx.x * 64 + threadIdx.x;
+  __shared__ double red[64][17];
+  const int e = blockIdx.x * 16 + threadIdx.x;
   double s = 0.0;
-  if (e < 2 * c)
-    for (int b = threadIdx.y; b < nblk; b += 16) s += (double)partial[(int64_t)b * 2 * c + e];
+  if (e < 2 * c) {
+    float v[16];
+    for (int b0 = threadIdx.y; b0 < nblk; b0 += 64 * 16) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int b = b0 + 64 * u;
+        v[u] = b < nblk ? partial[(int64_t)b * 2 * c + e] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += (double)v[u];
+    }
+  }
   red[threadIdx.y][threadIdx.x] = s;
   __syncthreads();
   if (threadIdx.y == 0 && e < 2 * c) {
     double t = 0.0;
-    for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
+    for (int r = 0; r < 64; ++r) t += red[r][threadIdx.x];
     sums[e] = t;
   }
 }
@@ -234,7 +246,7 @@ static int bn_partial(bool bwd, const float *x, const float *dy, const float *y,
     if (bwd) hipLaunchKernelGGL((bn_partial_kernel<true, 1>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial);
     else hipLaunchKernelGGL((bn_partial_kernel<false, 1>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial);
   }
-  hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)ceil_div(2 * c, 64)), dim3(64, 16), 0, st, partial, kStatBlocks, c, sums);
+  hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)ceil_div(2 * c, 16)), dim3(16, 64), 0, st, partial, kStatBlocks, c, sums);
   return check_launch("pcs_bn_partial");
 }
 
