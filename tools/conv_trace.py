@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a fused-conv launch spends its wall time, per wave: needs the debug library built with -DPCS_TRACE=1
-(openpcseg_amd/lib/dbg/trace.so, see profiles/round1_conv_pmc.md) through PCS_LIB_PATH.
+(`bash tools/build_debug_lib.sh trace -DPCS_TRACE=1`, see profiles/round1_conv_pmc.md) through PCS_LIB_PATH.
 Usage: PCS_LIB_PATH=$PWD/openpcseg_amd/lib/dbg/trace.so python tools/conv_trace.py <level 0..4> <cin> <cout> [frames]
 Phases (wall clock, 10 ns ticks): entry->start = LDS zero-fill + offset list + first operand loads; per group:
 loop = channel loop (operand loads + MFMAs), ticket = waiting for the earlier groups to commit, commit = LDS RMW;
