@@ -35,10 +35,21 @@ extern "C" int32_t pcs_conv_pick_tile_rows(int64_t n_dst, int64_t n_pairs, int32
   static const int fixed = getenv("PCS_CONV_TILE") ? atoi(getenv("PCS_CONV_TILE")) : 0;
   if (n_dst <= 0 || K <= 0 || !conv5_applies(cin, cout, K)) return 128;
   if (fixed > 0) return fixed;
-  const int nctt = conv_nctt(cout);
-  const int64_t ncol = ceil_div(cout, 16 * nctt);
   const int64_t slots = (int64_t)device_cus() * 2;
   const double ppr = (double)n_pairs / (double)n_dst;
+  if (cout >= 192) {
+    // wide outputs: 64-column tiles on 192..288-row tiles (two 4-wave workgroups per CU), see launch_conv_wave5
+    const int64_t ncol64 = ceil_div(cout, 64);
+    int best = 256;
+    double best_cost = 0;
+    for (int T = 192; T <= 288; T += 32) {
+      const double c = (double)ceil_div(ceil_div(n_dst, T) * ncol64, slots) * (T * ppr + 8.0 * K);
+      if (best_cost == 0 || c < best_cost) { best = T; best_cost = c; }
+    }
+    return best;
+  }
+  const int nctt = conv_nctt(cout);
+  const int64_t ncol = ceil_div(cout, 16 * nctt);
   auto cost = [&](int T) {
     const int64_t wgs = ceil_div(n_dst, T) * ncol;
     return (double)ceil_div(wgs, slots) * (T * ppr + 8.0 * K);

@@ -399,15 +399,24 @@ extern "C" int pcs_debug_conv_trace(long long *host_out) {
 #endif
 
 int pcs::launch_conv_wave5(ConvArgs a, hipStream_t st) {
-  const int nctt = conv_nctt(a.cout);
+  int nctt = conv_nctt(a.cout);
+  // wide outputs on tall tiles: 64-column tiles (4 workgroups per 256 columns instead of 2) -- the taller tile pads
+  // fewer MFMA rows and the A rows read twice as often cost nothing (profiles/round1_conv_pmc.md): +5..7 % at 256 ch
+  if (a.cout >= 192 && a.tile_rows >= 192) nctt = 4;
+  static const int force_nctt = getenv("PCS_CONV_NCTT") ? atoi(getenv("PCS_CONV_NCTT")) : 0;  // debug
+  static const int force_nw = getenv("PCS_CONV_NW") ? atoi(getenv("PCS_CONV_NW")) : 0;        // debug: 4 / 8
+  if (force_nctt && nctt > force_nctt) nctt = force_nctt;
   a.ncoltiles = (int)ceil_div(a.cout, 16 * nctt);
+  // 4-wave workgroups while two of them fit a CU's LDS, else one 8-wave workgroup
+  const size_t lds = (size_t)((a.tile_rows + 1) * (16 * nctt + 4)) * 4 + 1024;
+  const bool nw8 = force_nw ? force_nw == 8 : 2 * lds > 160 * 1024;
   // groups of 2 row blocks; PCS_CONV_V5=3/4: larger groups (debug: they spill at 6 / 8 column tiles)
   static const int v5r = getenv("PCS_CONV_V5") ? atoi(getenv("PCS_CONV_V5")) : 2;
 #define PCS_CONV5_CASE(N)                                                                           \
   case N:                                                                                           \
     if (v5r == 3) return launch_conv5<N, 4, 2, 3>(a, st);                                           \
     if (v5r == 4) return launch_conv5<N, 4, 2, 4>(a, st);                                           \
-    if (a.tile_rows > 160) return launch_conv5<N, 8, 2, 2>(a, st); /* one 8-wave workgroup per CU */ \
+    if (nw8) return launch_conv5<N, 8, 2, 2>(a, st); /* 8-wave workgroups */                          \
     return launch_conv5<N, 4, 2, 2>(a, st);
   switch (nctt) {
     PCS_CONV5_CASE(2)

@@ -148,7 +148,7 @@ class KmapEntry(list):
 def build_kernel_map(in_coords, out_coords, kernel_size, in_stride, dilation):
     offsets = get_kernel_offsets(kernel_size, stride=in_stride, dilation=dilation, device="cpu")
     symmetric = bool(torch.equal(offsets.flip(0), -offsets))  # odd kernel sizes
-    offsets = offsets.to(in_coords.device)
+    offsets = (offsets.pin_memory() if in_coords.is_cuda else offsets).to(in_coords.device, non_blocking=True)
     fwd = _be().build_kmap(in_coords, out_coords, offsets)
     return KmapEntry(fwd, in_coords, out_coords, offsets, symmetric)
 
@@ -193,8 +193,8 @@ def _identity_map(n, device, cache):
     if km is None:
         idx = torch.arange(n, dtype=torch.int32, device=device)
         km = native.KernelMap(torch.stack([idx, idx], dim=1).contiguous(),
-                              torch.tensor([0, n], dtype=torch.int32, device=device), [0, n],
-                              torch.tensor([n], dtype=torch.int64, device=device), n, n)
+                              native._h2d([0, n], torch.int32, device), [0, n],
+                              native._h2d([n], torch.int64, device), n, n)
         cache[key] = km
     return km
 

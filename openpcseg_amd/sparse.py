@@ -122,4 +122,7 @@ def get_kernel_offsets(size, stride=1, dilation=1, device="cpu"):
         grid = [[x, y, z] for z in axes[2] for y in axes[1] for x in axes[0]]
     else:
         grid = [[x, y, z] for x in axes[0] for y in axes[1] for z in axes[2]]
-    return torch.tensor(grid, dtype=torch.int, device=device)
+    if torch.device(device).type == "cpu":
+        return torch.tensor(grid, dtype=torch.int)
+    # pinned staging + asynchronous copy: a pageable host-to-device copy would wait for the whole GPU queue
+    return torch.tensor(grid, dtype=torch.int, pin_memory=True).to(device, non_blocking=True)
