@@ -55,9 +55,12 @@ extern "C" int32_t pcs_conv_pick_tile_rows(int64_t n_dst, int64_t n_pairs, int32
     return (double)ceil_div(wgs, slots) * (T * ppr + 8.0 * K);
   };
   // many waves of workgroups and few pairs per row (strides 1/2: 4-5.5 pairs per row, 1.28-1.36x MFMA padding at
-  // 128 rows): one 8-wave workgroup per CU on 256-row tiles pads 1.15-1.17x (measured +3..4.5 %)
-  if (ceil_div(n_dst, 128) * ncol >= 8 * slots && ppr < 6.5 &&
-      (size_t)(257 * (16 * nctt + 4)) * 4 + 1024 <= kMaxDynLds) return 256;
+  // 128 rows): one 8-wave workgroup per CU on 256..384-row tiles pads 1.12-1.17x (measured +3..8 %)
+  if (ceil_div(n_dst, 128) * ncol >= 8 * slots && ppr < 6.5) {
+    int T = 384;  // the tallest tile the LDS holds, up to 384 rows (256 -> 384 rows at 96 columns: another +4 %)
+    while (T > 128 && (size_t)((T + 1) * (16 * nctt + 4)) * 4 + 1024 > kMaxDynLds) T -= 32;
+    if (T >= 192) return T;
+  }
   // measured: beyond ~4 waves the choice among 96..160 is within +-3 % either way -> keep the default there
   if (ceil_div(n_dst, 128) * ncol >= 4 * slots) return 128;
   int best = 128;

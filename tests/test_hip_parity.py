@@ -204,7 +204,7 @@ def test_conv_forward_and_dgrad_kernel(hip, golden, cin, cout, tile):
 
 
 @pytest.mark.parametrize("cin,cout", [(96, 96), (128, 256), (64, 64)])
-@pytest.mark.parametrize("tile", [16, 80, 112, 144, 160, 224, 256, 288])
+@pytest.mark.parametrize("tile", [16, 80, 112, 144, 160, 224, 256, 288, 384])
 def test_conv_free_tile_heights(hip, golden, cin, cout, tile):
     """cin >= 64 kernel: any multiple of 16 is a legal tile height (the per-layer pick uses 80..160). The commit order
     (full row-block groups, then partial ones) depends on the tile, so heights agree to rounding, and one height is
@@ -235,7 +235,7 @@ def test_conv_tile_pick_and_errors(hip, golden):
     # many waves + few pairs per row (stride 1): 256-row tiles (one 8-wave workgroup per CU, less MFMA padding);
     # many waves, dense: default height; wide outputs (>= 192 columns): 64-column tiles on 192..288 rows, the height
     # that fills the last wave of workgroups (36k rows x 4 column tiles at 288 rows = 504 workgroups on 512 slots)
-    assert lib.pcs_conv_pick_tile_rows(1158864, 5112372, 27, 96, 96) == 256
+    assert lib.pcs_conv_pick_tile_rows(1158864, 5112372, 27, 96, 96) == 384
     assert lib.pcs_conv_pick_tile_rows(329421, 2752033, 27, 128, 128) == 128
     assert lib.pcs_conv_pick_tile_rows(36068, 331722, 27, 256, 256) == 288
     assert lib.pcs_conv_pick_tile_rows(113008, 1001308, 27, 128, 128) == 112
