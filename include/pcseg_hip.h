@@ -34,7 +34,7 @@ extern "C" {
 #define PCS_ELAUNCH (-3)  /* hipLaunch / hipMemsetAsync failed (pcs_last_error has text) */
 #define PCS_EUNSUPPORTED (-4)
 
-#define PCS_ABI_VERSION 1
+#define PCS_ABI_VERSION 2
 
 int pcs_abi_version(void);
 const char *pcs_last_error(void);

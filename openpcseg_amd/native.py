@@ -65,6 +65,7 @@ SIGNATURES = {
     "pcs_quantize_emit": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
 }
 
+ABI_VERSION = 2  # include/pcseg_hip.h PCS_ABI_VERSION (2: ReLU bit-mask arguments of the BN entries, int32 argmax)
 _lib = None
 
 
@@ -86,7 +87,7 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError = symbol missing = broken build
         fn.restype = res
         fn.argtypes = args
-    if lib.pcs_abi_version() != 1:
+    if lib.pcs_abi_version() != ABI_VERSION:
         raise RuntimeError("openpcseg_amd: ABI version mismatch")
     _lib = lib
     return lib
