@@ -135,3 +135,25 @@ def test_sync_fused_batchnorm_matches_global_batch(oracle_backend):
     assert np.allclose(gx_sh, full.grad.numpy(), atol=1e-5)
     assert np.allclose(got[0][3] + got[1][3], ref.weight.grad.numpy(), atol=1e-4)   # local sums add up (DDP averages)
     assert np.allclose(got[0][4], ref.running_var.numpy(), rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_device():
+    """The N > 1 code path of bench.py on the HIP backend: two ranks launched exactly like the driver launches them
+    (torch.distributed.run), both on cuda:0 with gloo carrying the collectives (PCS_BENCH_ONE_DEVICE rig): DDP over the
+    sparse convolutions, FusedBatchNorm in sync mode (per-layer statistics all-reduce, cached global row counts),
+    barrier + max-over-ranks timing, one JSON line from rank 0 with the whole-job frame count."""
+    import json
+    import subprocess
+    env = dict(os.environ, PCS_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--frames-per-gpu", "2"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["global_batch"] == 4
+    assert res["value"] > 0 and np.isfinite(res["config"]["loss"]) and "cpu_baseline" not in res
+    assert res["roofline"]["launches"] > 0
