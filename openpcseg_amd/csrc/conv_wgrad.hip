@@ -45,6 +45,31 @@ __device__ __forceinline__ void find_split(const int32_t *koff, int K, int pch, 
   *k_out = -1; *beg = 0; *end = 0;
 }
 
+// The same lookup by a whole wave at once (K <= 64): lane k loads its offset's slice bounds, one wave scan finds the
+// offset of `split` -- one load latency instead of up to K dependent ones at the head of every workgroup.
+__device__ __forceinline__ void find_split_wave(const int32_t *koff, int K, int pch, int split, int lane, int *beg,
+                                                int *end) {
+  if (K > 64) {
+    int k;
+    find_split(koff, K, pch, split, &k, beg, end);
+    return;
+  }
+  const int lo = lane < K ? koff[lane] : 0, hi = lane < K ? koff[lane + 1] : 0;
+  const int ns = (hi - lo + pch - 1) / pch;
+  int incl = ns;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  const unsigned long long hit = __ballot(split >= incl - ns && split < incl);  // at most one lane
+  if (!hit) { *beg = 0; *end = 0; return; }
+  const int src = __ffsll((long long)hit) - 1;
+  const int b = lo + (split - (incl - ns)) * pch;
+  const int e = b + pch < hi ? b + pch : hi;
+  *beg = __shfl(b, src, 64);
+  *end = __shfl(e, src, 64);
+}
+
 template <bool VEC>
 __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs w) {
   __shared__ __attribute__((aligned(16))) float abuf[WG_PB * WG_TS];
@@ -181,11 +206,23 @@ __global__ void __launch_bounds__(256) wgrad_reduce4_kernel(const float *__restr
   const int k = blockIdx.y;
   __shared__ int sh[2];
   __shared__ float4 red[16][16];
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int q = 0; q < k; ++q) acc += (koff[q + 1] - koff[q] + pch - 1) / pch;
-    sh[0] = acc;
-    sh[1] = (koff[k + 1] - koff[k] + pch - 1) / pch;
+  if (threadIdx.x < 64) {  // first split and split count of offset k: one wave scan over the offsets (K <= 64)
+    const int lane = threadIdx.x;
+    int acc = 0, mine = 0;
+    if (K <= 64) {
+      const int nsq = lane < K ? (koff[lane + 1] - koff[lane] + pch - 1) / pch : 0;
+      int incl = nsq;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      acc = __shfl(incl - nsq, k, 64);
+      mine = __shfl(nsq, k, 64);
+    } else {
+      for (int q = 0; q < k; ++q) acc += (koff[q + 1] - koff[q] + pch - 1) / pch;
+      mine = (koff[k + 1] - koff[k] + pch - 1) / pch;
+    }
+    if (lane == 0) { sh[0] = acc; sh[1] = mine; }
   }
   __syncthreads();
   const int base = sh[0], ns = sh[1];
@@ -343,11 +380,9 @@ __device__ __forceinline__ void wgrad_block(const Wgrad2Args &w, int a0, int b0,
 }
 
 __global__ void __launch_bounds__(256, 3) wgrad2_kernel(Wgrad2Args w) {
-  __shared__ int sh[3];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (tid == 0) find_split(w.koff, w.K, w.pch, blockIdx.x, &sh[0], &sh[1], &sh[2]);
-  __syncthreads();
-  const int beg = sh[1], end = sh[2];
+  int beg, end;
+  find_split_wave(w.koff, w.K, w.pch, blockIdx.x, lane, &beg, &end);  // per wave: no LDS, no barrier
   const int blk = blockIdx.y * 4 + wid;  // output block of this wave
   const int nag = wg_ngroups(w.ca);
   if (beg >= end || blk >= nag * w.nbg) return;
