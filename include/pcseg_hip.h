@@ -199,6 +199,10 @@ int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t cin, const
                              const int32_t *seg, int32_t tile_rows, int64_t n_dst,
                              const float *bias, float *dst, void *stream);
 
+/* dst[k][b][a] = src[k][a][b]: the per-offset transposed weights dgrad contracts with (the reference transposes
+ * inside torch::mm_out per offset, convolution_cuda.cu:259-263). */
+int pcs_transpose_kab_f32(const float *src, int32_t K, int32_t A, int32_t B, float *dst, void *stream);
+
 /* wgrad:  gW[k] = sum over pairs (a, b) of offset k:  fa[a, :]^T (outer) fb[b, :]
  *   fa (na, ca) rows indexed by pairs column a_col, fb (nb, cb) by the other column;
  *   gW (K, ca, cb). Deterministic two-pass split reduction; ws from pcs_conv_wgrad_ws_bytes.

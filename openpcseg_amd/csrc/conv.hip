@@ -19,7 +19,32 @@ int device_cus() {
   return cus;
 }
 
+// dst[k][b][a] = src[k][a][b]: per-offset transposed weights for dgrad (a few MB per layer, once per backward pass).
+// 32x32 LDS tiles (+1 padding), 128-byte lines on both sides -- the generic strided copy ran at ~0.7 TB/s here.
+__global__ void __launch_bounds__(256) transpose_kab_kernel(const float *__restrict__ src, int A, int B,
+                                                            float *__restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int k = blockIdx.z, a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float *s = src + (int64_t)k * A * B;
+  float *d = dst + (int64_t)k * A * B;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8)
+    if (a0 + r < A && b0 + tx < B) tile[r][tx] = s[(int64_t)(a0 + r) * B + b0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8)
+    if (b0 + r < B && a0 + tx < A) d[(int64_t)(b0 + r) * A + a0 + tx] = tile[tx][r];
+}
+
 }  // namespace
+
+extern "C" int pcs_transpose_kab_f32(const float *src, int32_t K, int32_t A, int32_t B, float *dst, void *stream) {
+  if (K <= 0 || A <= 0 || B <= 0 || K > 65535 || !src || !dst) { set_error("pcs_transpose_kab_f32: bad args"); return PCS_EINVAL; }
+  hipLaunchKernelGGL(transpose_kab_kernel, dim3((unsigned)ceil_div(B, 32), (unsigned)ceil_div(A, 32), (unsigned)K), dim3(256),
+                     0, as_stream(stream), src, A, B, dst);
+  return check_launch("pcs_transpose_kab_f32");
+}
 
 extern "C" int32_t pcs_conv_tile_rows(int32_t cin, int32_t cout) {
   (void)cin;

@@ -176,7 +176,7 @@ class _SparseConv(Function):
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
         grad_input = grad_weight = None
         if ctx.needs_input_grad[0]:
-            wt = w3.transpose(1, 2).contiguous()
+            wt = _be().transpose_weights(w3)
             grad_input = _be().conv_gather_gemm(grad_output, wt, entry.fwd if transposed else entry.rev)
         if ctx.needs_input_grad[1]:
             # fwd pairs are (in_row, out_row) of the NON-transposed conv; a transposed conv's

@@ -43,6 +43,7 @@ SIGNATURES = {
     "pcs_conv_pick_tile_rows": (c_int32, [c_int64, c_int64, c_int32, c_int32, c_int32]),
     "pcs_conv_gather_gemm_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32,
                                            _P, c_int32, c_int64, _P, _P, _P]),
+    "pcs_transpose_kab_f32": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_conv_wgrad_ws_bytes": (c_size_t, [_P, c_int32, c_int32, c_int32]),
     "pcs_conv_wgrad_f32": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P,
                                      _P, c_size_t, _P]),
@@ -406,6 +407,14 @@ class HipBackend:
                                                  _ptr(bias) if bias is not None else None, _ptr(dst),
                                                  _stream()), "pcs_conv_gather_gemm_f32")
         return dst
+
+    def transpose_weights(self, w):
+        """(K, A, B) -> (K, B, A) contiguous: the weights dgrad contracts with."""
+        w = _dev(w, "weight", torch.float32)
+        k, a, b = w.shape
+        out = torch.empty((k, b, a), dtype=torch.float32, device=w.device)
+        _check(self.lib.pcs_transpose_kab_f32(_ptr(w), k, a, b, _ptr(out), _stream()), "pcs_transpose_kab_f32")
+        return out
 
     def conv_wgrad(self, fa, fb, kmap, a_col):
         """gW[k] = sum_{pairs of k} fa[pair[a_col]]^T (x) fb[pair[1-a_col]] -> (K, ca, cb)."""

@@ -70,6 +70,9 @@ class OracleBackend:
     def ti_weights(self, coords, idx_query, scale):
         return torch.from_numpy(orc.calc_ti_weights(_np(coords), _np(idx_query), scale))
 
+    def transpose_weights(self, w):
+        return w.transpose(1, 2).contiguous()
+
     def quantize(self, points, voxel_size3, want_index, want_inverse):
         vox, index, inverse = orc.sparse_quantize(_np(points), voxel_size3)
         return (torch.from_numpy(vox), torch.from_numpy(index) if want_index else None,

@@ -230,6 +230,12 @@ def test_submanifold_reverse_map_mirror_equals_probe(hip, golden):
     assert (entry.rev.n_src, entry.rev.n_dst) == (built.n_src, built.n_dst)
 
 
+@pytest.mark.parametrize("shape", [(27, 256, 128), (8, 96, 32), (1, 20, 480), (27, 5, 33)])
+def test_weight_transpose(hip, shape):
+    w = torch.randn(*shape, device=DEV)
+    assert torch.equal(hip.transpose_weights(w), w.transpose(1, 2).contiguous())
+
+
 def test_conv_tile_pick_and_errors(hip, golden):
     lib = hip.lib
     # many waves + few pairs per row (stride 1): 256-row tiles (one 8-wave workgroup per CU, less MFMA padding);
