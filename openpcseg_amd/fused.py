@@ -18,10 +18,12 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def _global_rows(n_local, device, cache):
+def _global_rows(n_local, device, cache, level):
     """Total row count over all ranks for a tensor with n_local rows. One tiny all-reduce + host read per
-    resolution level and forward pass (cached in the pass-wide `cmaps` dict), not one per BN layer."""
-    key = ("_pcs_bn_rows", n_local)
+    resolution level and forward pass (cached in the pass-wide `cmaps` dict), not one per BN layer. The key holds the
+    level (tensor stride), so the hit / miss sequence -- hence the sequence of collectives -- is the same on every
+    rank whatever the per-rank row counts are."""
+    key = ("_pcs_bn_rows", level, n_local)
     if cache is not None and key in cache:
         return cache[key]
     t = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
@@ -34,7 +36,7 @@ def _global_rows(n_local, device, cache):
 
 class _FusedBN(Function):
     @staticmethod
-    def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, sync, cache):
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, sync, cache, level):
         be = native.backend()
         x = x.contiguous()
         res = res.contiguous() if res is not None else None
@@ -42,7 +44,7 @@ class _FusedBN(Function):
         sums = be.bn_stats(x)
         count = float(n)
         if sync and _world() > 1:
-            count = _global_rows(n, x.device, cache)
+            count = _global_rows(n, x.device, cache, level)
             sums = sums.clone()
             dist.all_reduce(sums)  # (sum, sum^2) over all ranks: SyncBatchNorm statistics
         stat = be.bn_finalize(sums, count, eps, momentum, running_mean, running_var)
@@ -71,7 +73,7 @@ class _FusedBN(Function):
         dx, dres = be.bn_bwd_apply(dy, x, gate, stat, sums2, count, weight, relu, has_res)
         dw = local[c:].float() if weight is not None else None   # local sums: DDP averages parameter grads
         db = local[:c].float() if weight is not None else None
-        return dx, dres, dw, db, None, None, None, None, None, None, None
+        return dx, dres, dw, db, None, None, None, None, None, None, None, None
 
 
 class FusedBatchNorm(nn.Module):
@@ -96,7 +98,7 @@ class FusedBatchNorm(nn.Module):
         if self.training:
             self.num_batches_tracked += 1
             y = _FusedBN.apply(x, r, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                               self.momentum, relu, self.sync, input.cmaps)
+                               self.momentum, relu, self.sync, input.cmaps, input.stride)
         else:
             inv = torch.rsqrt(self.running_var.double() + self.eps)
             stat = torch.cat([self.running_mean.double(), inv]).contiguous()
