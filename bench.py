@@ -52,10 +52,7 @@ class ConvMeter:
             e0.record()
             out = self.orig(src, weight, kmap, bias, tile_rows)
             e1.record()
-            k, cin, cout = weight.shape
-            p = kmap.num_pairs
-            self.records.append((e0, e1, 2.0 * p * cin * cout,
-                                 4.0 * (src.shape[0] * cin + kmap.n_dst * cout) + 8.0 * p + 4.0 * k * cin * cout))
+            self.records.append((e0, e1, kmap, tuple(weight.shape), src.shape[0]))  # pair counts are read at summary time
             return out
         self.be.conv_gather_gemm = wrapped
         return self
@@ -67,8 +64,11 @@ class ConvMeter:
         if not self.records:
             return None
         ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
-        flops = sum(r[2] for r in self.records)
-        abytes = sum(r[3] for r in self.records)
+        flops = abytes = 0.0
+        for _, _, kmap, (k, cin, cout), n_src in self.records:
+            p = kmap.num_pairs
+            flops += 2.0 * p * cin * cout
+            abytes += 4.0 * (n_src * cin + kmap.n_dst * cout) + 8.0 * p + 4.0 * k * cin * cout
         n = len(self.records)
         achieved = flops / (ms * 1e-3) / 1e12
         traffic = None  # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside bench.py)

@@ -125,14 +125,24 @@ class KmapEntry(list):
       .rev  pairs (out_row, in_row), in ascending within an offset   (built on first use;
             needed by dgrad and by transposed convolutions)"""
 
-    def __init__(self, fwd, in_coords, out_coords, offsets, symmetric=False):
-        super().__init__([fwd.pairs, fwd.nbsizes, (in_coords.shape[0], out_coords.shape[0])])
+    def __init__(self, fwd, in_coords, out_coords, offsets, symmetric=False, hint_key=None):
+        # item 0 (nbmaps) is read through __getitem__: the native map hands out its exact-size pair list lazily
+        super().__init__([None, fwd.nbsizes, (in_coords.shape[0], out_coords.shape[0])])
         self.fwd = fwd
         self._rev = None
         self._ctx = (in_coords, out_coords, offsets)
+        self._hint_key = hint_key
         # submanifold map (same coordinate tensor on both sides) with point-symmetric offsets: the input-sorted
         # map is a slice permutation of the forward map, no second probe pass
         self._mirror = symmetric and in_coords is out_coords
+
+    def __getitem__(self, i):
+        if isinstance(i, int) and i in (0, -3):
+            return self.fwd.pairs
+        return super().__getitem__(i)
+
+    def __iter__(self):
+        return iter([self[0], super().__getitem__(1), super().__getitem__(2)])
 
     @property
     def rev(self):
@@ -141,7 +151,8 @@ class KmapEntry(list):
             if self._mirror:
                 self._rev = self.fwd.mirror()
             else:
-                self._rev = _be().build_kmap(out_coords, in_coords, -offsets)
+                key = None if self._hint_key is None else self._hint_key + ("rev",)
+                self._rev = _be().build_kmap(out_coords, in_coords, -offsets, hint_key=key)
         return self._rev
 
 
@@ -149,8 +160,9 @@ def build_kernel_map(in_coords, out_coords, kernel_size, in_stride, dilation):
     offsets = get_kernel_offsets(kernel_size, stride=in_stride, dilation=dilation, device="cpu")
     symmetric = bool(torch.equal(offsets.flip(0), -offsets))  # odd kernel sizes
     offsets = (offsets.pin_memory() if in_coords.is_cuda else offsets).to(in_coords.device, non_blocking=True)
-    fwd = _be().build_kmap(in_coords, out_coords, offsets)
-    return KmapEntry(fwd, in_coords, out_coords, offsets, symmetric)
+    hint_key = (tuple(kernel_size), tuple(in_stride), tuple(dilation), in_coords is out_coords)  # map family
+    fwd = _be().build_kmap(in_coords, out_coords, offsets, hint_key=hint_key)
+    return KmapEntry(fwd, in_coords, out_coords, offsets, symmetric, hint_key)
 
 
 class _SparseConv(Function):

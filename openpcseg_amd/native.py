@@ -140,35 +140,84 @@ class HashTable:
         self.storage, self.capacity, self.n = storage, capacity, n
 
 
+_PPR_HINT = {}  # pairs per destination row last seen for a map family (kernel / stride key): launch-shape estimates
+
+
 class KernelMap:
     """A rulebook: pairs (P,2) int32 = (src_row, dst_row), k-major, dst ascending within k.
 
-    `koff` are the K+1 slice offsets (device int32) and `koff_host` the same numbers on the
-    host; `nbsizes` (K,) int64 mirrors the reference's kmap entry
-    (TS:torchsparse/nn/functional/conv.py:168). Tile-segment tables are cached per tile height.
+    `koff` are the K+1 slice offsets (device int32) and `koff_host` the same numbers on the host; `nbsizes` (K,) int64
+    mirrors the reference's kmap entry (TS:torchsparse/nn/functional/conv.py:168). Tile-segment tables are cached per
+    tile height.
+
+    Deferred sizes: a map built by `HipBackend.build_kmap` does not wait for its per-offset sizes. The pair list lives
+    in a buffer sized for the worst case (K * n_dst rows), the sizes travel to pinned host memory asynchronously, and
+    `koff_host` / `num_pairs` / `pairs` block on that copy only when first read -- in practice in the backward pass
+    (weight-gradient plan), long after it has landed. The forward launches (segment tables, fused conv) only need the
+    device-side `koff`, so a forward pass no longer drains the GPU queue once per map.
     """
 
-    def __init__(self, pairs, koff, koff_host, nbsizes, n_src, n_dst):
-        self.pairs, self.koff, self.koff_host, self.nbsizes = pairs, koff, koff_host, nbsizes
+    def __init__(self, pairs, koff, koff_host, nbsizes, n_src, n_dst, pending=None, hint_key=None):
+        self._pairs_raw, self.koff, self.nbsizes = pairs, koff, nbsizes
         self.n_src, self.n_dst = n_src, n_dst
-        self.K = len(koff_host) - 1
+        self._koff_host, self._pending, self.hint_key = koff_host, pending, hint_key
+        self.K = int(nbsizes.shape[0]) if koff_host is None else len(koff_host) - 1
         self._seg = {}
-        self._koff_c = (c_int32 * (self.K + 1))(*koff_host)
+        self._koff_c_cache = None
+
+    def _resolve(self):
+        if self._koff_host is None:
+            sizes, event = self._pending
+            event.synchronize()
+            ko = [0]
+            for v in sizes.tolist():
+                ko.append(ko[-1] + int(v))
+            self._koff_host, self._pending = ko, None
+            self._pairs_raw = self._pairs_raw[:ko[-1]]  # exact-size view of the worst-case buffer
+            if self.hint_key is not None and self.n_dst > 0:
+                _PPR_HINT[self.hint_key] = ko[-1] / float(self.n_dst)
+        return self._koff_host
+
+    @property
+    def resolved(self):
+        return self._koff_host is not None
+
+    @property
+    def koff_host(self):
+        return self._resolve()
+
+    @property
+    def pairs(self):
+        self._resolve()
+        return self._pairs_raw
+
+    @property
+    def _koff_c(self):
+        if self._koff_c_cache is None:
+            self._koff_c_cache = (c_int32 * (self.K + 1))(*self._resolve())
+        return self._koff_c_cache
 
     @property
     def num_pairs(self):
-        return self.koff_host[-1]
+        return self._resolve()[-1]
+
+    def num_pairs_estimate(self):
+        """Exact once the sizes are on the host; before that, the last pairs-per-row seen for this map family
+        (only the launch shape of the fused conv depends on it)."""
+        if self._koff_host is not None:
+            return self._koff_host[-1]
+        return int(_PPR_HINT.get(self.hint_key, 0.22 * self.K) * self.n_dst)
 
     def mirror(self):
         """The input-sorted map of a submanifold convolution with point-symmetric offsets (off[K-1-k] == -off[k]),
         without probing: its offset-k slice IS the offset-(K-1-k) slice of this map (pairs (r, q) with
         coord[r] = coord[q] - off[k], q ascending, r and q rows of the same coordinate set)."""
         k, ko = self.K, self.koff_host
-        pairs = torch.cat([self.pairs[ko[k - 1 - j]:ko[k - j]] for j in range(k)], dim=0)
+        pairs = torch.cat([self._pairs_raw[ko[k - 1 - j]:ko[k - j]] for j in range(k)], dim=0)
         koff_host = [0]
         for j in range(k):
             koff_host.append(koff_host[-1] + ko[k - j] - ko[k - 1 - j])
-        koff = _h2d(koff_host, torch.int32, self.pairs.device)
+        koff = _h2d(koff_host, torch.int32, self._pairs_raw.device)
         return KernelMap(pairs, koff, koff_host, self.nbsizes.flip(0), self.n_dst, self.n_src)
 
 
@@ -344,9 +393,10 @@ class HipBackend:
         return out
 
     # -- rulebook -------------------------------------------------------------------------------
-    def build_kmap(self, ref_coords, query_coords, offsets):
+    def build_kmap(self, ref_coords, query_coords, offsets, hint_key=None):
         """pairs (ref_row, query_row) for hash(query + offsets[k]) == hash(ref); k-major, query
-        ascending. One host sync (the per-offset sizes size the pair list)."""
+        ascending. No host sync: the per-offset sizes are copied to pinned memory asynchronously and read when
+        `koff_host` / `pairs` / `num_pairs` of the map are first needed (KernelMap, deferred sizes)."""
         ref_coords = _dev(ref_coords, "coords", torch.int32)
         query_coords = _dev(query_coords, "coords", torch.int32)
         offsets = _dev(offsets, "offsets", torch.int32)
@@ -360,28 +410,28 @@ class HipBackend:
         _check(self.lib.pcs_rulebook_probe(_ptr(query_coords), nq, _ptr(offsets), k, _ptr(table.storage),
                                            table.capacity, _ptr(results), _ptr(nbsizes), _ptr(ws),
                                            ws_bytes, _stream()), "pcs_rulebook_probe")
-        sizes = nbsizes.cpu().tolist()  # the one sync of a rulebook build
-        koff_host = [0]
-        for s in sizes:
-            koff_host.append(koff_host[-1] + int(s))
-        pairs = torch.empty((koff_host[-1], 2), dtype=torch.int32, device=dev)
+        sizes = torch.empty(k, dtype=torch.int64, pin_memory=True)
+        sizes.copy_(nbsizes, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        pairs = torch.empty((k * nq, 2), dtype=torch.int32, device=dev)  # worst case: every offset hits for every row
         koff = torch.empty(k + 1, dtype=torch.int32, device=dev)
         _check(self.lib.pcs_rulebook_fill(_ptr(results), nq, k, _ptr(ws), _ptr(pairs), _ptr(koff),
                                           _stream()), "pcs_rulebook_fill")
-        return KernelMap(pairs, koff, koff_host, nbsizes, ref_coords.shape[0], nq)
+        return KernelMap(pairs, koff, None, nbsizes, ref_coords.shape[0], nq, pending=(sizes, event), hint_key=hint_key)
 
     def tile_rows(self, cin, cout, kmap=None):
         """Output tile height of one conv launch: the library default, or with a kernel map the per-layer pick."""
         if kmap is None:
             return self.lib.pcs_conv_tile_rows(cin, cout)
-        return self.lib.pcs_conv_pick_tile_rows(kmap.n_dst, kmap.num_pairs, kmap.K, cin, cout)
+        return self.lib.pcs_conv_pick_tile_rows(kmap.n_dst, kmap.num_pairs_estimate(), kmap.K, cin, cout)
 
     def _segments(self, kmap, tile_rows):
         seg = kmap._seg.get(tile_rows)
         if seg is None:
             ntiles = (kmap.n_dst + tile_rows - 1) // tile_rows
-            seg = torch.empty(kmap.K * (ntiles + 1), dtype=torch.int32, device=kmap.pairs.device)
-            _check(self.lib.pcs_rulebook_tile_segments(_ptr(kmap.pairs), _ptr(kmap.koff), kmap.K,
+            seg = torch.empty(kmap.K * (ntiles + 1), dtype=torch.int32, device=kmap._pairs_raw.device)
+            _check(self.lib.pcs_rulebook_tile_segments(_ptr(kmap._pairs_raw), _ptr(kmap.koff), kmap.K,
                                                        kmap.n_dst, tile_rows, 1, _ptr(seg), _stream()),
                    "pcs_rulebook_tile_segments")
             kmap._seg[tile_rows] = seg
@@ -403,7 +453,7 @@ class HipBackend:
         seg = self._segments(kmap, t)
         dst = torch.empty((kmap.n_dst, cout), dtype=torch.float32, device=src.device)
         _check(self.lib.pcs_conv_gather_gemm_f32(_ptr(src), src.shape[0], cin, _ptr(weight), k, cout,
-                                                 _ptr(kmap.pairs), 0, _ptr(seg), t, kmap.n_dst,
+                                                 _ptr(kmap._pairs_raw), 0, _ptr(seg), t, kmap.n_dst,
                                                  _ptr(bias) if bias is not None else None, _ptr(dst),
                                                  _stream()), "pcs_conv_gather_gemm_f32")
         return dst

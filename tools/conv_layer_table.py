@@ -34,16 +34,17 @@ def main():
             return out
         return wrapped
 
-    be.conv_gather_gemm = timed("gemm", orig_g, lambda src, w, km, *r, **k: (km.n_dst, km.num_pairs, w.shape[0], w.shape[1], w.shape[2]))
-    be.conv_wgrad = timed("wgrad", orig_w, lambda fa, fb, km, ac: (km.n_dst, km.num_pairs, km.K, fa.shape[1], fb.shape[1]))
+    # the map object is kept and its pair count read after the step (reading it at launch time would wait for the GPU)
+    be.conv_gather_gemm = timed("gemm", orig_g, lambda src, w, km, *r, **k: (km, w.shape[0], w.shape[1], w.shape[2]))
+    be.conv_wgrad = timed("wgrad", orig_w, lambda fa, fb, km, ac: (km, km.K, fa.shape[1], fb.shape[1]))
     for it in range(2):
         rec.clear()
         out = model(fresh(batch))
         out["loss"].backward()
         torch.cuda.synchronize()
     agg = collections.OrderedDict()
-    for kind, shape, e0, e1 in rec:
-        key = (kind,) + shape
+    for kind, (km, k_, ci_, co_), e0, e1 in rec:
+        key = (kind, km.n_dst, km.num_pairs, k_, ci_, co_)
         t = agg.setdefault(key, [0, 0.0])
         t[0] += 1
         t[1] += e0.elapsed_time(e1)
