@@ -401,7 +401,14 @@ class HipBackend:
         query_coords = _dev(query_coords, "coords", torch.int32)
         offsets = _dev(offsets, "offsets", torch.int32)
         dev = ref_coords.device
-        table = self.table_build(self.hash(ref_coords))
+        # the table over one level's coordinates serves its submanifold map, its strided map and the transposed one
+        table = getattr(ref_coords, "_pcs_table", None)
+        if table is None or table.n != ref_coords.shape[0]:
+            table = self.table_build(self.hash(ref_coords))
+            try:
+                ref_coords._pcs_table = table
+            except AttributeError:
+                pass
         nq, k = query_coords.shape[0], offsets.shape[0]
         results = torch.empty((k, max(nq, 1)), dtype=torch.int32, device=dev)
         nbsizes = torch.empty(k, dtype=torch.int64, device=dev)
