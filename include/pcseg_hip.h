@@ -106,6 +106,14 @@ int pcs_devoxelize_fwd_f32(const float *feat, const int32_t *idx8, const float *
 int pcs_devoxelize_bwd_f32(const float *gout, const int32_t *idx8, const float *w8, int64_t n,
                            int64_t m, int32_t c, float *gfeat, void *stream);
 
+/* voxel_to_point map in one pass (R:pcseg/model/segmentor/voxel/minkunet/utils.py:69-105: floor, cat, kernel_hash
+ * over the 8 cell corners, hashquery, calc_ti_weights, two transposes): coords (n, coord_ld >= 4) float = x,y,z,..,batch
+ * in stride-1 voxel units, table = pcs_hashtable_build over the hashes of the level's voxel coordinates ->
+ * idx8 (n,8) int32 (voxel row, -1 absent; corner order of get_kernel_offsets(2, stride)) and w8 (n,8) trilinear
+ * weights, the layout pcs_devoxelize_fwd_f32 reads. */
+int pcs_corner_map_f32(const float *coords, int32_t coord_ld, int64_t n, int32_t stride, const void *table,
+                       int64_t capacity, int32_t *idx8, float *w8, void *stream);
+
 /* K10 without atomics: the same sum as pcs_devoxelize_bwd_f32, as a per-voxel segmented
  * reduction. order (E,) int64 = flat positions i*8+k of the VALID (idx >= 0) entries of idx8,
  * sorted by voxel; rowptr (m+1,) int64 = start of each voxel's run in `order`. Every gfeat row

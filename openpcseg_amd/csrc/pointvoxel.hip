@@ -214,6 +214,51 @@ __global__ void __launch_bounds__(256) ti_weights_kernel(const float *__restrict
   }
 }
 
+// ---- voxel_to_point map in one pass -------------------------------------------------------
+// What R:pcseg/model/segmentor/voxel/minkunet/utils.py:69-105 builds with floor / cat / K2 (8 hashes per point) /
+// hashquery (table rebuilt) / calc_ti_weights (~25 kernels) / two transposes: for every point the rows of the 8
+// corner voxels of its stride-s cell (-1 = absent) and the trilinear weights, already in the (N,8) layout K9 reads.
+// Corner order = get_kernel_offsets(2, s): z fastest. Weights in the reference's fp32 op order (ti_weights_kernel).
+__global__ void __launch_bounds__(256) corner_map_kernel(const float *__restrict__ coords, int ld, int64_t n, int stride,
+                                                         TableView table, int32_t *__restrict__ idx8,
+                                                         float *__restrict__ w8) {
+  const float scale = (float)stride;
+  const float inv_s3 = 1.0f / (scale * scale * scale);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = coords[i * ld + 0], y = coords[i * ld + 1], z = coords[i * ld + 2];
+    const int b = (int)coords[i * ld + ld - 1];
+    const int bx = (int)floorf(x / scale) * stride, by = (int)floorf(y / scale) * stride, bz = (int)floorf(z / scale) * stride;
+    float xf, yf, zf;
+    if (stride != 1) {
+      xf = floorf(x / scale) * scale; yf = floorf(y / scale) * scale; zf = floorf(z / scale) * scale;
+    } else {
+      xf = floorf(x); yf = floorf(y); zf = floorf(z);
+    }
+    const float xc = xf + scale, yc = yf + scale, zc = zf + scale;
+    const float ax[2] = {xc - x, x - xf}, ay[2] = {yc - y, y - yf}, az[2] = {zc - z, z - zf};
+    float wk[8];
+    int id[8];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ix = (k >> 2) & 1, iy = (k >> 1) & 1, iz = k & 1;
+      id[k] = table_lookup(table, fnv60(bx + ix * stride, by + iy * stride, bz + iz * stride, b));
+      float v = (ax[ix] * ay[iy]) * az[iz];
+      if (stride != 1) v *= inv_s3;
+      if (id[k] < 0) v = 0.f;
+      wk[k] = v;
+      sum += v;
+    }
+    const float den = sum + 1e-8f;
+    int4 *io = reinterpret_cast<int4 *>(idx8 + i * 8);
+    float4 *wo = reinterpret_cast<float4 *>(w8 + i * 8);
+    io[0] = make_int4(id[0], id[1], id[2], id[3]);
+    io[1] = make_int4(id[4], id[5], id[6], id[7]);
+    wo[0] = make_float4(wk[0] / den, wk[1] / den, wk[2] / den, wk[3] / den);
+    wo[1] = make_float4(wk[4] / den, wk[5] / den, wk[6] / den, wk[7] / den);
+  }
+}
+
 // ---- K10, contention-free form: per-voxel segmented reduction over a CSR of the (point, corner)
 // entries. entries sorted by voxel: order[e] = flat index i*8+k into idx8/w8; rowptr (m+1).
 // One row of TX lanes per voxel; every gfeat row is written exactly once (no memset, no atomics,
@@ -355,6 +400,19 @@ extern "C" int pcs_ti_weights_f32(const float *coords, int32_t coord_ld, const i
   hipLaunchKernelGGL(ti_weights_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream),
                      coords, coord_ld, idx_query, n, scale, inv_s3, scaled, w);
   return check_launch("pcs_ti_weights");
+}
+
+extern "C" int pcs_corner_map_f32(const float *coords, int32_t coord_ld, int64_t n, int32_t stride, const void *table,
+                                  int64_t capacity, int32_t *idx8, float *w8, void *stream) {
+  if (n < 0 || coord_ld < 4 || stride <= 0 || !table || capacity <= 0 || (capacity & (capacity - 1))) {
+    set_error("pcs_corner_map_f32: bad args");
+    return PCS_EINVAL;
+  }
+  if (n == 0) return PCS_OK;
+  if (!coords || !idx8 || !w8 || !aligned16(idx8) || !aligned16(w8)) { set_error("pcs_corner_map_f32: bad pointers"); return PCS_EINVAL; }
+  hipLaunchKernelGGL(corner_map_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), coords, coord_ld, n,
+                     stride, make_view(table, capacity), idx8, w8);
+  return check_launch("pcs_corner_map_f32");
 }
 
 extern "C" int pcs_devoxelize_bwd_csr_f32(const float *gout, const int64_t *order,

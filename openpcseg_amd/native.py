@@ -32,6 +32,7 @@ SIGNATURES = {
     "pcs_devoxelize_fwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P]),
     "pcs_devoxelize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int64, c_int32, _P, _P]),
     "pcs_devoxelize_bwd_csr_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, _P, _P]),
+    "pcs_corner_map_f32": (c_int32, [_P, c_int32, c_int64, c_int32, _P, c_int64, _P, _P, _P]),
     "pcs_ti_weights_f32": (c_int32, [_P, c_int32, _P, c_int64, c_float, _P, _P]),
     "pcs_downsample_pack": (c_int32, [_P, c_int64, _P, c_int32, _P, c_int32, _P, _P, _P, _P]),
     "pcs_downsample_unpack": (c_int32, [_P, c_int64, _P, _P]),
@@ -353,6 +354,30 @@ class HipBackend:
                                                _stream()), "pcs_devoxelize_bwd_f32")
         return gfeat
 
+    def level_table(self, voxel_coords):
+        """Hash table over one level's voxel coordinates, cached on the coordinate tensor (shared with its kernel maps)."""
+        voxel_coords = _dev(voxel_coords, "coords", torch.int32)
+        table = getattr(voxel_coords, "_pcs_table", None)
+        if table is None or table.n != voxel_coords.shape[0]:
+            table = self.table_build(self.hash(voxel_coords))
+            try:
+                voxel_coords._pcs_table = table
+            except AttributeError:
+                pass
+        return table
+
+    def corner_map(self, point_coords, voxel_coords, stride):
+        """(idx8 (N,8) int32, w8 (N,8) float32) of voxel_to_point in one kernel: rows of the 8 corner voxels of every
+        point's stride-`stride` cell and the trilinear weights (R:.../minkunet/utils.py:69-105)."""
+        pc = _dev(point_coords, "coords", torch.float32)
+        table = self.level_table(voxel_coords)
+        n = pc.shape[0]
+        idx8 = torch.empty((n, 8), dtype=torch.int32, device=pc.device)
+        w8 = torch.empty((n, 8), dtype=torch.float32, device=pc.device)
+        _check(self.lib.pcs_corner_map_f32(_ptr(pc), pc.shape[1], n, int(stride), _ptr(table.storage), table.capacity,
+                                           _ptr(idx8), _ptr(w8), _stream()), "pcs_corner_map_f32")
+        return idx8, w8
+
     def ti_weights(self, coords, idx_query, scale):
         coords = _dev(coords, "coords", torch.float32)
         idx_query = _dev(idx_query, "idx_query", torch.int64)
@@ -401,14 +426,7 @@ class HipBackend:
         query_coords = _dev(query_coords, "coords", torch.int32)
         offsets = _dev(offsets, "offsets", torch.int32)
         dev = ref_coords.device
-        # the table over one level's coordinates serves its submanifold map, its strided map and the transposed one
-        table = getattr(ref_coords, "_pcs_table", None)
-        if table is None or table.n != ref_coords.shape[0]:
-            table = self.table_build(self.hash(ref_coords))
-            try:
-                ref_coords._pcs_table = table
-            except AttributeError:
-                pass
+        table = self.level_table(ref_coords)  # shared by the level's submanifold / strided / transposed maps
         nq, k = query_coords.shape[0], offsets.shape[0]
         results = torch.empty((k, max(nq, 1)), dtype=torch.int32, device=dev)
         nbsizes = torch.empty(k, dtype=torch.int64, device=dev)

@@ -5,9 +5,12 @@ Behaviourally equivalent to R:pcseg/model/segmentor/voxel/minkunet/utils.py:11-1
 reference's own copy runs unmodified on top of `install_as_torchsparse()` as well (tested
 in-container); this copy exists because the reference tree does not travel to the GPU box.
 """
+import os
+
 import torch
 
 from .. import functional as F
+from .. import native
 from ..sparse import PointTensor, SparseTensor, get_kernel_offsets
 
 
@@ -33,11 +36,16 @@ def voxel_to_point(x, z, nearest=False):
     """Trilinear devoxelisation of x at the points of z; maps cached per stride (utils.py:69-105)."""
     s = x.s
     if z.idx_query.get(s) is None or z.weights.get(s) is None:
-        corners = get_kernel_offsets(2, s, 1, device=z.F.device)
-        base = torch.cat([torch.floor(z.C[:, :3] / s[0]).int() * s[0], z.C[:, -1:].int()], dim=1)
-        idx_query = F.sphashquery(F.sphash(base, corners), F.sphash(x.C.to(z.F.device)))
-        weights = F.calc_ti_weights(z.C, idx_query, scale=s[0]).t().contiguous()
-        idx_query = idx_query.t().contiguous()
+        be = native.backend()
+        if hasattr(be, "corner_map") and z.C.is_cuda and not nearest and os.environ.get("PCS_CORNER_MAP", "1") != "0":
+            # the whole map in one kernel: corner hashes, table lookup (the level's cached table), trilinear weights
+            idx_query, weights = be.corner_map(z.C, x.C, s[0])
+        else:
+            corners = get_kernel_offsets(2, s, 1, device=z.F.device)
+            base = torch.cat([torch.floor(z.C[:, :3] / s[0]).int() * s[0], z.C[:, -1:].int()], dim=1)
+            idx_query = F.sphashquery(F.sphash(base, corners), F.sphash(x.C.to(z.F.device)))
+            weights = F.calc_ti_weights(z.C, idx_query, scale=s[0]).t().contiguous()
+            idx_query = idx_query.t().contiguous()
         if nearest:
             weights[:, 1:] = 0.0
             idx_query[:, 1:] = -1

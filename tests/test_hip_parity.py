@@ -433,6 +433,28 @@ def test_fused_batchnorm_matches_torch(hip, c, relu, with_res):
     assert (ye - te).abs().max() <= 2e-5 * te.abs().max()
 
 
+@pytest.mark.parametrize("stride", [1, 2, 8])
+def test_corner_map_equals_the_op_sequence(hip, stride):
+    """pcs_corner_map_f32 == floor / cat / sphash(8 corners) / sphashquery / calc_ti_weights / transposes
+    (R:pcseg/model/segmentor/voxel/minkunet/utils.py:69-105): indices bit-exact, weights to the last bit or two."""
+    from openpcseg_amd import functional as F
+    from openpcseg_amd.sparse import get_kernel_offsets
+    rng = np.random.default_rng(stride)
+    vox = np.unique(np.concatenate([rng.integers(0, 40, size=(20000, 3)) // stride * stride,
+                                    rng.integers(0, 3, size=(20000, 1))], axis=1), axis=0).astype(np.int32)
+    pts = np.concatenate([rng.uniform(-1, 41, size=(50000, 3)), rng.integers(0, 3, size=(50000, 1))], axis=1).astype(np.float32)
+    xc, zc = t(vox), t(pts)
+    idx8, w8 = hip.corner_map(zc, xc, stride)
+    corners = get_kernel_offsets(2, stride, 1, device=DEV)
+    base = torch.cat([torch.floor(zc[:, :3] / stride).int() * stride, zc[:, -1:].int()], dim=1)
+    iq = F.sphashquery(F.sphash(base, corners), F.sphash(xc))
+    w = F.calc_ti_weights(zc, iq, scale=stride).t().contiguous()
+    assert torch.equal(idx8.long(), iq.t().contiguous())
+    assert (w8 - w).abs().max() <= 2e-7
+    assert int((idx8 >= 0).sum()) > 1000  # the case really has hits and misses
+    assert int((idx8 < 0).sum()) > 1000
+
+
 def test_fused_linear_matches_torch(hip):
     """The classifier (480 -> 20 over ~1e5..1e6 rows) on the fused conv kernels == nn.Linear, values and gradients."""
     from openpcseg_amd.fused import FusedLinear
