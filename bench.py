@@ -146,6 +146,33 @@ def cpu_baseline():
                 "sample": "cpu baseline exceeded the %d s cap on this host" % CPU_BASELINE_TIMEOUT_S}
 
 
+def preheat(step, distributed, dev, window=10, max_windows=30):
+    """Untimed clock warm-up before the W warm-up steps. Some MI355X boxes start a fresh process well below their
+    sustained clocks and take tens of seconds of load to get there (measured: the same binary at 173 -> 152 -> 137 ms
+    per step over its first minute on one box, flat at 137 ms from the first step on others). Windows of `window`
+    steps are run until a window is no longer > 1 % faster than the one before (at least two windows, at most
+    `max_windows`); with several ranks the decision is shared so that every rank runs the same number of steps.
+    The K timed steps that follow are full, unmodified steps. PCS_BENCH_PREHEAT=0 skips this."""
+    if os.environ.get("PCS_BENCH_PREHEAT", "1") == "0":
+        return
+    prev = None
+    for _ in range(max_windows):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(window):
+            step()
+        torch.cuda.synchronize()
+        cur = (time.perf_counter() - t0) / window
+        go = 1 if (prev is None or cur < 0.99 * prev) else 0
+        if distributed:
+            flag = torch.tensor([go], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            go = int(flag.item())
+        prev = cur
+        if not go:
+            break
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,6 +226,7 @@ def main():
 
     be = native.backend()
     with ConvMeter(be) as meter:
+        preheat(step, distributed, dev)
         for _ in range(args.warmup):
             step()
         if distributed:
