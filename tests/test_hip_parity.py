@@ -236,6 +236,27 @@ def test_weight_transpose(hip, shape):
     assert torch.equal(hip.transpose_weights(w), w.transpose(1, 2).contiguous())
 
 
+def test_rulebook_sizes_are_deferred(hip, golden):
+    """build_kmap returns without waiting for the per-offset sizes: the forward launches (segment table, fused conv)
+    run off the device-side offsets; koff_host / pairs / num_pairs resolve on first read and match the reference."""
+    from openpcseg_amd import functional as F
+    inc = golden["scene_coords"]
+    entry = F.build_kernel_map(t(inc), t(inc), (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    km = entry.fwd
+    assert not km.resolved and km._pairs_raw.shape[0] == 27 * inc.shape[0]  # worst-case buffer, sizes still in flight
+    x = torch.randn(inc.shape[0], 64, device=DEV)
+    w = torch.randn(27, 64, 64, device=DEV) * 0.05
+    y = hip.conv_gather_gemm(x, w, km)  # launch shape from the estimate, no host read
+    assert not km.resolved
+    nbmaps, nbsizes = golden["kmap_k3s1_nbmaps"], golden["kmap_k3s1_nbsizes"]
+    assert km.num_pairs == int(nbsizes.sum()) and km.resolved
+    assert np.array_equal(entry[0].cpu().numpy(), nbmaps) and km._pairs_raw.shape[0] == km.num_pairs
+    nb0, nb1, sizes = entry  # unpacks like the reference's kmap entry
+    assert nb0 is entry[0] and sizes == (inc.shape[0], inc.shape[0])
+    close(y, orc.conv_fwd(x.cpu().numpy(), w.cpu().numpy(), nbmaps, nbsizes, (inc.shape[0],) * 2), 2e-5)
+    assert km.num_pairs_estimate() == km.num_pairs
+
+
 def test_conv_tile_pick_and_errors(hip, golden):
     lib = hip.lib
     # many waves + few pairs per row (stride 1): 256-row tiles (one 8-wave workgroup per CU, less MFMA padding);
