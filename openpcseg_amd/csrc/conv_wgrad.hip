@@ -399,10 +399,12 @@ __global__ void __launch_bounds__(256, 3) wgrad2_kernel(Wgrad2Args w) {
 }
 
 int wgrad_plan(const int32_t *koff_host, int K, int ca, int cb, int *pch_out) {
-  // ~3072 workgroups in total (each = 4 output blocks of one split), >= 64 pairs per split
+  // workgroup = 4 output blocks of one split; >= 64 pairs per split
   const int nbq = (wg_ngroups(ca) * wg_ngroups(cb) + 3) / 4;
   int64_t P = koff_host[K] - koff_host[0];
-  int64_t target = 3072 / nbq;  // (1536 and 6144 measured within noise)
+  // measured per shape (tools/conv_microbench.py): ~3072 workgroups when an offset's weight block needs >= 4 of them
+  // (256-channel layers), ~1536 otherwise (64..128 channels: +2..16 %; fewer, longer splits = less partial traffic)
+  int64_t target = (nbq >= 4 ? 3072 : 1536) / nbq;
   if (target < K) target = K;
   int pch = (int)ceil_div(P > 0 ? P : 1, target);
   pch = (int)(ceil_div(pch, 32) * 32);
