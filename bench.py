@@ -163,6 +163,8 @@ def preheat(step, distributed, dev, window=10, max_windows=30):
             step()
         torch.cuda.synchronize()
         cur = (time.perf_counter() - t0) / window
+        if os.environ.get("PCS_BENCH_PREHEAT_LOG") == "1":
+            print("preheat window: %.1f ms/step" % (cur * 1e3), file=sys.stderr, flush=True)
         go = 1 if (prev is None or cur < 0.99 * prev) else 0
         if distributed:
             flag = torch.tensor([go], device=dev, dtype=torch.int32)
