@@ -146,17 +146,18 @@ def cpu_baseline():
                 "sample": "cpu baseline exceeded the %d s cap on this host" % CPU_BASELINE_TIMEOUT_S}
 
 
-def preheat(step, distributed, dev, window=10, max_windows=30):
+def preheat(step, distributed, dev, window=10, max_windows=40):
     """Untimed clock warm-up before the W warm-up steps. Some MI355X boxes start a fresh process well below their
     sustained clocks and take tens of seconds of load to get there (measured: the same binary at 173 -> 152 -> 137 ms
-    per step over its first minute on one box, flat at 137 ms from the first step on others). Windows of `window`
-    steps are run until a window is no longer > 1 % faster than the one before (at least two windows, at most
-    `max_windows`); with several ranks the decision is shared so that every rank runs the same number of steps.
+    per step over its first minute on one box -- about 0.5 % per second --, flat at 137 ms from the first step on
+    others). Windows of `window` steps are run until a window is no longer > 0.4 % faster than the one before (at
+    least three windows, at most `max_windows`); with several ranks the decision is shared so that every rank runs the
+    same number of steps.
     The K timed steps that follow are full, unmodified steps. PCS_BENCH_PREHEAT=0 skips this."""
     if os.environ.get("PCS_BENCH_PREHEAT", "1") == "0":
         return
     prev = None
-    for _ in range(max_windows):
+    for wi in range(max_windows):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(window):
@@ -165,7 +166,7 @@ def preheat(step, distributed, dev, window=10, max_windows=30):
         cur = (time.perf_counter() - t0) / window
         if os.environ.get("PCS_BENCH_PREHEAT_LOG") == "1":
             print("preheat window: %.1f ms/step" % (cur * 1e3), file=sys.stderr, flush=True)
-        go = 1 if (prev is None or cur < 0.99 * prev) else 0
+        go = 1 if (wi < 2 or cur < 0.996 * prev) else 0
         if distributed:
             flag = torch.tensor([go], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
