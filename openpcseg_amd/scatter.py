@@ -6,7 +6,6 @@ tree: PARITY UNPINNED -- semantics restated (per-voxel channel-wise max + argmax
 import sys
 import types
 
-import torch
 from torch.autograd import Function
 
 from . import native

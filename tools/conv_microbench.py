@@ -4,7 +4,6 @@ Usage: python tools/conv_microbench.py <level 0..4> <cin> <cout> [reps] [frames]
 level 0 = stride 1 ... level 4 = stride 16 (k3 submanifold map at that level)."""
 import os
 import sys
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
