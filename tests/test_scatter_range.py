@@ -131,3 +131,31 @@ def test_hip_backend_shim_matches_reference_golden(hip, golden):
     q = torch.from_numpy(golden["query_q"]).to(dev)
     r = tb.hash_query_cuda(q, h, torch.arange(h.numel(), device=dev)) - 1
     assert np.array_equal(r.cpu().numpy(), golden["query_out"])
+
+
+def test_scatter_max_result_is_tuple_like(oracle_backend):
+    """torch_scatter.scatter_max returns (out, argmax): the wrapper's result unpacks, indexes and has length 2 like a
+    tuple, and hands out an int64 argmax (materialised from the kernel's int32 one only when read)."""
+    from openpcseg_amd.scatter import ScatterMaxResult, scatter_max
+    src = torch.tensor([[1., 5.], [3., 2.], [0., 9.], [7., 7.]])
+    idx = torch.tensor([1, 1, 3, 1])
+    res = scatter_max(src, idx, dim=0)
+    assert isinstance(res, ScatterMaxResult) and len(res) == 2
+    out, arg = res
+    assert out.tolist() == [[0., 0.], [7., 7.], [0., 0.], [0., 9.]]
+    assert arg.dtype == torch.int64 and arg.tolist() == [[-1, -1], [3, 3], [-1, -1], [2, 2]]
+    assert res[0] is out and res[1] is arg and res[-1] is arg and res[-2] is out
+    assert scatter_max(src, idx, dim=0, dim_size=6)[0].shape == (6, 2)
+    with pytest.raises(AssertionError):
+        scatter_max(src, idx, dim=1)
+
+
+def test_kmap_entry_reads_like_the_reference_list(golden, oracle_backend):
+    """kmaps[key] = [nbmaps, nbsizes, (n_in, n_out)] (TS:torchsparse/nn/functional/conv.py:174-176): index, unpack, len."""
+    from openpcseg_amd import functional as F
+    c = torch.from_numpy(golden["scene_coords"])
+    entry = F.build_kernel_map(c, c, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    assert len(entry) == 3
+    nbmaps, nbsizes, sizes = entry
+    assert np.array_equal(nbmaps.numpy(), golden["kmap_k3s1_nbmaps"]) and np.array_equal(nbsizes.numpy(), golden["kmap_k3s1_nbsizes"])
+    assert sizes == (c.shape[0], c.shape[0]) and entry[0] is nbmaps and entry[-1] == sizes and entry[1] is nbsizes
