@@ -84,6 +84,84 @@ class ConvMeter:
                 "flops_per_launch": round(flops / n), "algorithmic_bytes_per_launch": round(abytes / n)}
 
 
+class ClockSampler:
+    """Shader clock / socket power of the GPU during the timed region, sampled from a host thread (amdsmi, else
+    sysfs hwmon): the fp32-MFMA kernels scale with the sustained clock (boxes of this pool differ by up to 1.4x on
+    them while the HBM-bound kernels agree), so the bench line carries the clock it was measured at."""
+
+    def __init__(self, dev_index, period_s=0.1):
+        import threading
+        self.period, self.samples, self.src = period_s, [], None
+        self._stop = threading.Event()
+        self._read = self._probe(dev_index)
+        self._thr = threading.Thread(target=self._run, daemon=True) if self._read else None
+
+    def _probe(self, dev_index):
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            h = amdsmi.amdsmi_get_processor_handles()[dev_index]
+            ct = getattr(amdsmi.AmdSmiClkType, "GFX", None) or amdsmi.AmdSmiClkType.SYS
+
+            def read():
+                clk = amdsmi.amdsmi_get_clock_info(h, ct).get("clk")
+                pw = amdsmi.amdsmi_get_power_info(h)
+                p = pw.get("current_socket_power")
+                if not isinstance(p, (int, float)):
+                    p = pw.get("average_socket_power")
+                return (float(clk) if isinstance(clk, (int, float)) else None,
+                        float(p) if isinstance(p, (int, float)) else None)
+            read()
+            self.src = "amdsmi"
+            return read
+        except Exception:
+            pass
+        try:
+            import glob
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*/freq1_input"))
+            f = cards[dev_index]
+            pw = os.path.join(os.path.dirname(f), "power1_average")
+
+            def read():
+                clk = float(open(f).read()) / 1e6
+                p = float(open(pw).read()) / 1e6 if os.path.exists(pw) else None
+                return clk, p
+            read()
+            self.src = "sysfs"
+            return read
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append(self._read())
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self._thr:
+            self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._thr:
+            self._thr.join(timeout=2)
+
+    def summary(self):
+        clk = [c for c, _ in self.samples if c]
+        pw = [p for _, p in self.samples if p]
+        if not clk:
+            return {"sclk_mhz_mean": None, "source": self.src, "note": "no clock source readable on this host"}
+        out = {"sclk_mhz_mean": round(sum(clk) / len(clk), 1), "sclk_mhz_min": min(clk), "sclk_mhz_max": max(clk),
+               "samples": len(clk), "source": self.src}
+        if pw:
+            out["socket_power_w_mean"] = round(sum(pw) / len(pw), 1)
+        return out
+
+
 def to_device(batch, dev):
     lidar, tg = batch["lidar"], batch["targets"]
     coords = lidar.C.to(dev)
@@ -236,15 +314,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         meter.enabled = True
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        dt = time.perf_counter() - t0
+        with ClockSampler(dev_index) as clocks:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                loss = step()
+            torch.cuda.synchronize()
+            if distributed:
+                dist.barrier()
+            dt = time.perf_counter() - t0
         meter.enabled = False
         roof = meter.summary()
+        clk = clocks.summary()
+        if roof is not None:
+            roof["clock"] = clk
+            if clk.get("sclk_mhz_mean"):
+                # the nominal peak is quoted at 2400 MHz; what the MFMA pipe could deliver at the clock this box held
+                roof["peak_at_measured_clock"] = round(PEAK_FP32_MFMA_TFLOPS * clk["sclk_mhz_mean"] / 2400.0, 1)
+                roof["frac_at_measured_clock"] = round(roof["achieved"] / roof["peak_at_measured_clock"], 4)
     if distributed:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

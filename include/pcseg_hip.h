@@ -34,7 +34,7 @@ extern "C" {
 #define PCS_ELAUNCH (-3)  /* hipLaunch / hipMemsetAsync failed (pcs_last_error has text) */
 #define PCS_EUNSUPPORTED (-4)
 
-#define PCS_ABI_VERSION 2
+#define PCS_ABI_VERSION 3
 
 int pcs_abi_version(void);
 const char *pcs_last_error(void);
@@ -298,7 +298,7 @@ int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const 
  * semantickitti_voxel.py:112-120) for scans that are already resident in HBM. Contract: voxel =
  * floor(point / voxel_size) evaluated in double like NumPy does, one representative row per voxel =
  * its FIRST occurrence, voxels ordered by ascending ravel hash (row-major index inside the bounding box).
- *   floor: points (n, row_stride >= 3) float32 (is_float = 1) or int32 (0); voxel_size3 = 3 HOST doubles;
+ *   floor: points (n, row_stride >= 3) float32 (is_float = 1), float64 (2) or int32 (0); voxel_size3 = 3 HOST doubles;
  *          coords (n,3) int32 out; bbox = 6 DEVICE int32 {min xyz, max xyz}, preset by the caller to
  *          {INT32_MAX x3, INT32_MIN x3}.
  *   keys:  keys[i] = ((x - xmin) * ey + (y - ymin)) * ez + (z - zmin), int64.
@@ -313,6 +313,32 @@ int pcs_quantize_keys(const int32_t *coords, int64_t n, const int32_t *bbox, int
 int pcs_quantize_flags(const int64_t *sorted_keys, int64_t n, int32_t *flags, void *stream);
 int pcs_quantize_emit(const int32_t *flags, const int64_t *rank, const int64_t *perm, const int32_t *coords,
                       int64_t n, int32_t *vox, int64_t *index, int64_t *inverse, void *stream);
+
+/* ---- Cylinder3D front-end on the device -------------------------------
+ * Replaces, for scans already resident in HBM, the per-frame NumPy work of
+ * R:pcseg/data/dataset/semantickitti/semantickitti_cylinder.py (cart2polar :19-22, cylindrical partition
+ * :144-160, voxelize_with_label :31-45) and the eval-time voxel -> point mapping of
+ * R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:441-453.
+ *   partition : points (n, row_stride >= 3) float32 [x, y, z, extras...]; space_min3 / space_max3 = 3 HOST doubles
+ *               (CYLINDER_SPACE_MIN / _MAX: rho, phi in degrees, z), grid3 = 3 HOST ints (CYLINDER_GRID_SIZE).
+ *               polar (n,3) float32 [rho, phi_deg, z] (may be NULL); coord (n,3) int32 cell indices
+ *               = floor((clip(polar, min, max) - min) / ((max - min) / (grid - 1))) in float64 like NumPy;
+ *               feat (n, 8 + row_stride - 3) float32 = [cell centre (3), polar (3), x, y, extras] (may be NULL).
+ *   label vote: voxel_labels[v] = first arg-max over classes of #{points i: inverse[i] == v, labels[i] == class},
+ *               labels equal to ignore_label (67 in the reference) are not counted; counter_ws = m * num_classes
+ *               int32 (zeroed inside); bad_flag = 1 DEVICE int32, set to 1 if a counted label is outside
+ *               [0, num_classes) (the reference raises IndexError there).
+ *   argmax    : out[i] = first arg-max of logits[inverse ? inverse[i] : i] (m rows of c floats), -1 for an
+ *               out-of-range row: `out[cur_inv].argmax(1)` of the reference without the (n, c) intermediate.
+ */
+int pcs_cylinder_partition_f32(const float *points, int64_t n, int32_t row_stride, const double *space_min3,
+                               const double *space_max3, const int32_t *grid3, float *polar, int32_t *coord,
+                               float *feat, void *stream);
+int pcs_voxel_label_vote(const int64_t *inverse, const int64_t *labels, int64_t n, int64_t m, int32_t num_classes,
+                         int64_t ignore_label, int32_t *counter_ws, int32_t *bad_flag, int64_t *voxel_labels,
+                         void *stream);
+int pcs_rows_argmax_gather_f32(const float *logits, int64_t m, int32_t c, const int64_t *inverse, int64_t n,
+                               int64_t *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) quantize_emit_kernel(const int32_t *__res
 
 extern "C" int pcs_quantize_floor(const void *points, int32_t is_float, int64_t n, int32_t row_stride,
                                   const double *voxel_size3, int32_t *coords, int32_t *bbox, void *stream) {
-  if (n < 0 || row_stride < 3 || !voxel_size3 || !(voxel_size3[0] > 0) || !(voxel_size3[1] > 0) || !(voxel_size3[2] > 0)) {
+  if (n < 0 || row_stride < 3 || is_float < 0 || is_float > 2 || !voxel_size3 || !(voxel_size3[0] > 0) || !(voxel_size3[1] > 0) || !(voxel_size3[2] > 0)) {
     set_error("pcs_quantize_floor: bad args");
     return PCS_EINVAL;
   }
@@ -92,7 +92,10 @@ extern "C" int pcs_quantize_floor(const void *points, int32_t is_float, int64_t 
   if (!points || !coords || !bbox) { set_error("pcs_quantize_floor: null pointer"); return PCS_EINVAL; }
   hipStream_t st = as_stream(stream);
   const int g = stream_grid(n, 256);
-  if (is_float)
+  if (is_float == 2)
+    hipLaunchKernelGGL(quantize_floor_kernel<double>, dim3(g), dim3(256), 0, st, reinterpret_cast<const double *>(points), n,
+                       row_stride, voxel_size3[0], voxel_size3[1], voxel_size3[2], coords, bbox);
+  else if (is_float)
     hipLaunchKernelGGL(quantize_floor_kernel<float>, dim3(g), dim3(256), 0, st, reinterpret_cast<const float *>(points), n,
                        row_stride, voxel_size3[0], voxel_size3[1], voxel_size3[2], coords, bbox);
   else

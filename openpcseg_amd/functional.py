@@ -200,7 +200,7 @@ class _SparseConv(Function):
 
 def _identity_map(n, device, cache):
     """K = 1 map (i, i): lets the split-reduction wgrad kernel compute x^T @ dy of a 1x1x1 convolution."""
-    key = ("_pcs_identity", n)
+    key = ("_pcs_identity", n, str(device))
     km = cache.get(key)
     if km is None:
         idx = torch.arange(n, dtype=torch.int32, device=device)

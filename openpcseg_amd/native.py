@@ -65,9 +65,12 @@ SIGNATURES = {
     "pcs_quantize_keys": (c_int32, [_P, c_int64, _P, _P, _P]),
     "pcs_quantize_flags": (c_int32, [_P, c_int64, _P, _P]),
     "pcs_quantize_emit": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "pcs_cylinder_partition_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "pcs_voxel_label_vote": (c_int32, [_P, _P, c_int64, c_int64, c_int32, c_int64, _P, _P, _P, _P]),
+    "pcs_rows_argmax_gather_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
 }
 
-ABI_VERSION = 2  # include/pcseg_hip.h PCS_ABI_VERSION (2: ReLU bit-mask arguments of the BN entries, int32 argmax)
+ABI_VERSION = 3  # include/pcseg_hip.h PCS_ABI_VERSION (3: cylinder front-end entries, float64 quantize input)
 _lib = None
 
 
@@ -132,6 +135,27 @@ def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _cache_key(t):
+    """Identity of a tensor's CONTENT for the caches hung on caller tensors: storage address, shape and the in-place
+    version counter. An in-place update (`copy_`, `+=`, index assignment) bumps `_version`, so a static input buffer
+    refilled between steps never sees a stale table / CSR (the reference recomputes hash, query and sort on every
+    call and has no such hazard)."""
+    return (t.data_ptr(), tuple(t.shape), t._version)
+
+
+def _cached(holder, name, key, make):
+    """holder.<name> = (key, value) memo; rebuilt when the key differs. Tensors that refuse attributes just recompute."""
+    hit = getattr(holder, name, None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    value = make()
+    try:
+        setattr(holder, name, (key, value))
+    except AttributeError:
+        pass
+    return value
+
+
 class HashTable:
     """Device open-addressing table over a vector of 60-bit hashes (value = position)."""
 
@@ -174,7 +198,9 @@ class KernelMap:
             for v in sizes.tolist():
                 ko.append(ko[-1] + int(v))
             self._koff_host, self._pending = ko, None
-            self._pairs_raw = self._pairs_raw[:ko[-1]]  # exact-size view of the worst-case buffer
+            # exact-size copy: the worst-case buffer (K * n_dst rows, ~5x the pairs of a stride-1 map) is released
+            # instead of living through backward behind a view; segment tables built from it stay valid (same rows)
+            self._pairs_raw = self._pairs_raw[:ko[-1]].clone()
             if self.hint_key is not None and self.n_dst > 0:
                 _PPR_HINT[self.hint_key] = ko[-1] / float(self.n_dst)
         return self._koff_host
@@ -287,11 +313,7 @@ class HipBackend:
         c = feats.shape[1]
         m = counts.shape[0]
         holder = cache_on if cache_on is not None else idx
-        csr = getattr(holder, "_pcs_vox_csr", None)
-        if csr is None or csr[2] != m or csr[3] != idx.shape[0]:
-            order, rowptr = self._csr(idx, m)
-            csr = (order, rowptr, m, idx.shape[0])
-            holder._pcs_vox_csr = csr
+        csr = _cached(holder, "_pcs_vox_csr", _cache_key(holder) + (m, idx.shape[0]), lambda: self._csr(idx, m))
         out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
         _check(self.lib.pcs_voxelize_fwd_csr_f32(_ptr(feats), _ptr(csr[0]), _ptr(csr[1]), _ptr(counts), m, c,
                                                  _ptr(out), _stream()), "pcs_voxelize_fwd_csr_f32")
@@ -333,13 +355,7 @@ class HipBackend:
         same map serves every backward of one forward), then a segmented reduction."""
         gout = _dev(gout, "grad_output", torch.float32)
         n, c = gout.shape
-        csr = getattr(idx8, "_pcs_csr", None)
-        if csr is None or csr[2] != m:
-            flat = idx8.reshape(-1)
-            vals, order = torch.sort(flat)
-            rowptr = torch.searchsorted(vals, torch.arange(m + 1, device=flat.device, dtype=vals.dtype))
-            csr = (order.contiguous(), rowptr.contiguous(), m)
-            idx8._pcs_csr = csr
+        csr = _cached(idx8, "_pcs_csr", _cache_key(idx8) + (m,), lambda: self._csr(idx8, m))
         gfeat = torch.empty((m, c), dtype=torch.float32, device=gout.device)
         _check(self.lib.pcs_devoxelize_bwd_csr_f32(_ptr(gout), _ptr(csr[0]), _ptr(csr[1]), _ptr(w8), m, c,
                                                    _ptr(gfeat), _stream()), "pcs_devoxelize_bwd_csr_f32")
@@ -357,14 +373,8 @@ class HipBackend:
     def level_table(self, voxel_coords):
         """Hash table over one level's voxel coordinates, cached on the coordinate tensor (shared with its kernel maps)."""
         voxel_coords = _dev(voxel_coords, "coords", torch.int32)
-        table = getattr(voxel_coords, "_pcs_table", None)
-        if table is None or table.n != voxel_coords.shape[0]:
-            table = self.table_build(self.hash(voxel_coords))
-            try:
-                voxel_coords._pcs_table = table
-            except AttributeError:
-                pass
-        return table
+        return _cached(voxel_coords, "_pcs_table", _cache_key(voxel_coords),
+                       lambda: self.table_build(self.hash(voxel_coords)))
 
     def corner_map(self, point_coords, voxel_coords, stride):
         """(idx8 (N,8) int32, w8 (N,8) float32) of voxel_to_point in one kernel: rows of the 8 corner voxels of every
@@ -516,11 +526,8 @@ class HipBackend:
         src = _dev(src, "src", torch.float32)
         index = _dev(index, "index", torch.int64)
         c = src.shape[1]
-        csr = getattr(index, "_pcs_csr", None)  # the cylinder models scatter several tensors over one index
-        if csr is None or csr[2] != m:
-            csr = self._csr(index, m) + (m,)
-            index._pcs_csr = csr
-        order, rowptr = csr[0], csr[1]
+        # the cylinder models scatter several tensors over one index
+        order, rowptr = _cached(index, "_pcs_csr", _cache_key(index) + (m,), lambda: self._csr(index, m))
         out = torch.empty((m, c), dtype=torch.float32, device=src.device)
         arg = torch.empty((m, c), dtype=torch.int32, device=src.device)
         _check(self.lib.pcs_scatter_max_fwd_f32(_ptr(src), _ptr(order), _ptr(rowptr), m, c, _ptr(out), _ptr(arg),
@@ -543,15 +550,12 @@ class HipBackend:
 
     def _pixel_csr(self, pxpy, b, h, w):
         """Points sorted by pixel (out-of-image points first) + row pointers over the B*H*W pixels; cached on pxpy."""
-        csr = getattr(pxpy, "_pcs_px_csr", None)
-        if csr is None or csr[2] != (b, h, w):
+        def make():
             pb, px, py = pxpy[:, 0].long(), pxpy[:, 1].long(), pxpy[:, 2].long()
             ok = (pb >= 0) & (pb < b) & (px >= 0) & (px < w) & (py >= 0) & (py < h)
             key = torch.where(ok, (pb * h + py) * w + px, torch.full_like(pb, -1))
-            order, rowptr = self._csr(key, b * h * w)
-            csr = (order, rowptr, (b, h, w))
-            pxpy._pcs_px_csr = csr
-        return csr
+            return self._csr(key, b * h * w)
+        return _cached(pxpy, "_pcs_px_csr", _cache_key(pxpy) + (b, h, w), make)
 
     def denselize_fwd(self, feat, count_map, pxpy):
         """out[b, :, py, px] = mean of the feature rows of the points of pixel (b, py, px). C % 4 == 0: segmented over
@@ -667,16 +671,22 @@ class HipBackend:
         """points (n, >=3) float32 / int32 on the device -> (vox (m,3) int32, index (m) int64 | None,
         inverse (n) int64 | None); reference order and representative (TS:torchsparse/utils/quantize.py:24-46)."""
         points = _dev(points, "coords")
-        if points.dtype not in (torch.float32, torch.int32):
+        if points.dim() != 2 or points.shape[1] != 3:
+            # the reference divides (n, d) by a 3-vector (quantize.py:33): NumPy broadcasting admits d == 3 only
+            raise ValueError("sparse_quantize: coords must be (n, 3), got %s" % (tuple(points.shape),))
+        if points.dtype not in (torch.float32, torch.float64, torch.int32):
+            # half / bfloat16 -> float32 (exact); other integer types -> int32. float64 stays float64: NumPy divides
+            # float64 by float64, and a float32 round trip moves points that sit near a voxel face
             points = points.float() if points.is_floating_point() else points.int()
         points = points.contiguous()
+        kind = 2 if points.dtype == torch.float64 else int(points.is_floating_point())
         n, stride = points.shape
         dev = points.device
         vox_size = (c_double * 3)(*[float(v) for v in voxel_size3])
         coords = torch.empty((n, 3), dtype=torch.int32, device=dev)
         i32 = torch.iinfo(torch.int32)
         bbox = _h2d([i32.max] * 3 + [i32.min] * 3, torch.int32, dev)
-        _check(self.lib.pcs_quantize_floor(_ptr(points), int(points.is_floating_point()), n, stride, vox_size,
+        _check(self.lib.pcs_quantize_floor(_ptr(points), kind, n, stride, vox_size,
                                            _ptr(coords), _ptr(bbox), _stream()), "pcs_quantize_floor")
         keys = torch.empty(n, dtype=torch.int64, device=dev)
         _check(self.lib.pcs_quantize_keys(_ptr(coords), n, _ptr(bbox), _ptr(keys), _stream()), "pcs_quantize_keys")
@@ -692,6 +702,49 @@ class HipBackend:
                                           _ptr(index) if want_index else None,
                                           _ptr(inverse) if want_inverse else None, _stream()), "pcs_quantize_emit")
         return vox, index, inverse
+
+
+    # -- cylinder front-end ------------------------------------------------------------------------------
+    def cylinder_partition(self, points, space_min, space_max, grid_size, want_polar=True, want_feat=True):
+        """points (n, >=3) float32 -> (polar (n,3) f32 | None, coord (n,3) int32, feat (n, 8 + extras) f32 | None)."""
+        points = _dev(points, "points", torch.float32)
+        n, stride = points.shape
+        lo = (c_double * 3)(*[float(v) for v in space_min])
+        hi = (c_double * 3)(*[float(v) for v in space_max])
+        grid = (c_int32 * 3)(*[int(v) for v in grid_size])
+        dev = points.device
+        polar = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_polar else None
+        coord = torch.empty((n, 3), dtype=torch.int32, device=dev)
+        feat = torch.empty((n, 8 + stride - 3), dtype=torch.float32, device=dev) if want_feat else None
+        _check(self.lib.pcs_cylinder_partition_f32(_ptr(points), n, stride, lo, hi, grid,
+                                                   _ptr(polar) if want_polar else None, _ptr(coord),
+                                                   _ptr(feat) if want_feat else None, _stream()),
+               "pcs_cylinder_partition_f32")
+        return polar, coord, feat
+
+    def voxel_label_vote(self, inverse, labels, m, num_classes, ignore_label):
+        """-> (voxel_labels (m,) int64, bad (1,) int32 device flag: a counted label was out of range)."""
+        inverse = _dev(inverse, "inverse_map", torch.int64)
+        labels = _dev(labels, "point_labels", torch.int64)
+        dev = inverse.device
+        ws = torch.empty(max(int(m) * int(num_classes), 1), dtype=torch.int32, device=dev)
+        bad = torch.empty(1, dtype=torch.int32, device=dev)
+        out = torch.empty(int(m), dtype=torch.int64, device=dev)
+        _check(self.lib.pcs_voxel_label_vote(_ptr(inverse), _ptr(labels), inverse.numel(), int(m), int(num_classes),
+                                             int(ignore_label), _ptr(ws), _ptr(bad), _ptr(out), _stream()),
+               "pcs_voxel_label_vote")
+        return out, bad
+
+    def rows_argmax_gather(self, logits, inverse=None):
+        logits = _dev(logits, "logits", torch.float32)
+        m, c = logits.shape
+        if inverse is not None:
+            inverse = _dev(inverse, "inverse_map", torch.int64)
+        n = inverse.numel() if inverse is not None else m
+        out = torch.empty(n, dtype=torch.int64, device=logits.device)
+        _check(self.lib.pcs_rows_argmax_gather_f32(_ptr(logits), m, c, _ptr(inverse) if inverse is not None else None,
+                                                   n, _ptr(out), _stream()), "pcs_rows_argmax_gather_f32")
+        return out
 
 
 _BACKEND = None

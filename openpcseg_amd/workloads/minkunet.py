@@ -94,8 +94,6 @@ class MinkUNet(nn.Module):
         self.in_dim, self.pres, self.vres = in_dim, pres, vres
         self.stem = nn.Sequential(spnn.Conv3d(in_dim, cs[0], kernel_size=3), _norm(cs[0], dist), spnn.ReLU(True),
                                   spnn.Conv3d(cs[0], cs[0], kernel_size=3), _norm(cs[0], dist), spnn.ReLU(True))
-        self._stem = lambda x: _bn_act(self.stem[4], self.stem[3](_bn_act(self.stem[1], self.stem[0](x), act=self.stem[2])),
-                                       act=self.stem[5])
         enc_in = [cs[0], cs[1], cs[2], cs[3]]
         for i in range(4):
             setattr(self, "stage%d" % (i + 1), nn.Sequential(
@@ -111,6 +109,10 @@ class MinkUNet(nn.Module):
         self.classifier = nn.Sequential((FusedLinear if FUSED else nn.Linear)(cs[4] + cs[6] + cs[8], num_class))
         self.dropout = nn.Dropout(dropout, True)
         self.criterion = SegLoss(ignore_index=ignore_label, label_smoothing=label_smoothing)
+
+    def _stem(self, x):
+        h = _bn_act(self.stem[1], self.stem[0](x), act=self.stem[2])
+        return _bn_act(self.stem[4], self.stem[3](h), act=self.stem[5])
 
     def point_logits(self, x):
         """x: SparseTensor (feats (N,>=in_dim), coords (N,4) int) -> per-point logits (N, num_class)."""

@@ -10,7 +10,7 @@ Needs /root/reference (so it cannot run on the GPU box; the .npz files are commi
 Known reference CPU-twin defects are worked around WITHOUT changing semantics:
   - kernel_hash_cpu uses row 0's batch index for every row (hash_cpu.cpp:29): called per batch;
   - devoxelize_backward_cpu is wrong (devoxelize_cpu.cpp:51-53): not used for goldens.
-Usage: python tests/golden/make_golden.py [models | quantize]
+Usage: python tests/golden/make_golden.py [models | quantize | config2 | cylinder]
 """
 import os
 import sys
@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 OUT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(OUT))
+sys.path.insert(0, OUT)
 from seeded import seeded_state  # noqa: E402
 
 
@@ -190,7 +191,12 @@ def import_reference_minkunet():
     ed = types.ModuleType("easydict")
     ed.EasyDict = _AttrDict
     sys.modules.setdefault("easydict", ed)
-    sys.path.insert(0, "/root/reference")
+    from stage_reference import reference_root
+    root = reference_root()
+    if root is None:
+        raise RuntimeError("neither /root/reference nor the staged tests/_refsrc is present")
+    if root not in sys.path:
+        sys.path.insert(0, root)
     import importlib
     return importlib.import_module("pcseg.model.segmentor.voxel.minkunet.minkunet")
 
@@ -412,8 +418,96 @@ def main_quantize():
     print("wrote quantize_golden.npz:", {k: v.shape for k, v in g.items() if k.endswith("_vox")})
 
 
+CONFIG2_ROW_STEP = 16  # rows of the full-frame logits kept in the fixture (every 16th voxel row)
+
+
+def main_config2():
+    """BASELINE config 2 at full size: the reference's MinkUNet-18 cr1.0 (PLANES x 1.0, NUM_LAYER [2]*8), fp32, ONE full
+    synthetic frame (seed 0, 120 000 rays, 0.05 m voxels), train mode (batch statistics), forward + loss on the
+    reference's torchsparse + its compiled CPU backend. The input is regenerated from the seed by the tests
+    (openpcseg_amd.workloads.synthetic), so the fixture keeps its checksum, every 16th row of the logits, float64
+    column sums of all rows, and the loss."""
+    import_reference_torchsparse()
+    from openpcseg_amd.workloads.synthetic import make_batch
+    mod = import_reference_minkunet()
+    cfg = _AttrDict(NAME="MinkUNet", IGNORE_LABEL=0, IN_FEATURE_DIM=4, BLOCK="ResBlock", NUM_LAYER=[2] * 8,
+                    PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96], cr=1.0, DROPOUT_P=0.0, LABEL_SMOOTHING=0.1,
+                    IF_DIST=False)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    model = mod.MinkUNet(cfg, 20)
+    seeded_state(model)
+    model.train()
+    batch = make_batch([0])
+    feats, coords = batch["lidar"].feats.clone(), batch["lidar"].coords.clone()
+    cap = {}
+    model.classifier.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", o.detach().clone()))
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import time
+    t0 = time.time()
+    try:
+        ret, _, _ = model(batch)
+    finally:
+        torch.Tensor.cuda = orig
+    print("reference forward: %.1f s" % (time.time() - t0))
+    logits = cap["logits"].numpy()
+    g = {"n_voxels": np.array(coords.shape[0]),
+         "coords_crc": np.array(zlib.crc32(coords.numpy().tobytes())),
+         "feats_crc": np.array(zlib.crc32(feats.numpy().tobytes())),
+         "labels_crc": np.array(zlib.crc32(batch["targets"].feats.numpy().tobytes())),
+         "row_step": np.array(CONFIG2_ROW_STEP),
+         "logits_rows": logits[::CONFIG2_ROW_STEP].copy(),
+         "logits_colsum": logits.astype(np.float64).sum(0),
+         "logits_abssum": np.abs(logits.astype(np.float64)).sum(0),
+         "loss": np.array(float(ret["loss"].detach()))}
+    np.savez_compressed(os.path.join(OUT, "config2_golden.npz"), **g)
+    print("wrote config2_golden.npz: voxels", coords.shape[0], "rows kept", g["logits_rows"].shape, "loss", g["loss"])
+
+
+def main_cylinder():
+    """Cylinder front-end: the reference's OWN dataset transform
+    (R:pcseg/data/dataset/semantickitti/semantickitti_cylinder.py:19-45 cart2polar / voxelize_with_label and
+    :144-173 get_single_sample, inference branch = no augmentation) run on synthetic scans with the shipped
+    cy480 configuration (R:tools/cfgs/voxel/semantic_kitti/cylinder_cy480_cr10.yaml:7-9) and a reduced grid.
+    The class is instantiated without its __init__ (which wants the dataset on disk); `np.int`, removed from
+    NumPy >= 1.24 and still used by the reference (:158,:170-175), is aliased to `int` for the run."""
+    import_reference_torchsparse()
+    import_reference_minkunet()  # import stubs + sys.path for the reference tree
+    import importlib
+    if not hasattr(np, "int"):
+        np.int = int
+    mod = importlib.import_module("pcseg.data.dataset.semantickitti.semantickitti_cylinder")
+    from openpcseg_amd.workloads.synthetic import make_scan
+    g = {}
+    cases = {"cy480": (6, 20000, [0, -180, -4], [50, 180, 2], [480, 360, 32]),
+             "small": (7, 5000, [0, -180, -4], [50, 180, 2], [120, 90, 16]),
+             "clip": (8, 4000, [2, -90, -2], [30, 120, 1], [64, 48, 8])}   # points outside the cylinder are clipped
+    for name, (seed, n, lo, hi, grid) in cases.items():
+        pts = make_scan(seed, n).astype(np.float32)
+        rng = np.random.default_rng(seed + 100)
+        labels = rng.integers(0, 20, size=n).astype(np.int64)
+        labels[rng.random(n) < 0.05] = 67   # the "don't count" label of voxelize_with_label (:36)
+        ds = object.__new__(mod.SemkittiCylinderDataset)
+        ds.training, ds.if_tta = False, False
+        ds.class_names = ["c%d" % i for i in range(20)]
+        ds.cylinder_space_max, ds.cylinder_space_min, ds.grid_size = np.array(hi), np.array(lo), np.array(grid)
+        ds.point_cloud_dataset = [{"labels": labels.copy(), "xyzret": pts.copy(), "path": name}]
+        ret = ds.get_single_sample(0)
+        g[name + "_points"], g[name + "_labels"] = pts, labels
+        g[name + "_cfg"] = np.array([lo, hi, grid], dtype=np.int64)
+        for k in ("point_feature", "point_coord", "voxel_feature", "voxel_coord", "voxel_label", "inverse_map"):
+            g[name + "_" + k] = ret[k]
+    np.savez_compressed(os.path.join(OUT, "cylinder_golden.npz"), **g)
+    print("wrote cylinder_golden.npz:", {k: v.shape for k, v in g.items() if k.endswith("voxel_coord")})
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "models":
+    if len(sys.argv) > 1 and sys.argv[1] == "cylinder":
+        main_cylinder()
+    elif len(sys.argv) > 1 and sys.argv[1] == "config2":
+        main_config2()
+    elif len(sys.argv) > 1 and sys.argv[1] == "models":
         main_models()
     elif len(sys.argv) > 1 and sys.argv[1] == "quantize":
         main_quantize()

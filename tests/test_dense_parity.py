@@ -1,0 +1,163 @@
+"""Parity of the hot kernels at BASELINE density (-m gpu): the resolution levels of FULL 120k-point scans.
+
+The op-level cases of test_hip_parity.py run on a 3k-voxel scene with 1.5 pairs per output row, where an offset rarely
+has two 16-row blocks in a tile. Here the maps are the ones bench.py times: two synthetic frames (seeds 0, 1) at
+0.05 m, levels at tensor strides 1..8 with 4..8.8 pairs per row, so the row-block groups (R = 2), the multi-wave
+ticket queue, the 8-wave / 384-row configuration and the 64-column tiles of conv_os5_kernel and the split-reduction
+wgrad2_kernel all carry real work -- and every result is compared with the scalar oracle
+(oracle/pcs_oracle.c::orc_conv_fwd / orc_conv_bwd <- TS:torchsparse/backend/convolution/convolution_cpu.cpp:38-183).
+Rulebooks are compared bit-exactly, order included, on the full frame and on the 12-frame batch of the bench
+(oracle.build_kmap <- TS:torchsparse/nn/functional/conv.py:156-176).
+Tolerance for fp32: 2e-5 of the tensor maximum (MFMA vs scalar summation order), as in test_hip_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def close(a, b, rtol):
+    a = a.detach().cpu().numpy().astype(np.float64) if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-6)
+    assert err <= rtol, err
+
+
+def scan_levels(seeds):
+    """{tensor stride: (N,4) int32 coords} of a batch of full scans, built by the ORACLE: stride 1 in ascending-hash
+    order (what initial_voxelize hands to the first conv, R:.../minkunet/utils.py:11-36), coarser levels in the
+    lexicographic order spdownsample produces (TS:.../functional/downsample.py:47-51)."""
+    from openpcseg_amd.workloads.synthetic import make_batch
+    c = make_batch(list(seeds))["lidar"].C.numpy()
+    h = orc.sphash(c)
+    lv = {1: np.ascontiguousarray(c[np.argsort(h, kind="stable")])}
+    for s in (1, 2, 4):
+        lv[2 * s] = orc.spdownsample(lv[s], 2, 2, s)
+    return lv
+
+
+@pytest.fixture(scope="module")
+def levels():
+    return scan_levels([0, 1])
+
+
+_MAPS = {}
+
+
+def level_map(levels, stride):
+    """(HIP KmapEntry, oracle nbmaps, nbsizes, n) of the k = 3 submanifold map of one level; the HIP rulebook is
+    asserted bit-equal to the oracle's, order included, before it is used."""
+    if stride not in _MAPS:
+        from openpcseg_amd import functional as F
+        c = levels[stride]
+        dc = t(c)
+        entry = F.build_kernel_map(dc, dc, (3, 3, 3), (stride,) * 3, (1, 1, 1))
+        nbmaps, nbsizes = orc.build_kmap(c, c, 3, stride)
+        assert np.array_equal(entry[1].cpu().numpy(), nbsizes)
+        assert np.array_equal(entry[0].cpu().numpy().astype(np.int64), nbmaps)
+        _MAPS[stride] = (entry, nbmaps, nbsizes, c.shape[0])
+    return _MAPS[stride]
+
+
+def test_levels_have_baseline_density(levels):
+    """P/N = 3.95 / 5.72 / 8.55 / 8.83 at strides 1 / 2 / 4 / 8 (one frame; two here)."""
+    n = {s: levels[s].shape[0] for s in levels}
+    assert n[1] > 180000 and n[4] > 50000 and n[8] > 17000
+    for s, lo in ((1, 3.5), (2, 5.0), (4, 7.5), (8, 7.5)):
+        nbsizes = orc.build_kmap(levels[s], levels[s], 3, s)[1]
+        assert nbsizes.sum() / n[s] > lo, (s, nbsizes.sum() / n[s])
+
+
+# stride, cin, cout, forced tile height (None = the per-layer pick of pcs_conv_pick_tile_rows)
+FWD_CASES = [
+    (4, 128, 128, None), (4, 128, 128, 112), (4, 128, 128, 256), (4, 128, 128, 288),
+    (4, 192, 128, None), (4, 192, 128, 128), (4, 256, 128, 224),
+    (8, 256, 256, None), (8, 256, 256, 128), (8, 256, 256, 224), (8, 256, 256, 288),
+    (8, 384, 256, None), (8, 384, 256, 256),
+    (2, 64, 64, None), (2, 128, 64, 256),
+    (1, 96, 96, 384), (1, 128, 96, None), (1, 96, 96, 128),
+]
+
+
+@pytest.mark.parametrize("stride,cin,cout,tile", FWD_CASES)
+def test_conv_forward_dense_map(hip, levels, stride, cin, cout, tile):
+    """conv_os5_kernel forward on a BASELINE-density map vs the oracle; the same launch twice is bit-identical."""
+    entry, nbmaps, nbsizes, n = level_map(levels, stride)
+    rng = np.random.default_rng(stride * 100000 + cin * 100 + cout)
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    w = (rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32)
+    dx, dw = t(x), t(w)
+    y = hip.conv_gather_gemm(dx, dw, entry.fwd, tile_rows=tile)
+    close(y, orc.conv_fwd(x, w, nbmaps, nbsizes, (n, n)), 2e-5)
+    assert torch.equal(y, hip.conv_gather_gemm(dx, dw, entry.fwd, tile_rows=tile))
+
+
+@pytest.mark.parametrize("stride,cin,cout", [(4, 128, 128), (4, 192, 128), (8, 256, 256), (8, 384, 256), (1, 128, 96)])
+def test_conv_backward_dense_map(hip, levels, stride, cin, cout):
+    """dgrad (conv_os5_kernel on the input-sorted map, transposed weights) and wgrad (wgrad2_kernel + split reduction)
+    vs orc_conv_bwd on a BASELINE-density map."""
+    entry, nbmaps, nbsizes, n = level_map(levels, stride)
+    rng = np.random.default_rng(stride * 100000 + cin * 100 + cout + 1)
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    gy = rng.normal(size=(n, cout)).astype(np.float32)
+    w = (rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32)
+    ogx, ogw = orc.conv_bwd(x, gy, w, nbmaps, nbsizes)
+    gx = hip.conv_gather_gemm(t(gy), hip.transpose_weights(t(w)), entry.rev)
+    close(gx, ogx, 2e-5)
+    gw = hip.conv_wgrad(t(x), t(gy), entry.fwd, 0)
+    close(gw, ogw, 2e-5)
+    assert torch.equal(gw, hip.conv_wgrad(t(x), t(gy), entry.fwd, 0))
+
+
+def test_strided_maps_full_frame_bit_exact(hip, levels):
+    """k2 s2 down-conv maps (and the coordinates spdownsample emits) between the levels of the full scans, bit-exact
+    incl. order; plus one strided + one transposed conv over them vs the oracle."""
+    from openpcseg_amd import functional as F
+    for s in (1, 2, 4):
+        cin_c, cout_c = levels[s], levels[2 * s]
+        out = hip.downsample(t(cin_c), [2 * s] * 3)
+        assert np.array_equal(out.cpu().numpy(), cout_c)
+        entry = F.build_kernel_map(t(cin_c), out, (2, 2, 2), (s,) * 3, (1, 1, 1))
+        nbmaps, nbsizes = orc.build_kmap(cin_c, cout_c, 2, s)
+        assert np.array_equal(entry[1].cpu().numpy(), nbsizes)
+        assert np.array_equal(entry[0].cpu().numpy().astype(np.int64), nbmaps)
+    # stride 4 -> 8, 128 -> 128 down-conv and its transposed up-conv 256 -> 128 (decoder shape)
+    n_in, n_out = cin_c.shape[0], cout_c.shape[0]
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(n_in, 128)).astype(np.float32)
+    w = (rng.normal(size=(8, 128, 128)) / np.sqrt(128 * 8)).astype(np.float32)
+    close(hip.conv_gather_gemm(t(x), t(w), entry.fwd), orc.conv_fwd(x, w, nbmaps, nbsizes, (n_in, n_out)), 2e-5)
+    xu = rng.normal(size=(n_out, 256)).astype(np.float32)
+    wu = (rng.normal(size=(8, 256, 128)) / np.sqrt(256 * 8)).astype(np.float32)
+    close(hip.conv_gather_gemm(t(xu), t(wu), entry.rev),
+          orc.conv_fwd(xu, wu, nbmaps, nbsizes, (n_in, n_out), transposed=True), 2e-5)
+
+
+def test_rulebook_bench_batch_bit_exact(hip):
+    """The 12-frame batch bench.py times (about 1.16 M voxels, 4.6 M pairs): stride-1 k3 rulebook and the first
+    down-conv map vs the oracle, bit-exact incl. order."""
+    from openpcseg_amd import functional as F
+    lv = scan_levels(range(12))
+    c1 = lv[1]
+    assert c1.shape[0] > 1_000_000 and int(c1[:, 3].max()) == 11
+    d1 = t(c1)
+    entry = F.build_kernel_map(d1, d1, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    nbmaps, nbsizes = orc.build_kmap(c1, c1, 3, 1)
+    assert np.array_equal(entry[1].cpu().numpy(), nbsizes)
+    assert np.array_equal(entry[0].cpu().numpy().astype(np.int64), nbmaps)
+    rev = entry.rev  # mirrored map == probing the negated offsets
+    built = hip.build_kmap(d1, d1, -entry._ctx[2])
+    assert torch.equal(rev.pairs, built.pairs) and rev.koff_host == built.koff_host
+    out = hip.downsample(d1, [2, 2, 2])
+    assert np.array_equal(out.cpu().numpy(), lv[2])
+    e2 = F.build_kernel_map(d1, out, (2, 2, 2), (1, 1, 1), (1, 1, 1))
+    nb2, ns2 = orc.build_kmap(c1, lv[2], 2, 1)
+    assert np.array_equal(e2[1].cpu().numpy(), ns2) and np.array_equal(e2[0].cpu().numpy().astype(np.int64), nb2)
