@@ -267,9 +267,12 @@ int pcs_denselize_bwd_f32(const float *gout, const int32_t *count_map, const int
  * voxel features fused with the residual add and the ReLU that follow it in the reference's
  * blocks (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:31-129: Conv3d -> (Sync)BatchNorm
  * -> ReLU, and relu(net(x) + downsample(x))). Statistics are two-level and fixed-order
- * (deterministic); `sums` (2c doubles: sum x | sum x^2) is the vector a data-parallel run
- * all-reduces between the stats and the finalize call -- SyncBatchNorm semantics --, `sums2`
- * (sum g | sum g*xhat) the one it all-reduces in backward.
+ * (deterministic); `sums` (2c + 1 doubles: sum x | sum x^2 | row count n) is the vector a data-parallel
+ * run all-reduces between the stats and the finalize call -- SyncBatchNorm semantics; the global count
+ * then reaches finalize / bwd_apply as the DEVICE pointer `count_dev` (= sums + 2c; overrides the host
+ * `count` when non-NULL), so no rank ever reads it back --, `sums2` (sum g | sum g*xhat) the one it
+ * all-reduces in backward. The forward partial sums are taken about a pivot row and un-shifted in
+ * double (E[x^2] - mean^2 on raw fp32 sums cancels when |mean| >> std).
  *   forward : pcs_bn_stats_f32 -> [all-reduce sums, count] -> pcs_bn_finalize_f32 (stat = mean | invstd,
  *             running stats updated with the unbiased variance like nn.BatchNorm1d)
  *             -> pcs_bn_apply_f32: y = act((x - mean) * invstd * w + b [+ res])
@@ -282,15 +285,15 @@ int pcs_denselize_bwd_f32(const float *gout, const int32_t *count_map, const int
  */
 int32_t pcs_bn_num_partials(void);
 int pcs_bn_stats_f32(const float *x, int64_t n, int32_t c, float *partial_ws, double *sums, void *stream);
-int pcs_bn_finalize_f32(const double *sums, double count, int32_t c, double eps, double momentum,
-                        float *running_mean, float *running_var, double *stat, void *stream);
+int pcs_bn_finalize_f32(const double *sums, double count, const double *count_dev, int32_t c, double eps,
+                        double momentum, float *running_mean, float *running_var, double *stat, void *stream);
 int pcs_bn_apply_f32(const float *x, const float *res, const double *stat, const float *w, const float *b,
                      int64_t n, int32_t c, int32_t relu, float *y, uint32_t *mask, void *stream);
 int pcs_bn_bwd_stats_f32(const float *dy, const float *x, const float *y, const uint32_t *mask, const double *stat,
                          int64_t n, int32_t c, int32_t relu, float *partial_ws, double *sums2, void *stream);
 int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const uint32_t *mask, const double *stat,
-                         const double *sums2, double count, const float *w, int64_t n, int32_t c,
-                         int32_t relu, float *dx, float *dres, void *stream);
+                         const double *sums2, double count, const double *count_dev, const float *w, int64_t n,
+                         int32_t c, int32_t relu, float *dx, float *dres, void *stream);
 
 /* ---- device-side sparse_quantize ---------------------------------------------------------------
  * Replaces the dataloader-side NumPy voxel dedup TS:torchsparse/utils/quantize.py:9-46

@@ -39,10 +39,12 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float *__restrict
 #pragma unroll
     for (int q = 0; q < V; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
     if (j < cv) {
+      // forward: sums of (x - pivot) and (x - pivot)^2 with pivot = row 0 of the tensor (a sample of the channel),
+      // un-shifted in double by the reduce kernel: E[x^2] - mean^2 on RAW fp32 partial sums loses var/mean^2 digits
       float mean[V], invstd[V];
 #pragma unroll
       for (int q = 0; q < V; ++q) {
-        mean[q] = BWD ? (float)stat[j * V + q] : 0.f;
+        mean[q] = BWD ? (float)stat[j * V + q] : (n > 0 ? x[j * V + q] : 0.f);
         invstd[q] = BWD ? (float)stat[c + j * V + q] : 0.f;
       }
       for (int64_t i = (int64_t)blockIdx.x * TY + ty; i < n; i += (int64_t)gridDim.x * TY) {
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float *__restrict
           }
         } else {
 #pragma unroll
-          for (int q = 0; q < V; ++q) { const float t = comp(xv, q); s0[q] += t; s1[q] += t * t; }
+          for (int q = 0; q < V; ++q) { const float t = comp(xv, q) - mean[q]; s0[q] += t; s1[q] += t * t; }
         }
       }
     }
@@ -86,42 +88,59 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float *__restrict
   }
 }
 
-// sums[e] = sum over the nblk partial rows of partial[b][e], e in [0, 2c), accumulated in double in a FIXED order
-// (thread ty sums rows ty, ty+64, ...; then ty = 0..63 in order): deterministic. 16 columns x 64 row lanes per
-// workgroup: the kernel is pure latency (a few MB once per BatchNorm pass, 378 launches per training step), so the
-// rows are spread over as many lanes as a workgroup holds and each lane keeps its 16 loads in flight together.
-__global__ void __launch_bounds__(1024) bn_reduce_kernel(const float *__restrict__ partial, int nblk, int c,
+// sums[ch] / sums[c + ch] = sum over the nblk partial rows of partial[b][0][ch] / partial[b][1][ch], accumulated in
+// double in a FIXED order (thread ty sums rows ty, ty+64, ...; then ty = 0..63 in order): deterministic. 16 channels x
+// 64 row lanes per workgroup: the kernel is pure latency (a few MB once per BatchNorm pass, 378 launches per training
+// step), so the rows are spread over as many lanes as a workgroup holds and each lane keeps its loads in flight
+// together. Forward (pivot != NULL): the partials are sums of (x - pivot) and (x - pivot)^2; the raw moments
+//   sum x = S0 + n p,   sum x^2 = S1 + 2 p S0 + n p^2
+// are formed here in double, and sums[2c] = n (the vector a data-parallel run all-reduces: SyncBN needs the global count).
+template <typename PT>
+__global__ void __launch_bounds__(1024) bn_reduce_kernel(const PT *__restrict__ partial, int nblk, int c,
+                                                         const float *__restrict__ pivot, int64_t n,
                                                          double *__restrict__ sums) {
-  __shared__ double red[64][17];
-  const int e = blockIdx.x * 16 + threadIdx.x;
-  double s = 0.0;
-  if (e < 2 * c) {
-    float v[16];
-    for (int b0 = threadIdx.y; b0 < nblk; b0 += 64 * 16) {
+  __shared__ double red[2][64][17];
+  const int ch = blockIdx.x * 16 + threadIdx.x;
+  double s0 = 0.0, s1 = 0.0;
+  if (ch < c) {
+    PT v0[8], v1[8];
+    for (int b0 = threadIdx.y; b0 < nblk; b0 += 64 * 8) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int b = b0 + 64 * u;
-        v[u] = b < nblk ? partial[(int64_t)b * 2 * c + e] : 0.f;
+        v0[u] = b < nblk ? partial[(int64_t)b * 2 * c + ch] : (PT)0;
+        v1[u] = b < nblk ? partial[(int64_t)b * 2 * c + c + ch] : (PT)0;
       }
 #pragma unroll
-      for (int u = 0; u < 16; ++u) s += (double)v[u];
+      for (int u = 0; u < 8; ++u) { s0 += (double)v0[u]; s1 += (double)v1[u]; }
     }
   }
-  red[threadIdx.y][threadIdx.x] = s;
+  red[0][threadIdx.y][threadIdx.x] = s0;
+  red[1][threadIdx.y][threadIdx.x] = s1;
   __syncthreads();
-  if (threadIdx.y == 0 && e < 2 * c) {
-    double t = 0.0;
-    for (int r = 0; r < 64; ++r) t += red[r][threadIdx.x];
-    sums[e] = t;
+  if (threadIdx.y == 0 && ch < c) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int r = 0; r < 64; ++r) { t0 += red[0][r][threadIdx.x]; t1 += red[1][r][threadIdx.x]; }
+    if (pivot) {
+      const double p = n > 0 ? (double)pivot[ch] : 0.0, dn = (double)n;
+      t1 = t1 + 2.0 * p * t0 + dn * p * p;
+      t0 = t0 + dn * p;
+    }
+    sums[ch] = t0;
+    sums[c + ch] = t1;
   }
+  if (pivot && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) sums[2 * c] = (double)n;
 }
 
 // stat[0..c) = mean, stat[c..2c) = invstd; running stats updated like nn.BatchNorm1d (unbiased var, momentum)
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const double *__restrict__ sums, double count, int c,
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const double *__restrict__ sums, double count,
+                                                          const double *__restrict__ count_dev, int c,
                                                           double eps, double momentum, float *running_mean,
                                                           float *running_var, double *__restrict__ stat) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
+  if (count_dev) count = *count_dev;  // the all-reduced global row count stays on the device (no host read)
+  if (!(count > 0.0)) count = 1.0;
   const double mean = sums[ch] / count;
   double var = sums[c + ch] / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -179,9 +198,12 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *__restri
                                                            const float *__restrict__ y, const uint32_t *__restrict__ mask,
                                                            const double *__restrict__ stat,
                                                            const double *__restrict__ sums2, double count,
+                                                           const double *__restrict__ count_dev,
                                                            const float *__restrict__ w, int64_t n, int c, int cv,
                                                            int relu, float *__restrict__ dx, float *__restrict__ dres) {
   using VT = typename NV<V>::T;
+  if (count_dev) count = *count_dev;
+  if (!(count > 0.0)) count = 1.0;
   for (int j = threadIdx.x; j < cv; j += blockDim.x) {
     float mean[V], invstd[V], k1[V], k2[V], ws[V];
 #pragma unroll
@@ -246,7 +268,8 @@ static int bn_partial(bool bwd, const float *x, const float *dy, const float *y,
     if (bwd) hipLaunchKernelGGL((bn_partial_kernel<true, 1>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial);
     else hipLaunchKernelGGL((bn_partial_kernel<false, 1>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial);
   }
-  hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)ceil_div(2 * c, 16)), dim3(16, 64), 0, st, partial, kStatBlocks, c, sums);
+  hipLaunchKernelGGL(bn_reduce_kernel<float>, dim3((unsigned)ceil_div(c, 16)), dim3(16, 64), 0, st, partial, kStatBlocks, c,
+                     bwd ? nullptr : x, n, sums);
   return check_launch("pcs_bn_partial");
 }
 
@@ -255,11 +278,11 @@ extern "C" int pcs_bn_stats_f32(const float *x, int64_t n, int32_t c, float *par
   return bn_partial(false, x, nullptr, nullptr, nullptr, nullptr, n, c, 0, partial_ws, sums, as_stream(stream));
 }
 
-extern "C" int pcs_bn_finalize_f32(const double *sums, double count, int32_t c, double eps, double momentum,
-                                   float *running_mean, float *running_var, double *stat, void *stream) {
-  if (c <= 0 || count <= 0 || !sums || !stat) { set_error("pcs_bn_finalize: bad args"); return PCS_EINVAL; }
+extern "C" int pcs_bn_finalize_f32(const double *sums, double count, const double *count_dev, int32_t c, double eps,
+                                   double momentum, float *running_mean, float *running_var, double *stat, void *stream) {
+  if (c <= 0 || (!count_dev && !(count > 0)) || !sums || !stat) { set_error("pcs_bn_finalize: bad args"); return PCS_EINVAL; }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(c, 256)), dim3(256), 0, as_stream(stream), sums, count,
-                     c, eps, momentum, running_mean, running_var, stat);
+                     count_dev, c, eps, momentum, running_mean, running_var, stat);
   return check_launch("pcs_bn_finalize");
 }
 
@@ -289,9 +312,10 @@ extern "C" int pcs_bn_bwd_stats_f32(const float *dy, const float *x, const float
 }
 
 extern "C" int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const uint32_t *mask,
-                                    const double *stat, const double *sums2, double count, const float *w, int64_t n,
-                                    int32_t c, int32_t relu, float *dx, float *dres, void *stream) {
-  if (n < 0 || c <= 0 || count <= 0) { set_error("pcs_bn_bwd_apply: bad sizes"); return PCS_EINVAL; }
+                                    const double *stat, const double *sums2, double count, const double *count_dev,
+                                    const float *w, int64_t n, int32_t c, int32_t relu, float *dx, float *dres,
+                                    void *stream) {
+  if (n < 0 || c <= 0 || (!count_dev && !(count > 0))) { set_error("pcs_bn_bwd_apply: bad sizes"); return PCS_EINVAL; }
   if (n == 0) return PCS_OK;
   if (!dy || !x || !stat || !sums2 || !dx || (relu && !y && !mask)) { set_error("pcs_bn_bwd_apply: null pointer"); return PCS_EINVAL; }
   hipStream_t st = as_stream(stream);
@@ -299,10 +323,10 @@ extern "C" int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float
   if (mask && (!vec || (c & 31))) { set_error("pcs_bn_bwd_apply: the ReLU bit mask needs c % 32 == 0 and 16-byte aligned rows"); return PCS_EUNSUPPORTED; }
   if (vec) {
     Geo g = geo<4>(n, c);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, w, n, c, g.cv, relu, dx, dres);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, g.cv, relu, dx, dres);
   } else {
     Geo g = geo<1>(n, c);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, w, n, c, g.cv, relu, dx, dres);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, g.cv, relu, dx, dres);
   }
   return check_launch("pcs_bn_bwd_apply");
 }

@@ -3,8 +3,8 @@ reference's conv blocks as ONE forward apply pass and ONE backward apply pass ov
 
 `FusedBatchNorm` has the parameters / buffers / state_dict keys of nn.BatchNorm1d (and nn.SyncBatchNorm), so
 reference checkpoints load; `sync=True` all-reduces the (sum, sum^2, count) vector over the default process group
-between the statistics and the apply kernels -- SyncBatchNorm semantics, one small collective per layer and
-direction (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:23-25)."""
+between the statistics and the apply kernels -- SyncBatchNorm semantics, ONE small collective per layer and
+direction on a dedicated process group, the global row count travelling inside the vector and staying on the device (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:23-25)."""
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -18,20 +18,29 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def _global_rows(n_local, device, cache, level):
-    """Total row count over all ranks for a tensor with n_local rows. One tiny all-reduce + host read per
-    resolution level and forward pass (cached in the pass-wide `cmaps` dict), not one per BN layer. The key holds the
-    level (tensor stride), so the hit / miss sequence -- hence the sequence of collectives -- is the same on every
-    rank whatever the per-rank row counts are."""
-    key = ("_pcs_bn_rows", level, n_local)
-    if cache is not None and key in cache:
-        return cache[key]
-    t = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
-    dist.all_reduce(t)
-    total = float(t.item())
-    if cache is not None:
-        cache[key] = total
-    return total
+_STATS_GROUP = {}
+
+
+def _stats_group():
+    """A process group of its own for the BatchNorm statistics. On the default group the tiny (<= 6 KB) statistics
+    all-reduces of backward queue FIFO behind DDP's 25 MB gradient buckets on the same RCCL communicator and stream
+    -- each of the 63 BN layers then waits for a bucket to cross the xGMI ring before it can normalise its gradient.
+    A second communicator (high-priority stream on RCCL) lets them overtake. PCS_BN_GROUP=0 keeps the default group."""
+    import os
+    if os.environ.get("PCS_BN_GROUP", "1") == "0":
+        return None
+    key = dist.get_world_size(), dist.get_backend()
+    g = _STATS_GROUP.get(key)
+    if g is None:
+        kw = {}
+        if dist.get_backend() == "nccl":
+            try:
+                kw["pg_options"] = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:
+                pass
+        g = dist.new_group(backend=dist.get_backend(), **kw)  # collective: every rank reaches its first BN layer
+        _STATS_GROUP[key] = g
+    return g
 
 
 class _FusedBN(Function):
@@ -41,27 +50,28 @@ class _FusedBN(Function):
         x = x.contiguous()
         res = res.contiguous() if res is not None else None
         n, c = x.shape
-        sums = be.bn_stats(x)
-        count = float(n)
+        sums = be.bn_stats(x)  # [sum x | sum x^2 | n]
+        count, count_dev = float(n), None
         if sync and _world() > 1:
-            count = _global_rows(n, x.device, cache, level)
-            sums = sums.clone()
-            dist.all_reduce(sums)  # (sum, sum^2) over all ranks: SyncBatchNorm statistics
-        stat = be.bn_finalize(sums, count, eps, momentum, running_mean, running_var)
+            # ONE collective per layer and direction: the row count rides in the statistics vector and the global
+            # count stays on the device (finalize / bwd_apply read it there) -- no count all-reduce, no host sync
+            dist.all_reduce(sums, group=_stats_group())
+            count_dev = sums[2 * c:]
+        stat = be.bn_finalize(sums, count, eps, momentum, running_mean, running_var, count_dev=count_dev)
         # c % 32 == 0: the backward passes read the ReLU gate as a bit mask (1/32 of a tensor) instead of y
         if relu and c % 32 == 0 and c % 4 == 0:
             y, gate = be.bn_apply(x, res, stat, weight, bias, relu, want_mask=True)
         else:
             y = be.bn_apply(x, res, stat, weight, bias, relu)
             gate = y if relu else None
-        ctx.save_for_backward(x, gate, stat, weight)
+        ctx.save_for_backward(x, gate, stat, weight, count_dev)
         ctx.cfg = (count, relu, sync, res is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         be = native.backend()
-        x, gate, stat, weight = ctx.saved_tensors
+        x, gate, stat, weight, count_dev = ctx.saved_tensors
         count, relu, sync, has_res = ctx.cfg
         dy = dy.contiguous()
         c = x.shape[1]
@@ -69,8 +79,8 @@ class _FusedBN(Function):
         sums2 = local
         if sync and _world() > 1:
             sums2 = local.clone()
-            dist.all_reduce(sums2)
-        dx, dres = be.bn_bwd_apply(dy, x, gate, stat, sums2, count, weight, relu, has_res)
+            dist.all_reduce(sums2, group=_stats_group())
+        dx, dres = be.bn_bwd_apply(dy, x, gate, stat, sums2, count, weight, relu, has_res, count_dev=count_dev)
         dw = local[c:].float() if weight is not None else None   # local sums: DDP averages parameter grads
         db = local[:c].float() if weight is not None else None
         return dx, dres, dw, db, None, None, None, None, None, None, None, None

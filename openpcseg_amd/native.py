@@ -57,10 +57,10 @@ SIGNATURES = {
     "pcs_denselize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_bn_num_partials": (c_int32, []),
     "pcs_bn_stats_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P]),
-    "pcs_bn_finalize_f32": (c_int32, [_P, c_double, c_int32, c_double, c_double, _P, _P, _P, _P]),
+    "pcs_bn_finalize_f32": (c_int32, [_P, c_double, _P, c_int32, c_double, c_double, _P, _P, _P, _P]),
     "pcs_bn_apply_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
     "pcs_bn_bwd_stats_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
-    "pcs_bn_bwd_apply_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_double, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
+    "pcs_bn_bwd_apply_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_double, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
     "pcs_quantize_floor": (c_int32, [_P, c_int32, c_int64, c_int32, _P, _P, _P, _P]),
     "pcs_quantize_keys": (c_int32, [_P, c_int64, _P, _P, _P]),
     "pcs_quantize_flags": (c_int32, [_P, c_int64, _P, _P]),
@@ -607,18 +607,20 @@ class HipBackend:
 
     # -- fused BatchNorm (+residual, +ReLU) -------------------------------------------------------
     def bn_stats(self, x):
-        """-> sums (2c,) float64 = [sum x | sum x^2] (what SyncBN all-reduces)."""
+        """-> sums (2c + 1,) float64 = [sum x | sum x^2 | n] (the vector SyncBN all-reduces; the count rides along)."""
         x = _dev(x, "input", torch.float32)
         n, c = x.shape
         ws = torch.empty(self.lib.pcs_bn_num_partials() * 2 * c, dtype=torch.float32, device=x.device)
-        sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        sums = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
         _check(self.lib.pcs_bn_stats_f32(_ptr(x), n, c, _ptr(ws), _ptr(sums), _stream()), "pcs_bn_stats_f32")
         return sums
 
-    def bn_finalize(self, sums, count, eps, momentum, running_mean, running_var):
+    def bn_finalize(self, sums, count, eps, momentum, running_mean, running_var, count_dev=None):
+        """stat = [mean | invstd]; `count_dev` (1-element float64 device tensor, e.g. sums[2c:]) replaces the host count."""
         c = sums.numel() // 2
         stat = torch.empty(2 * c, dtype=torch.float64, device=sums.device)
-        _check(self.lib.pcs_bn_finalize_f32(_ptr(sums), float(count), c, float(eps), float(momentum),
+        _check(self.lib.pcs_bn_finalize_f32(_ptr(sums), float(count), _ptr(count_dev) if count_dev is not None else None,
+                                            c, float(eps), float(momentum),
                                             _ptr(running_mean) if running_mean is not None else None,
                                             _ptr(running_var) if running_var is not None else None, _ptr(stat),
                                             _stream()), "pcs_bn_finalize_f32")
@@ -655,13 +657,14 @@ class HipBackend:
                                              _ptr(ws), _ptr(sums2), _stream()), "pcs_bn_bwd_stats_f32")
         return sums2
 
-    def bn_bwd_apply(self, dy, x, gate, stat, sums2, count, w, relu, want_res):
+    def bn_bwd_apply(self, dy, x, gate, stat, sums2, count, w, relu, want_res, count_dev=None):
         n, c = x.shape
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if want_res else None
         yp, mp = self._gate(gate, relu)
         _check(self.lib.pcs_bn_bwd_apply_f32(_ptr(dy), _ptr(x), yp, mp, _ptr(stat), _ptr(sums2),
-                                             float(count), _ptr(w) if w is not None else None, n, c, int(relu),
+                                             float(count), _ptr(count_dev) if count_dev is not None else None,
+                                             _ptr(w) if w is not None else None, n, c, int(relu),
                                              _ptr(dx), _ptr(dres) if want_res else None, _stream()),
                "pcs_bn_bwd_apply_f32")
         return dx, dres

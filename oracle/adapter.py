@@ -140,12 +140,14 @@ class OracleBackend:
     # fused BatchNorm pieces restated with plain torch (nn.BatchNorm1d training semantics)
     def bn_stats(self, x):
         xd = x.double()
-        return torch.cat([xd.sum(0), (xd * xd).sum(0)])
+        return torch.cat([xd.sum(0), (xd * xd).sum(0), torch.tensor([float(x.shape[0])], dtype=torch.float64)])
 
-    def bn_finalize(self, sums, count, eps, momentum, running_mean, running_var):
+    def bn_finalize(self, sums, count, eps, momentum, running_mean, running_var, count_dev=None):
         c = sums.numel() // 2
+        if count_dev is not None:
+            count = float(count_dev[0])
         mean = sums[:c] / count
-        var = (sums[c:] / count - mean * mean).clamp_(min=0)
+        var = (sums[c:2 * c] / count - mean * mean).clamp_(min=0)
         if running_mean is not None:
             unb = var * count / (count - 1.0) if count > 1 else var
             running_mean.mul_(1 - momentum).add_((momentum * mean).float())
@@ -178,8 +180,10 @@ class OracleBackend:
         xh = (x - stat[:c].float()) * stat[c:].float()
         return torch.cat([g.double().sum(0), (g * xh).double().sum(0)])
 
-    def bn_bwd_apply(self, dy, x, gate, stat, sums2, count, w, relu, want_res):
+    def bn_bwd_apply(self, dy, x, gate, stat, sums2, count, w, relu, want_res, count_dev=None):
         c = x.shape[1]
+        if count_dev is not None:
+            count = float(count_dev[0])
         g = (dy * self._gate(gate, c)) if relu else dy
         xh = (x - stat[:c].float()) * stat[c:].float()
         dx = (g - (sums2[:c] / count).float() - xh * (sums2[c:] / count).float()) * stat[c:].float()
