@@ -157,3 +157,72 @@ def test_bench_two_ranks_on_one_device():
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["global_batch"] == 4
     assert res["value"] > 0 and np.isfinite(res["config"]["loss"]) and "cpu_baseline" not in res
     assert res["roofline"]["launches"] > 0
+
+
+def _nccl_bn_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL
+    from openpcseg_amd.fused import FusedBatchNorm
+    from openpcseg_amd.sparse import SparseTensor
+    torch.manual_seed(5)
+    full = torch.randn(3000, 64) * 2 + 1
+    res = torch.randn(3000, 64)
+    lo, hi = (0, 1200) if rank == 0 else (1200, 3000)          # ragged shards
+    x = full[lo:hi].to(dev).requires_grad_(True)
+    bn = FusedBatchNorm(64, sync=True).to(dev).train()
+    y = bn(SparseTensor(x, torch.zeros(hi - lo, 4, dtype=torch.int32, device=dev)), residual=res[lo:hi].to(dev), relu=True).F
+    (y * torch.arange(1, 65, device=dev)).sum().backward()
+    q.put((rank, y.detach().cpu().numpy(), x.grad.cpu().numpy(), bn.weight.grad.cpu().numpy(), bn.running_var.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sync_fused_batchnorm_over_rccl():
+    """FusedBatchNorm(sync=True) on two MI355X over RCCL (backend "nccl"): statistics all-reduce on the dedicated
+    process group, device-resident global count. Skipped on boxes with one visible GPU."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 visible GPUs (RCCL)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    torch.manual_seed(5)
+    full = (torch.randn(3000, 64) * 2 + 1).requires_grad_(True)
+    res = torch.randn(3000, 64)
+    ref = torch.nn.BatchNorm1d(64).train()
+    y = torch.relu(ref(full) + res)
+    (y * torch.arange(1, 65)).sum().backward()
+    assert np.allclose(np.concatenate([got[0][1], got[1][1]]), y.detach().numpy(), atol=1e-4)
+    assert np.allclose(np.concatenate([got[0][2], got[1][2]]), full.grad.numpy(), atol=1e-4)
+    assert np.allclose(got[0][3] + got[1][3], ref.weight.grad.numpy(), rtol=1e-4, atol=1e-3)
+    assert np.allclose(got[0][4], ref.running_var.numpy(), rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_rccl():
+    """bench.py --gpus 2 exactly as the driver launches it, one GPU per rank, backend "nccl" (RCCL over xGMI): the first
+    execution of the real multi-GPU path whenever the box shows two devices; skipped otherwise."""
+    import json
+    import subprocess
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 visible GPUs (RCCL)")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("PCS_BENCH_ONE_DEVICE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--frames-per-gpu", "2"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=560)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["value"] > 0

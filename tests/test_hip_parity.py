@@ -594,3 +594,21 @@ def test_caches_follow_inplace_updates(hip, golden):
         ref = orc.scatter_max(src.cpu().numpy(), index.cpu().numpy(), 30)[0]
         assert np.array_equal(out.cpu().numpy(), ref)
         index.copy_(t(rng.integers(0, 30, size=2000).astype(np.int64)))
+
+
+def test_fused_batchnorm_large_mean_statistics(hip):
+    """|mean| >> std: E[x^2] - mean^2 on raw fp32 partial sums would lose var / mean^2 digits. The statistics pass sums
+    (x - pivot) and (x - pivot)^2 and un-shifts in double: mean / invstd match a float64 two-pass reference."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    n, c = 200000, 64
+    x = torch.randn(n, c, device=DEV, generator=g) * 0.01 + torch.linspace(-300.0, 300.0, c, device=DEV)
+    sums = hip.bn_stats(x)
+    assert float(sums[2 * c]) == n
+    stat = hip.bn_finalize(sums, float(n), 1e-5, 0.1, None, None)
+    xd = x.double()
+    mean, var = xd.mean(0), xd.var(0, unbiased=False)
+    assert torch.allclose(stat[:c], mean, rtol=0, atol=1e-6)
+    assert torch.allclose(stat[c:], 1.0 / torch.sqrt(var + 1e-5), rtol=2e-4)
+    # the device-resident count path (what SyncBN uses) gives the same statistics
+    stat2 = hip.bn_finalize(sums, 0.0, 1e-5, 0.1, None, None, count_dev=sums[2 * c:])
+    assert torch.equal(stat, stat2)
