@@ -317,6 +317,30 @@ int pcs_quantize_flags(const int64_t *sorted_keys, int64_t n, int32_t *flags, vo
 int pcs_quantize_emit(const int32_t *flags, const int64_t *rank, const int64_t *perm, const int32_t *coords,
                       int64_t n, int32_t *vox, int64_t *index, int64_t *inverse, void *stream);
 
+/* ---- half-precision convolution (bf16 / fp16 storage, 16-bit MFMA, fp32 accumulate) --------------
+ * The mixed-precision path of the reference: under `--amp` its ops cast their inputs to half
+ * (TS:torchsparse/nn/functional/conv.py:19) and convolution_cuda.cu:61,120-127 runs gather / mm / scatter
+ * in half. dtype: 1 = bfloat16, 2 = float16 (features, prepared weights and outputs share it).
+ * Served shapes: pcs_conv_h_applies(cin, cout, K) != 0 (cin % 32 == 0, cin >= 64, cout % 4 == 0, K <= 32) --
+ * the >= 64-channel layers; callers convert other shapes to fp32 and use the _f32 entries.
+ *   prepare : W (K, A, B) fp32 master weights -> Wp, the weights in MFMA fragment order, converted to `dtype`.
+ *             transpose = 0: forward (contraction over A = cin, columns B = cout); transpose = 1: dgrad
+ *             (contraction over B, columns A). Wp bytes = pcs_conv_prepared_weights_bytes(K, contraction, columns).
+ *   conv    : pcs_conv_gather_gemm_f32 with src / dst in halfs and Wp instead of W; bias stays fp32 and is added
+ *             in fp32 before the single rounding of the output.
+ *   wgrad   : pcs_conv_wgrad_f32 with half operands; accumulated and returned in fp32 (gW, ws as in _f32).
+ */
+int pcs_conv_h_applies(int32_t cin, int32_t cout, int32_t K);
+size_t pcs_conv_prepared_weights_bytes(int32_t K, int32_t contraction, int32_t columns);
+int pcs_conv_prepare_weights_h(const float *W, int32_t K, int32_t A, int32_t B, int32_t transpose, int32_t dtype,
+                               void *Wp, void *stream);
+int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t cin, const void *Wp, int32_t K, int32_t cout,
+                           const int32_t *pairs, int32_t src_col, const int32_t *seg, int32_t tile_rows,
+                           int64_t n_dst, const float *bias, void *dst, int32_t dtype, void *stream);
+int pcs_conv_wgrad_h(const void *fa, int32_t ca, const void *fb, int32_t cb, const int32_t *pairs, int32_t a_col,
+                     const int32_t *koff_dev, const int32_t *koff_host, int32_t K, float *gW, void *ws,
+                     size_t ws_bytes, int32_t dtype, void *stream);
+
 /* ---- Cylinder3D front-end on the device -------------------------------
  * Replaces, for scans already resident in HBM, the per-frame NumPy work of
  * R:pcseg/data/dataset/semantickitti/semantickitti_cylinder.py (cart2polar :19-22, cylindrical partition

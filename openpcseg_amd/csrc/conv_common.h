@@ -39,6 +39,23 @@ struct ConvArgs {
   int cin, cout, K, src_col, ncoltiles, xcd_remap, tile_rows;
 };
 
+// storage-format tags of the half-precision kernels (features / prepared weights / outputs)
+struct Bf16 {};
+struct Fp16 {};
+struct Fp32 {};
+__device__ __forceinline__ float h2f(Bf16, uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ float h2f(Fp16, uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t f2h(Bf16, float f) {  // round to nearest even; NaN stays NaN
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint16_t f2h(Fp16, float f) {
+  const _Float16 h = (_Float16)f;
+  return __builtin_bit_cast(uint16_t, h);
+}
+
 constexpr size_t kMaxDynLds = 160 * 1024 - 256;  // per-workgroup LDS ceiling of a gfx950 CU, minus the static part
 
 // 16-column MFMA tiles per column tile of the wave kernels: 1, 2, 3, 4, 6 or 8

@@ -1,0 +1,436 @@
+// Half-precision fused convolution (bf16 / fp16 storage, v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulate): the
+// mixed-precision path of the reference (`--amp`: TS:torchsparse/nn/functional/conv.py:19 casts the op inputs to
+// half; TS:torchsparse/backend/convolution/convolution_cuda.cu:61,120-127 runs gather / mm / scatter in half).
+//
+// Same output-stationary structure as conv_wave5.hip -- wave-autonomous row-block groups, fp32 accumulator tile in
+// LDS, ticket-ordered commit, every dst row written once -- with the operand side rebuilt for 16-bit MFMAs, whose
+// 16x-higher rate turns the kernel from MFMA-bound into L2/gather-bound:
+//   * one contraction step = 32 channels = ONE 16-byte load per lane and operand: lane (n = lane & 15, g = lane >> 4)
+//     reads the 8 halfs src[row_n][32 s + 8 g .. +7] (A) and the 8 halfs of column n of the weights (B);
+//   * the weights are re-packed once per layer call (pcs_conv_prepare_weights_h) into MFMA FRAGMENT ORDER:
+//     block (offset k, 16-column tile t, step s) is 1 KB with lane l's 16 bytes at offset 16 l, so a wave's B load
+//     is one fully contiguous 1 KB read (eight whole 128-B lines) instead of 16 half-line pieces; the fp32 master
+//     weights are converted in the same pass (no separate cast kernel), stored column-major per offset ([column][contraction]) for the forward pass and for dgrad alike;
+//   * column tile f of a 64-column quad owns columns 64 q + 4 n + f (as in the fp32 kernel), so the commit and the
+//     epilogue move 16-byte LDS words.
+// Requires cin % 32 == 0, cin >= 64, cout % 4 == 0 (conv5_applies): the >= 64-channel layers; other shapes are
+// converted to fp32 by the host layer and take the fp32 kernels.
+#include "conv_common.h"
+
+using namespace pcs;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mfma_h(Bf16, const uint4 &a, const uint4 &b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_h(Fp16, const uint4 &a, const uint4 &b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// local column (inside a CT-wide column tile) that lane n of 16-column tile tl feeds -- the interleave the commit and
+// the epilogue of the wave kernels assume (quads of 4 tiles: 64 q + 4 n + f; a pair: + 2 n + f; a single: + n)
+__host__ __device__ inline int h_local_col(int nctt, int tl, int n) {
+  const int n4 = nctt / 4, n2 = (nctt % 4) / 2;
+  if (tl < 4 * n4) return 64 * (tl / 4) + 4 * n + (tl % 4);
+  if (tl < 4 * n4 + 2 * n2) return 64 * n4 + 2 * n + (tl - 4 * n4);
+  return 64 * n4 + 32 * n2 + n;
+}
+
+// Wp block (k, global 16-column tile gt, step s) = 64 lanes x 8 halfs; lane 16 g + n, element j =
+//   Wmath[k][32 s + 8 g + j][column(gt, n)],  Wmath[k][c][col] = transpose ? W[k][col][c] : W[k][c][col]
+// (W is (K, A, B) fp32: forward contracts over A = cin, dgrad over B = cout). Columns >= ccols are zero.
+template <typename HT>
+__global__ void __launch_bounds__(256) prepare_weights_kernel(const float *__restrict__ W, int K, int A, int B, int transpose,
+                                                              int nctt, int nt16, int ns, uint4 *__restrict__ Wp) {
+  const int ccon = transpose ? B : A, ccols = transpose ? A : B;
+  const int64_t total = (int64_t)K * nt16 * ns * 64;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    int64_t b = i >> 6;
+    const int s = (int)(b % ns); b /= ns;
+    const int gt = (int)(b % nt16);
+    const int k = (int)(b / nt16);
+    const int n = lane & 15, g = lane >> 4;
+    const int col = (gt / nctt) * 16 * nctt + h_local_col(nctt, gt % nctt, n);
+    uint16_t h[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = 32 * s + 8 * g + j;
+      float v = 0.f;
+      if (col < ccols && c < ccon)
+        v = transpose ? W[((int64_t)k * A + col) * B + c] : W[((int64_t)k * A + c) * B + col];
+      h[j] = f2h(HT{}, v);
+    }
+    uint4 o;
+    o.x = h[0] | ((uint32_t)h[1] << 16); o.y = h[2] | ((uint32_t)h[3] << 16);
+    o.z = h[4] | ((uint32_t)h[5] << 16); o.w = h[6] | ((uint32_t)h[7] << 16);
+    Wp[i] = o;
+  }
+}
+
+struct ConvArgsH {
+  const char *src;    // (n_src, cin) halfs
+  const char *Wp;     // prepared weights, fragment order
+  const float *bias;  // fp32, may be NULL
+  uint16_t *dst;      // (n_dst, cout) halfs
+  const int32_t *pairs;
+  const int32_t *seg;
+  int64_t n_dst;
+  int64_t ntiles;
+  int cin, cout, K, src_col, ncoltiles, xcd_remap, tile_rows, nt16, ns;
+};
+
+template <int NCTT, int NW_, int R_>
+struct Conv5hCfg {
+  static constexpr int NW = NW_;
+  static constexpr int R = R_;
+  static constexpr int NT = 64 * NW;
+  static constexpr int CT = 16 * NCTT;
+  static constexpr int ACS = CT + 4;
+  static constexpr int N4 = NCTT / 4;
+  static constexpr int N2 = (NCTT % 4) / 2;
+  static constexpr int N1 = NCTT % 2;
+  static constexpr size_t lds_bytes(int T) { return (size_t)((T + 1) * ACS) * 4 + 5 * 33 * 4 + 16; }
+};
+
+template <typename HT, int NCTT, int NW, int MINW, int R>
+__global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
+  using C = Conv5hCfg<NCTT, NW, R>;
+  const int T = a.tile_rows;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *acc_l = reinterpret_cast<float *>(smem);            // [T+1][ACS], row T = sink for padding rows
+  int *kl_k = reinterpret_cast<int *>(acc_l + (T + 1) * C::ACS);  // [32] offset id
+  int *kl_s = kl_k + 32;                                     // [32] first pair
+  int *kl_m = kl_s + 32;                                     // [32] #pairs
+  int *kl_g = kl_m + 32;                                     // [33] first FULL group (prefix over the offsets)
+  int *kl_h = kl_g + 33;                                     // [33] first partial group (prefix)
+  int *commit = kl_h + 33;
+  __shared__ int nk_s;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  unsigned bid = blockIdx.x;
+  if (a.xcd_remap) {
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int64_t tile = bid / a.ncoltiles;
+  const int ctile = bid % a.ncoltiles;
+  const int n0 = ctile * C::CT;
+  const int64_t row0 = tile * T;
+  const int64_t nt1 = a.ntiles + 1;
+
+  if (wid == 0) {  // non-empty offsets of this tile + prefix of their row-block groups (as conv_wave5.hip)
+    const int k = lane;
+    int s0 = 0, m = 0;
+    if (k < a.K) {
+      s0 = a.seg[(int64_t)k * nt1 + tile];
+      m = a.seg[(int64_t)k * nt1 + tile + 1] - s0;
+    }
+    const unsigned long long mask = __ballot(m > 0);
+    const int nrb = (m + 15) >> 4;
+    const int nfull = nrb / R, npart = (nrb % R) ? 1 : 0;
+    int incl = nfull | (npart << 16);
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (m > 0) {
+      const int pos = __popcll(mask & ((1ULL << lane) - 1ULL));
+      kl_k[pos] = k; kl_s[pos] = s0; kl_m[pos] = m;
+      kl_g[pos] = (incl & 0xFFFF) - nfull; kl_h[pos] = (incl >> 16) - npart;
+    }
+    const int total = __shfl(incl, 63, 64);
+    if (lane == 0) {
+      const int nkk = __popcll(mask);
+      nk_s = nkk; kl_g[nkk] = total & 0xFFFF; kl_h[nkk] = total >> 16; *commit = 0;
+    }
+  }
+  for (int i = tid; i < (T + 1) * C::ACS; i += C::NT) acc_l[i] = 0.f;
+  __syncthreads();
+  const int nk = nk_s;
+  const int total_full = nk > 0 ? kl_g[nk] : 0;
+  const int total_grp = nk > 0 ? total_full + kl_h[nk] : 0;
+
+  // B fragments of this column tile: 16-column tiles that do not exist (beyond cout) read tile 0, results dropped
+  const int gt0 = ctile * NCTT;
+  int btile[NCTT];
+#pragma unroll
+  for (int t = 0; t < NCTT; ++t) btile[t] = (gt0 + t < a.nt16) ? t : 0;
+  const int NS = a.ns;
+
+  struct Frag {  // one 32-channel step: A pieces of the R row blocks + the NCTT B fragments
+    uint4 a[R];
+    uint4 b[NCTT];
+  };
+  struct Ctx {  // one group: R row blocks of one offset
+    const char *srow[R];
+    const char *Wk;  // fragment blocks of (offset, first 16-column tile of this column tile), this lane's 16 bytes
+    int dloc[R];
+    int nr;
+    unsigned vmask;
+  };
+  auto load_frag = [&](Frag &f, const Ctx &cx, int s) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) f.a[r] = *reinterpret_cast<const uint4 *>(cx.srow[r] + (size_t)s * 64);
+#pragma unroll
+    for (int t = 0; t < NCTT; ++t)
+      f.b[t] = *reinterpret_cast<const uint4 *>(cx.Wk + ((size_t)btile[t] * NS + s) * 1024);
+  };
+  auto locate = [&](int grp, int &i_hint, int *pidx, unsigned &vmask, int &nr) {
+    int rb0, e;
+    if (grp < total_full) {
+      e = i_hint;
+      while (kl_g[e + 1] <= grp) ++e;
+      i_hint = e;
+      rb0 = (grp - kl_g[e]) * R;
+      nr = R;
+    } else {
+      const int q = grp - total_full;
+      e = (i_hint & 32) ? (i_hint & 31) : 0;
+      while (kl_h[e + 1] <= q) ++e;
+      i_hint = e | 32;
+      const int nrb = (kl_m[e] + 15) >> 4;
+      rb0 = (nrb / R) * R;
+      nr = nrb - rb0;
+    }
+    const int m = kl_m[e];
+    vmask = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int rk = (rb0 + r) * 16 + l15;
+      const bool v = rk < m;
+      vmask |= v ? (1u << r) : 0u;
+      pidx[r] = kl_s[e] + (v ? rk : m - 1);  // padding rows re-read the slice's last pair
+    }
+  };
+  auto make_ctx = [&](Ctx &cx, const int2 *pr, unsigned vmask, int nr, int i_k) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      cx.srow[r] = a.src + ((int64_t)(a.src_col ? pr[r].y : pr[r].x) * a.cin + 8 * g) * 2;
+      cx.dloc[r] = ((vmask >> r) & 1u) ? (int)((a.src_col ? pr[r].x : pr[r].y) - row0) : T;
+    }
+    cx.vmask = vmask;
+    cx.nr = nr;
+    cx.Wk = a.Wp + (((int64_t)kl_k[i_k & 31] * a.nt16 + gt0) * NS) * 1024 + lane * 16;
+  };
+
+  int i = 0;
+  Ctx cur;
+  Frag f0, f1;
+  if (wid < total_grp) {
+    int pidx[R]; unsigned vm; int nr;
+    locate(wid, i, pidx, vm, nr);
+    int2 pr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) pr[r] = reinterpret_cast<const int2 *>(a.pairs)[pidx[r]];
+    make_ctx(cur, pr, vm, nr, i);
+    load_frag(f0, cur, 0);
+  }
+  for (int grp = wid; grp < total_grp; grp += C::NW) {  // wave-uniform loop, no barrier inside
+    const int grpn = grp + C::NW < total_grp ? grp + C::NW : grp;
+    int in = i, pidx_n[R], nr_n; unsigned vm_n;
+    locate(grpn, in, pidx_n, vm_n, nr_n);
+    int2 pr_n[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) pr_n[r] = reinterpret_cast<const int2 *>(a.pairs)[pidx_n[r]];
+
+    f32x4 acc[R][NCTT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int t = 0; t < NCTT; ++t) acc[r][t] = (f32x4){0, 0, 0, 0};
+    const unsigned vmask = cur.vmask;
+    const int nr = cur.nr;  // wave-uniform
+    auto mfma_frag = [&](const Frag &f) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (r < nr) {  // wave-uniform
+          const bool ok = (vmask >> r) & 1u;
+          uint4 av = f.a[r];
+          if (!ok) av = make_uint4(0u, 0u, 0u, 0u);  // padding rows contribute exact zeros
+#pragma unroll
+          for (int t = 0; t < NCTT; ++t) acc[r][t] = mfma_h(HT{}, av, f.b[t], acc[r][t]);
+        }
+      }
+    };
+    Ctx nxt;
+    // two fragment sets, software-pipelined: the loads of step s+1 are issued before the MFMAs of step s; the first
+    // fragment of the NEXT group is in flight during the last step and the commit of this one
+    int s = 0;
+    for (; s + 2 < NS; s += 2) {
+      load_frag(f1, cur, s + 1);
+      mfma_frag(f0);
+      load_frag(f0, cur, s + 2);
+      mfma_frag(f1);
+    }
+    if (NS - s == 2) {
+      load_frag(f1, cur, s + 1);
+      mfma_frag(f0);
+      make_ctx(nxt, pr_n, vm_n, nr_n, in);
+      load_frag(f0, nxt, 0);
+      mfma_frag(f1);
+    } else {  // odd number of steps (cin = 96, 160, ...)
+      make_ctx(nxt, pr_n, vm_n, nr_n, in);
+      load_frag(f1, nxt, 0);
+      mfma_frag(f0);
+      f0 = f1;
+    }
+    // ---- in-order commit of the group's row blocks (identical to conv_wave5.hip) ------------------------------
+    if (lane == 0) {
+      while (__hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != grp)
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r < nr) {  // wave-uniform
+        float *d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = acc_l + __shfl(cur.dloc[r], 4 * g + j, 64) * C::ACS;
+        float4 v4[4][C::N4 > 0 ? C::N4 : 1];
+        float2 v2[4];
+        float v1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int q = 0; q < C::N4; ++q) v4[j][q] = *reinterpret_cast<const float4 *>(d[j] + 64 * q + 4 * l15);
+          if (C::N2) v2[j] = *reinterpret_cast<const float2 *>(d[j] + 64 * C::N4 + 2 * l15);
+          if (C::N1) v1[j] = d[j][64 * C::N4 + 32 * C::N2 + l15];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int q = 0; q < C::N4; ++q) {
+            v4[j][q].x += acc[r][4 * q + 0][j]; v4[j][q].y += acc[r][4 * q + 1][j];
+            v4[j][q].z += acc[r][4 * q + 2][j]; v4[j][q].w += acc[r][4 * q + 3][j];
+            *reinterpret_cast<float4 *>(d[j] + 64 * q + 4 * l15) = v4[j][q];
+          }
+          if (C::N2) {
+            v2[j].x += acc[r][4 * C::N4 + 0][j]; v2[j].y += acc[r][4 * C::N4 + 1][j];
+            *reinterpret_cast<float2 *>(d[j] + 64 * C::N4 + 2 * l15) = v2[j];
+          }
+          if (C::N1) d[j][64 * C::N4 + 32 * C::N2 + l15] = v1[j] + acc[r][NCTT - 1][j];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) __hip_atomic_store(commit, grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    cur = nxt;
+    i = in;
+  }
+  __syncthreads();
+  // epilogue: fp32 tile (+ fp32 bias) -> halfs, 8-byte stores, every dst row written once
+  const int rows = (int)((a.n_dst - row0) < (int64_t)T ? (a.n_dst - row0) : (int64_t)T);
+  for (int e = tid; e < rows * (C::CT / 4); e += C::NT) {
+    const int r = e / (C::CT / 4), cq = (e % (C::CT / 4)) * 4;
+    if (n0 + cq < a.cout) {
+      float4 v = *reinterpret_cast<const float4 *>(acc_l + r * C::ACS + cq);
+      if (a.bias) {
+        const float4 b = *reinterpret_cast<const float4 *>(a.bias + n0 + cq);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      uint2 o;
+      o.x = f2h(HT{}, v.x) | ((uint32_t)f2h(HT{}, v.y) << 16);
+      o.y = f2h(HT{}, v.z) | ((uint32_t)f2h(HT{}, v.w) << 16);
+      *reinterpret_cast<uint2 *>(a.dst + (row0 + r) * a.cout + n0 + cq) = o;
+    }
+  }
+}
+
+template <typename HT, int NCTT, int NW, int MINW, int R>
+int launch_conv5h(const ConvArgsH &a, hipStream_t st) {
+  using C = Conv5hCfg<NCTT, NW, R>;
+  const int64_t nblocks = a.ntiles * a.ncoltiles;
+  if (nblocks <= 0) return PCS_OK;
+  if (nblocks > 0x7FFFFFFF) { set_error("pcs_conv_h: grid too large"); return PCS_EUNSUPPORTED; }
+  auto kern = conv_os5h_kernel<HT, NCTT, NW, MINW, R>;
+  const size_t lds = C::lds_bytes(a.tile_rows);
+  if (lds > kMaxDynLds) { set_error("pcs_conv_h: tile_rows too large for this column tile"); return PCS_EUNSUPPORTED; }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(C::NT), lds, st, a);
+  return check_launch("pcs_conv_gather_gemm_h(wave5h)");
+}
+
+template <typename HT>
+int launch_h(ConvArgsH a, hipStream_t st) {
+  const int nctt = conv_nctt(a.cout);
+  a.ncoltiles = (int)ceil_div(a.cout, 16 * nctt);
+  const size_t lds = (size_t)((a.tile_rows + 1) * (16 * nctt + 4)) * 4 + 1024;
+  const bool nw8 = 2 * lds > 160 * 1024;  // 4-wave workgroups while two of them fit a CU's LDS, else one 8-wave workgroup
+  static const int rr = getenv("PCS_CONVH_R") ? atoi(getenv("PCS_CONVH_R")) : 2;  // debug: row blocks per group (2 / 4)
+#define PCS_CONV5H_CASE(N)                                                                          \
+  case N:                                                                                           \
+    if constexpr (N <= 4) {                                                                         \
+      if (rr == 4) return nw8 ? launch_conv5h<HT, N, 8, 2, 4>(a, st) : launch_conv5h<HT, N, 4, 2, 4>(a, st); \
+    }                                                                                               \
+    return nw8 ? launch_conv5h<HT, N, 8, 2, 2>(a, st) : launch_conv5h<HT, N, 4, 2, 2>(a, st);
+  switch (nctt) {
+    PCS_CONV5H_CASE(2)
+    PCS_CONV5H_CASE(4)
+    PCS_CONV5H_CASE(6)
+    PCS_CONV5H_CASE(8)
+  }
+#undef PCS_CONV5H_CASE
+  set_error("pcs_conv_gather_gemm_h: unreachable");
+  return PCS_EINVAL;
+}
+
+}  // namespace
+
+extern "C" size_t pcs_conv_prepared_weights_bytes(int32_t K, int32_t ccon, int32_t ccols) {
+  if (K <= 0 || ccon <= 0 || ccols <= 0 || ccon % 32) return 0;
+  return (size_t)K * (size_t)ceil_div(ccols, 16 * conv_nctt(ccols)) * conv_nctt(ccols) * (size_t)(ccon / 32) * 1024;
+}
+
+extern "C" int pcs_conv_h_applies(int32_t cin, int32_t cout, int32_t K) { return conv5_applies(cin, cout, K) ? 1 : 0; }
+
+extern "C" int pcs_conv_prepare_weights_h(const float *W, int32_t K, int32_t A, int32_t B, int32_t transpose, int32_t dtype,
+                                          void *Wp, void *stream) {
+  const int ccon = transpose ? B : A, ccols = transpose ? A : B;
+  if (K <= 0 || A <= 0 || B <= 0 || !W || !Wp || (dtype != 1 && dtype != 2) || !conv5_applies(ccon, ccols, K)) {
+    set_error("pcs_conv_prepare_weights_h: bad args / shape not served by the half kernels");
+    return PCS_EINVAL;
+  }
+  const int nctt = conv_nctt(ccols), nt16 = (int)ceil_div(ccols, 16 * nctt) * nctt, ns = ccon / 32;
+  const int64_t total = (int64_t)K * nt16 * ns * 64;
+  const int grid = stream_grid(total, 256);
+  if (dtype == 1)
+    hipLaunchKernelGGL(prepare_weights_kernel<Bf16>, dim3(grid), dim3(256), 0, as_stream(stream), W, K, A, B, transpose, nctt,
+                       nt16, ns, reinterpret_cast<uint4 *>(Wp));
+  else
+    hipLaunchKernelGGL(prepare_weights_kernel<Fp16>, dim3(grid), dim3(256), 0, as_stream(stream), W, K, A, B, transpose, nctt,
+                       nt16, ns, reinterpret_cast<uint4 *>(Wp));
+  return check_launch("pcs_conv_prepare_weights_h");
+}
+
+extern "C" int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t cin, const void *Wp, int32_t K, int32_t cout,
+                                      const int32_t *pairs, int32_t src_col, const int32_t *seg, int32_t tile_rows,
+                                      int64_t n_dst, const float *bias, void *dst, int32_t dtype, void *stream) {
+  if (cin <= 0 || cout <= 0 || K <= 0 || n_dst < 0 || n_src < 0 || (src_col != 0 && src_col != 1) || (dtype != 1 && dtype != 2)) {
+    set_error("pcs_conv_gather_gemm_h: bad sizes");
+    return PCS_EINVAL;
+  }
+  if (!conv5_applies(cin, cout, K)) { set_error("pcs_conv_gather_gemm_h: shape not served by the half kernels (needs cin %% 32 == 0, cin >= 64, cout %% 4 == 0)"); return PCS_EUNSUPPORTED; }
+  if (n_dst == 0) return PCS_OK;
+  if (!Wp || !seg || !dst || (n_src > 0 && !src)) { set_error("pcs_conv_gather_gemm_h: null pointer"); return PCS_EINVAL; }
+  if ((((uintptr_t)src | (uintptr_t)Wp | (uintptr_t)bias) & 15) || ((uintptr_t)dst & 7)) { set_error("pcs_conv_gather_gemm_h: misaligned pointer"); return PCS_EINVAL; }
+  if (tile_rows < 16 || tile_rows > 512 || tile_rows % 16) { set_error("pcs_conv_gather_gemm_h: tile_rows must be a multiple of 16 in [16, 512]"); return PCS_EINVAL; }
+  ConvArgsH a;
+  a.src = reinterpret_cast<const char *>(src); a.Wp = reinterpret_cast<const char *>(Wp); a.bias = bias;
+  a.dst = reinterpret_cast<uint16_t *>(dst); a.pairs = pairs; a.seg = seg;
+  a.n_dst = n_dst; a.ntiles = ceil_div(n_dst, tile_rows); a.tile_rows = tile_rows;
+  a.cin = cin; a.cout = cout; a.K = K; a.src_col = src_col; a.ncoltiles = 1; a.xcd_remap = 1;
+  const int nctt = conv_nctt(cout);
+  a.nt16 = (int)ceil_div(cout, 16 * nctt) * nctt;
+  a.ns = cin / 32;
+  return dtype == 1 ? launch_h<Bf16>(a, as_stream(stream)) : launch_h<Fp16>(a, as_stream(stream));
+}

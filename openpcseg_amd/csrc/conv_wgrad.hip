@@ -273,8 +273,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce4_kernel(const float *__restr
 // split; partial blocks go to the workspace and wgrad_reduce_kernel sums the splits in order.
 // ================================================================================================
 struct Wgrad2Args {
-  const float *fa;
-  const float *fb;
+  const void *fa;  // rows of ET (float, or bf16 / fp16 halfs converted to fp32 on load)
+  const void *fb;
   const int32_t *pairs;
   const int32_t *koff;
   float *partial;  // [nsplit_total][ca][cb]
@@ -300,7 +300,30 @@ __device__ __forceinline__ float wcomp(const float3 &v, int i) { return i == 0 ?
 __device__ __forceinline__ float wcomp(const float2 &v, int i) { return i == 0 ? v.x : v.y; }
 __device__ __forceinline__ float wcomp(const float &v, int) { return v; }
 
-template <int AW, int BW>
+// N consecutive channels of one row -> a float vector. Fp32: one 4..16-byte load; halfs: one 2..8-byte load (three
+// 2-byte loads for the 48-wide groups, whose 6-byte pieces are only 2-byte aligned), widened in registers.
+template <typename V, int N> __device__ __forceinline__ V wload(Fp32, const void *base, int64_t elem) {
+  return *reinterpret_cast<const V *>(reinterpret_cast<const float *>(base) + elem);
+}
+template <typename V, int N, typename HT> __device__ __forceinline__ V wload(HT, const void *base, int64_t elem) {
+  const uint16_t *p = reinterpret_cast<const uint16_t *>(base) + elem;
+  V v;
+  if constexpr (N == 4) {
+    const uint2 r = *reinterpret_cast<const uint2 *>(p);
+    v.x = h2f(HT{}, (uint16_t)(r.x & 0xFFFFu)); v.y = h2f(HT{}, (uint16_t)(r.x >> 16));
+    v.z = h2f(HT{}, (uint16_t)(r.y & 0xFFFFu)); v.w = h2f(HT{}, (uint16_t)(r.y >> 16));
+  } else if constexpr (N == 3) {
+    v.x = h2f(HT{}, p[0]); v.y = h2f(HT{}, p[1]); v.z = h2f(HT{}, p[2]);
+  } else if constexpr (N == 2) {
+    const uint32_t r = *reinterpret_cast<const uint32_t *>(p);
+    v.x = h2f(HT{}, (uint16_t)(r & 0xFFFFu)); v.y = h2f(HT{}, (uint16_t)(r >> 16));
+  } else {
+    v = h2f(HT{}, p[0]);
+  }
+  return v;
+}
+
+template <int AW, int BW, typename ET>
 __device__ __forceinline__ void wgrad_block(const Wgrad2Args &w, int a0, int b0, int beg, int end,
                                             float *out, int lane) {
   using AV = typename WVec<AW>::T;
@@ -330,8 +353,8 @@ __device__ __forceinline__ void wgrad_block(const Wgrad2Args &w, int a0, int b0,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ra = __shfl(ia, 4 * j + g, 64), rb = __shfl(ib, 4 * j + g, 64);
-      bt.a[j] = *reinterpret_cast<const AV *>(w.fa + (int64_t)ra * w.ca + acl);
-      bt.b[j] = *reinterpret_cast<const BV *>(w.fb + (int64_t)rb * w.cb + bcl);
+      bt.a[j] = wload<AV, NA>(ET{}, w.fa, (int64_t)ra * w.ca + acl);
+      bt.b[j] = wload<BV, NB>(ET{}, w.fb, (int64_t)rb * w.cb + bcl);
     }
   };
   auto mfma_batch = [&](const Batch &bt, int p0) {
@@ -379,6 +402,7 @@ __device__ __forceinline__ void wgrad_block(const Wgrad2Args &w, int a0, int b0,
   }
 }
 
+template <typename ET>
 __global__ void __launch_bounds__(256, 3) wgrad2_kernel(Wgrad2Args w) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int beg, end;
@@ -390,7 +414,7 @@ __global__ void __launch_bounds__(256, 3) wgrad2_kernel(Wgrad2Args w) {
   const int aw = wg_gwidth(w.ca), bw = wg_gwidth(w.cb);
   float *out = w.partial + (int64_t)blockIdx.x * w.ca * w.cb;
   const int a0 = aw * ag, b0 = bw * bg;
-#define PCS_WG_CASE(A, B) if (aw == A && bw == B) { wgrad_block<A, B>(w, a0, b0, beg, end, out, lane); return; }
+#define PCS_WG_CASE(A, B) if (aw == A && bw == B) { wgrad_block<A, B, ET>(w, a0, b0, beg, end, out, lane); return; }
   PCS_WG_CASE(64, 64) PCS_WG_CASE(64, 48) PCS_WG_CASE(64, 32) PCS_WG_CASE(64, 16)
   PCS_WG_CASE(48, 64) PCS_WG_CASE(48, 48) PCS_WG_CASE(48, 32) PCS_WG_CASE(48, 16)
   PCS_WG_CASE(32, 64) PCS_WG_CASE(32, 48) PCS_WG_CASE(32, 32) PCS_WG_CASE(32, 16)
@@ -425,11 +449,13 @@ extern "C" size_t pcs_conv_wgrad_ws_bytes(const int32_t *koff_host, int32_t K, i
   return (size_t)(ns > 0 ? ns : 1) * ca * cb * sizeof(float);
 }
 
-extern "C" int pcs_conv_wgrad_f32(const float *fa, int32_t ca, const float *fb, int32_t cb,
-                                  const int32_t *pairs, int32_t a_col, const int32_t *koff_dev,
-                                  const int32_t *koff_host, int32_t K, float *gW, void *ws,
-                                  size_t ws_bytes, void *stream) {
-  if (ca <= 0 || cb <= 0 || K <= 0 || !koff_dev || !koff_host || !gW || (a_col != 0 && a_col != 1)) {
+// dtype 0: fp32 operands; 1 / 2: bf16 / fp16 operands (the weight gradient is accumulated and returned in fp32)
+static int conv_wgrad_any(const void *fa_v, int32_t ca, const void *fb_v, int32_t cb,
+                          const int32_t *pairs, int32_t a_col, const int32_t *koff_dev,
+                          const int32_t *koff_host, int32_t K, float *gW, void *ws,
+                          size_t ws_bytes, int dtype, void *stream) {
+  const float *fa = reinterpret_cast<const float *>(fa_v), *fb = reinterpret_cast<const float *>(fb_v);
+  if (ca <= 0 || cb <= 0 || K <= 0 || !koff_dev || !koff_host || !gW || (a_col != 0 && a_col != 1) || dtype < 0 || dtype > 2) {
     set_error("pcs_conv_wgrad_f32: bad args");
     return PCS_EINVAL;
   }
@@ -447,16 +473,19 @@ extern "C" int pcs_conv_wgrad_f32(const float *fa, int32_t ca, const float *fb, 
   w.fa = fa; w.fb = fb; w.pairs = pairs; w.koff = koff_dev; w.partial = reinterpret_cast<float *>(ws);
   w.ca = ca; w.cb = cb; w.K = K; w.a_col = a_col; w.pch = pch;
   const bool vec = (ca % 4 == 0) && (cb % 4 == 0) && (((uintptr_t)fa | (uintptr_t)fb) & 15) == 0;
+  if (dtype != 0 && !vec) { set_error("pcs_conv_wgrad_h: half operands need channel counts that are multiples of 4 and 16-byte aligned tensors"); return PCS_EUNSUPPORTED; }
   if (vec) {
     Wgrad2Args w2;
     w2.fa = fa; w2.fb = fb; w2.pairs = pairs; w2.koff = koff_dev; w2.partial = reinterpret_cast<float *>(ws);
     w2.ca = ca; w2.cb = cb; w2.K = K; w2.a_col = a_col; w2.pch = pch; w2.nbg = wg_ngroups(cb);
     const int nblk = wg_ngroups(ca) * wg_ngroups(cb);
-    hipLaunchKernelGGL(wgrad2_kernel, dim3((unsigned)ns, (unsigned)ceil_div(nblk, 4)), dim3(256), 0, st, w2);
+    const dim3 grid2((unsigned)ns, (unsigned)ceil_div(nblk, 4));
+    if (dtype == 0) hipLaunchKernelGGL(wgrad2_kernel<Fp32>, grid2, dim3(256), 0, st, w2);
+    else if (dtype == 1) hipLaunchKernelGGL(wgrad2_kernel<Bf16>, grid2, dim3(256), 0, st, w2);
+    else hipLaunchKernelGGL(wgrad2_kernel<Fp16>, grid2, dim3(256), 0, st, w2);
   } else {
     dim3 grid((unsigned)ns, (unsigned)ceil_div(ca, 128), (unsigned)ceil_div(cb, 128));
-    if (vec) hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(256), 0, st, w);
-    else hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(256), 0, st, w);
+    hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(256), 0, st, w);
   }
   int rc = check_launch("pcs_conv_wgrad_f32");
   if (rc) return rc;
@@ -470,4 +499,19 @@ extern "C" int pcs_conv_wgrad_f32(const float *fa, int32_t ca, const float *fb, 
                        reinterpret_cast<const float *>(ws), koff_dev, (int)K, pch, cc, gW);
   }
   return check_launch("pcs_conv_wgrad_f32(reduce)");
+}
+
+extern "C" int pcs_conv_wgrad_f32(const float *fa, int32_t ca, const float *fb, int32_t cb,
+                                  const int32_t *pairs, int32_t a_col, const int32_t *koff_dev,
+                                  const int32_t *koff_host, int32_t K, float *gW, void *ws,
+                                  size_t ws_bytes, void *stream) {
+  return conv_wgrad_any(fa, ca, fb, cb, pairs, a_col, koff_dev, koff_host, K, gW, ws, ws_bytes, 0, stream);
+}
+
+extern "C" int pcs_conv_wgrad_h(const void *fa, int32_t ca, const void *fb, int32_t cb,
+                                const int32_t *pairs, int32_t a_col, const int32_t *koff_dev,
+                                const int32_t *koff_host, int32_t K, float *gW, void *ws,
+                                size_t ws_bytes, int32_t dtype, void *stream) {
+  if (dtype != 1 && dtype != 2) { set_error("pcs_conv_wgrad_h: dtype must be 1 (bf16) or 2 (fp16)"); return PCS_EINVAL; }
+  return conv_wgrad_any(fa, ca, fb, cb, pairs, a_col, koff_dev, koff_host, K, gW, ws, ws_bytes, dtype, stream);
 }

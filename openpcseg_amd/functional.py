@@ -12,8 +12,9 @@ Internals differ: every op is one or a few C-ABI calls (openpcseg_amd.native); t
 built by a fused probe/compaction pass instead of kernel_hash -> hashquery -> sum -> nonzero,
 and the convolution is an output-stationary fused gather-GEMM (no per-offset launches, no
 `nbsizes.cpu()` per call).
-Autocast: the reference casts op inputs to fp16 under AMP (`custom_fwd(cast_inputs=torch.half)`);
-this round the kernels are fp32, so under autocast inputs are cast to fp32 instead.
+Autocast: the reference casts op inputs to fp16 under AMP (`custom_fwd(cast_inputs=torch.half)`). Here conv3d follows
+the autocast dtype (bf16 or fp16) on the 16-bit MFMA kernels (`_SparseConv`); voxelize / devoxelize keep fp32 (at
+least the reference's precision).
 """
 import torch
 from torch.autograd import Function
@@ -165,36 +166,75 @@ def build_kernel_map(in_coords, out_coords, kernel_size, in_stride, dilation):
     return KmapEntry(fwd, in_coords, out_coords, offsets, symmetric, hint_key)
 
 
+_HALF = (torch.bfloat16, torch.float16)
+
+
+def _amp_dtype(t):
+    """The half dtype this op computes in, or None for fp32: the input's own dtype when it already is half, else the
+    autocast dtype while autocast is on (the reference casts op inputs to half under AMP,
+    TS:torchsparse/nn/functional/conv.py:19 `custom_fwd(cast_inputs=torch.half)`)."""
+    if t.dtype in _HALF:
+        return t.dtype
+    if t.is_cuda and torch.is_autocast_enabled("cuda"):
+        d = torch.get_autocast_dtype("cuda")
+        return d if d in _HALF else None
+    return None
+
+
 class _SparseConv(Function):
     """out = conv(input) over a kernel map; backward = dgrad (same fused kernel on the other
-    map, per-offset transposed weights) + wgrad (split reduction)."""
+    map, per-offset transposed weights) + wgrad (split reduction).
+
+    Mixed precision (autocast, or half features in): layers the half kernels serve (cin, cout >= 64-class shapes,
+    pcs_conv_h_applies) run on the 16-bit MFMA kernels -- features and outputs in bf16 / fp16, weights re-packed
+    from the fp32 master copy per call, fp32 accumulation, fp32 weight gradient; the remaining thin layers are
+    computed in fp32 and their output rounded to the half dtype, like the reference's half pipeline would hand on."""
 
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, input, weight, entry, transposed):
-        input = input.contiguous()
-        weight = weight.contiguous()
+        be = _be()
+        hd = _amp_dtype(input)
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
+        k, cin, cout = w3.shape
         kmap = entry.rev if transposed else entry.fwd
-        out = _be().conv_gather_gemm(input, w3, kmap)
-        ctx.for_backwards = (input, weight, entry, transposed)
+        if hd is not None and input.is_cuda and be.conv_h_applies(cin, cout, k):
+            x = input.contiguous().to(hd)
+            wp = be.prepare_weights_h(w3.detach().float().contiguous(), hd, transpose=False)
+            out = be.conv_gather_gemm_h(x, wp, k, cout, kmap)
+        else:
+            x = input.contiguous().float()
+            out = be.conv_gather_gemm(x, w3.float().contiguous(), kmap)
+            if hd is not None:
+                out = out.to(hd)
+        ctx.for_backwards = (x, weight, entry, transposed, hd)
         return out
 
     @staticmethod
-    @custom_bwd(device_type="cuda")
     def backward(ctx, grad_output):
-        input, weight, entry, transposed = ctx.for_backwards
-        grad_output = grad_output.contiguous()
+        be = _be()
+        x, weight, entry, transposed, hd = ctx.for_backwards
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
+        k, cin, cout = w3.shape
         grad_input = grad_weight = None
         if ctx.needs_input_grad[0]:
-            wt = _be().transpose_weights(w3)
-            grad_input = _be().conv_gather_gemm(grad_output, wt, entry.fwd if transposed else entry.rev)
+            dmap = entry.fwd if transposed else entry.rev
+            if hd is not None and be.conv_h_applies(cout, cin, k):
+                wp = be.prepare_weights_h(w3.detach().float().contiguous(), hd, transpose=True)
+                grad_input = be.conv_gather_gemm_h(grad_output.contiguous().to(hd), wp, k, cin, dmap)
+            else:
+                wt = be.transpose_weights(w3.detach().float().contiguous())
+                grad_input = be.conv_gather_gemm(grad_output.contiguous().float(), wt, dmap)
+            # the gradient leaves in the dtype the forward input arrived in (what autograd expects)
+            grad_input = grad_input.to(x.dtype if hd is None else hd)
         if ctx.needs_input_grad[1]:
             # fwd pairs are (in_row, out_row) of the NON-transposed conv; a transposed conv's
             # input lives on the out rows (column 1)
-            grad_weight = _be().conv_wgrad(input, grad_output, entry.fwd, 1 if transposed else 0)
-            grad_weight = grad_weight.view_as(weight)
+            a_col = 1 if transposed else 0
+            if x.dtype in _HALF and cin % 4 == 0 and cout % 4 == 0:
+                grad_weight = be.conv_wgrad_h(x, grad_output.contiguous().to(x.dtype), entry.fwd, a_col)
+            else:
+                grad_weight = be.conv_wgrad(x.float(), grad_output.contiguous().float(), entry.fwd, a_col)
+            grad_weight = grad_weight.view_as(weight).to(weight.dtype)
         return grad_input, grad_weight, None, None
 
 
@@ -217,22 +257,33 @@ class _PointwiseConv(Function):
     million-row contraction, which hipBLASLt runs on ~12 workgroups -- the split-reduction wgrad kernel is used."""
 
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, feats, weight, cache):
+        hd = _amp_dtype(feats)
         ctx.save_for_backward(feats, weight)
-        ctx.cache = cache
-        return feats.matmul(weight)
+        ctx.cache, ctx.hd = cache, hd
+        if hd is None:
+            return feats.float().matmul(weight.float())
+        return feats.to(hd).matmul(weight.to(hd))  # hipBLASLt, fp32 accumulate
 
     @staticmethod
-    @custom_bwd(device_type="cuda")
     def backward(ctx, grad_output):
         feats, weight = ctx.saved_tensors
         grad_output = grad_output.contiguous()
-        gin = grad_output.matmul(weight.t()) if ctx.needs_input_grad[0] else None
-        gw = None
+        hd = ctx.hd
+        gin = gw = None
+        if ctx.needs_input_grad[0]:
+            if hd is None:
+                gin = grad_output.float().matmul(weight.float().t())
+            else:
+                gin = grad_output.to(hd).matmul(weight.to(hd).t())
         if ctx.needs_input_grad[1]:
             km = _identity_map(feats.shape[0], feats.device, ctx.cache)
-            gw = _be().conv_wgrad(feats.contiguous(), grad_output, km, 0)[0]
+            ca, cb = feats.shape[1], grad_output.shape[1]
+            if hd is not None and ca % 4 == 0 and cb % 4 == 0:
+                gw = _be().conv_wgrad_h(feats.contiguous().to(hd), grad_output.to(hd), km, 0)[0]
+            else:
+                gw = _be().conv_wgrad(feats.contiguous().float(), grad_output.float(), km, 0)[0]
+            gw = gw.to(weight.dtype)
         return gin, gw, None
 
 

@@ -65,6 +65,12 @@ SIGNATURES = {
     "pcs_quantize_keys": (c_int32, [_P, c_int64, _P, _P, _P]),
     "pcs_quantize_flags": (c_int32, [_P, c_int64, _P, _P]),
     "pcs_quantize_emit": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "pcs_conv_h_applies": (c_int32, [c_int32, c_int32, c_int32]),
+    "pcs_conv_prepared_weights_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "pcs_conv_prepare_weights_h": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "pcs_conv_gather_gemm_h": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32, _P, c_int32, c_int64,
+                                         _P, _P, c_int32, _P]),
+    "pcs_conv_wgrad_h": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P, _P, c_size_t, c_int32, _P]),
     "pcs_cylinder_partition_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "pcs_voxel_label_vote": (c_int32, [_P, _P, c_int64, c_int64, c_int32, c_int64, _P, _P, _P, _P]),
     "pcs_rows_argmax_gather_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
@@ -492,6 +498,58 @@ class HipBackend:
                                                  _ptr(bias) if bias is not None else None, _ptr(dst),
                                                  _stream()), "pcs_conv_gather_gemm_f32")
         return dst
+
+    # -- half-precision convolution (bf16 / fp16 MFMA) ------------------------------------------------------
+    _HALF = {torch.bfloat16: 1, torch.float16: 2}
+
+    def conv_h_applies(self, cin, cout, k):
+        return bool(self.lib.pcs_conv_h_applies(int(cin), int(cout), int(k)))
+
+    def prepare_weights_h(self, weight, dtype, transpose):
+        """fp32 master weights (K, A, B) -> fragment-ordered `dtype` weights for the half kernels (uint8 buffer).
+        transpose=False: forward (contract over A); True: dgrad (contract over B)."""
+        weight = _dev(weight, "weight", torch.float32)
+        k, a, b = weight.shape
+        con, cols = (b, a) if transpose else (a, b)
+        nbytes = self.lib.pcs_conv_prepared_weights_bytes(k, con, cols)
+        if nbytes == 0:
+            raise RuntimeError("openpcseg_amd: shape (%d, %d, %d) is not served by the half-precision kernels" % (k, a, b))
+        wp = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+        _check(self.lib.pcs_conv_prepare_weights_h(_ptr(weight), k, a, b, int(bool(transpose)), self._HALF[dtype], _ptr(wp),
+                                                   _stream()), "pcs_conv_prepare_weights_h")
+        return wp
+
+    def conv_gather_gemm_h(self, src, wp, k, cout, kmap, bias=None, tile_rows=None):
+        """Half-precision fused conv: src (n, cin) bf16 / fp16, wp = prepare_weights_h(...) of the same dtype."""
+        if src.dtype not in self._HALF:
+            raise TypeError("openpcseg_amd: conv_gather_gemm_h wants bfloat16 / float16 features, got %s" % src.dtype)
+        src = _dev(src, "input")
+        cin = src.shape[1]
+        if k != kmap.K:
+            raise ValueError("kernel volume %d does not match the kernel map (%d)" % (k, kmap.K))
+        if bias is not None:
+            bias = _dev(bias, "bias", torch.float32)
+        t = tile_rows or self.tile_rows(cin, cout, kmap)
+        seg = self._segments(kmap, t)
+        dst = torch.empty((kmap.n_dst, cout), dtype=src.dtype, device=src.device)
+        _check(self.lib.pcs_conv_gather_gemm_h(_ptr(src), src.shape[0], cin, _ptr(wp), k, cout, _ptr(kmap._pairs_raw), 0,
+                                               _ptr(seg), t, kmap.n_dst, _ptr(bias) if bias is not None else None,
+                                               _ptr(dst), self._HALF[src.dtype], _stream()), "pcs_conv_gather_gemm_h")
+        return dst
+
+    def conv_wgrad_h(self, fa, fb, kmap, a_col):
+        """Weight gradient from half operands, accumulated and returned in fp32 (K, ca, cb)."""
+        if fa.dtype not in self._HALF or fb.dtype != fa.dtype:
+            raise TypeError("openpcseg_amd: conv_wgrad_h wants two tensors of the same half dtype")
+        fa, fb = _dev(fa, "input"), _dev(fb, "grad_output")
+        ca, cb = fa.shape[1], fb.shape[1]
+        gw = torch.empty((kmap.K, ca, cb), dtype=torch.float32, device=fa.device)
+        ws_bytes = self.lib.pcs_conv_wgrad_ws_bytes(kmap._koff_c, kmap.K, ca, cb)
+        ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=fa.device)
+        _check(self.lib.pcs_conv_wgrad_h(_ptr(fa), ca, _ptr(fb), cb, _ptr(kmap.pairs), a_col, _ptr(kmap.koff),
+                                         kmap._koff_c, kmap.K, _ptr(gw), _ptr(ws), ws_bytes, self._HALF[fa.dtype],
+                                         _stream()), "pcs_conv_wgrad_h")
+        return gw
 
     def transpose_weights(self, w):
         """(K, A, B) -> (K, B, A) contiguous: the weights dgrad contracts with."""

@@ -161,3 +161,99 @@ def test_rulebook_bench_batch_bit_exact(hip):
     e2 = F.build_kernel_map(d1, out, (2, 2, 2), (1, 1, 1), (1, 1, 1))
     nb2, ns2 = orc.build_kmap(c1, lv[2], 2, 1)
     assert np.array_equal(e2[1].cpu().numpy(), ns2) and np.array_equal(e2[0].cpu().numpy().astype(np.int64), nb2)
+
+
+# ---- half-precision path (bf16 / fp16 storage, 16-bit MFMA, fp32 accumulate) -------------------------------------
+def _round_half(a, dtype):
+    """fp32 array -> the nearest bf16 / fp16 values, as fp32 (what the kernels see as their operands)."""
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).float().numpy()
+
+
+# rounding of the stored output: half an ulp = 2^-9 (bf16, 8 significand bits) / 2^-12 (fp16, 11 bits) of the value, plus
+# the fp32 accumulation-order term of the fp32 tests relative to the tensor maximum
+_HALF_TOL = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
+
+
+def close_half(y, ref, dtype):
+    y = y.detach().float().cpu().numpy().astype(np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert y.shape == ref.shape
+    bound = _HALF_TOL[dtype] * np.abs(ref) + 4e-5 * max(np.abs(ref).max(), 1e-6)
+    bad = np.abs(y - ref) > bound
+    assert not bad.any(), (int(bad.sum()), float(np.abs(y - ref).max()), float(np.abs(ref).max()))
+
+
+HALF_CASES = [(4, 128, 128, None), (4, 192, 128, 128), (8, 256, 256, None), (8, 384, 256, 256), (1, 96, 96, 384),
+              (1, 128, 96, None), (2, 64, 64, None), (4, 160, 96, 112), (8, 256, 20, None)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("stride,cin,cout,tile", HALF_CASES)
+def test_half_conv_forward_dense_map(hip, levels, dtype, stride, cin, cout, tile):
+    """conv_os5h_kernel vs the oracle run on the SAME half-rounded operands in fp32 (the 16-bit MFMA multiplies
+    exactly and accumulates in fp32, so only the output rounding separates the two); odd step counts (cin = 160, 96),
+    partial column tiles (cout = 20, 96) and forced tile heights included; bit-reproducible."""
+    entry, nbmaps, nbsizes, n = level_map(levels, stride)
+    rng = np.random.default_rng(stride * 100000 + cin * 100 + cout + 7)
+    x = _round_half(rng.normal(size=(n, cin)).astype(np.float32), dtype)
+    w = _round_half((rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32), dtype)
+    bias = rng.normal(size=cout).astype(np.float32)
+    wp = hip.prepare_weights_h(t(w), dtype, transpose=False)
+    dx = t(x).to(dtype)
+    y = hip.conv_gather_gemm_h(dx, wp, 27, cout, entry.fwd, tile_rows=tile)
+    assert y.dtype == dtype and y.shape == (n, cout)
+    ref = orc.conv_fwd(x, w, nbmaps, nbsizes, (n, n))
+    close_half(y, ref, dtype)
+    assert torch.equal(y, hip.conv_gather_gemm_h(dx, wp, 27, cout, entry.fwd, tile_rows=tile))
+    yb = hip.conv_gather_gemm_h(dx, wp, 27, cout, entry.fwd, bias=t(bias), tile_rows=tile)
+    close_half(yb, ref + bias[None, :], dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("stride,cin,cout", [(4, 128, 128), (8, 384, 256), (1, 128, 96)])
+def test_half_conv_backward_dense_map(hip, levels, dtype, stride, cin, cout):
+    """dgrad on the half kernel (weights re-packed with transpose=True) and the fp32-accumulated weight gradient from
+    half operands (pcs_conv_wgrad_h) vs orc_conv_bwd on the half-rounded operands."""
+    entry, nbmaps, nbsizes, n = level_map(levels, stride)
+    rng = np.random.default_rng(stride * 100000 + cin * 100 + cout + 9)
+    x = _round_half(rng.normal(size=(n, cin)).astype(np.float32), dtype)
+    gy = _round_half(rng.normal(size=(n, cout)).astype(np.float32), dtype)
+    w = _round_half((rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32), dtype)
+    ogx, ogw = orc.conv_bwd(x, gy, w, nbmaps, nbsizes)
+    wpt = hip.prepare_weights_h(t(w), dtype, transpose=True)
+    gx = hip.conv_gather_gemm_h(t(gy).to(dtype), wpt, 27, cin, entry.rev)
+    close_half(gx, ogx, dtype)
+    gw = hip.conv_wgrad_h(t(x).to(dtype), t(gy).to(dtype), entry.fwd, 0)
+    assert gw.dtype == torch.float32
+    close(gw, ogw, 2e-5)   # exact products of half operands, fp32 accumulation: the fp32 bound holds
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv3d_under_autocast(hip, levels, dtype):
+    """conv3d under torch.autocast: >= 64-channel layers on the 16-bit MFMA kernels (half out), thin layers in fp32
+    with a half-rounded output; gradients reach the fp32 master weights in fp32 and agree with the fp32 path to
+    half precision."""
+    from openpcseg_amd import functional as F
+    from openpcseg_amd.sparse import SparseTensor
+    c = t(levels[4])
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(c.shape[0], 64, device=DEV, generator=g)
+    w1 = (torch.randn(27, 64, 128, device=DEV, generator=g) * 0.03).requires_grad_(True)
+    w2 = (torch.randn(27, 128, 16, device=DEV, generator=g) * 0.03).requires_grad_(True)
+
+    def run(amp):
+        for w in (w1, w2):
+            w.grad = None
+        xs = SparseTensor(x.clone().requires_grad_(True), c, 4)
+        with torch.autocast("cuda", dtype=dtype, enabled=amp):
+            h = F.conv3d(xs, w1, 3)
+            y = F.conv3d(h, w2, 3)
+        y.F.float().square().sum().backward()
+        return h.F, y.F, w1.grad.clone(), w2.grad.clone(), xs.F.grad.clone()
+
+    h32, y32, g1, g2, gx = run(False)
+    hh, yh, g1h, g2h, gxh = run(True)
+    assert hh.dtype == dtype and yh.dtype == dtype and g1h.dtype == torch.float32 and gxh.dtype == torch.float32
+    tol = 40 * _HALF_TOL[dtype]
+    for a, b in ((hh, h32), (yh, y32), (g1h, g1), (g2h, g2), (gxh, gx)):
+        assert (a.float() - b).abs().max() <= tol * b.abs().max(), ((a.float() - b).abs().max(), b.abs().max())
