@@ -33,55 +33,79 @@ from openpcseg_amd.workloads.minkunet import MK34_LAYERS, MinkUNet  # noqa: E402
 from openpcseg_amd.workloads.synthetic import make_batch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 POINTS_PER_FRAME = 120000
 
 
 class ConvMeter:
-    """Wraps the backend's fused conv launch: HIP events on the launch stream (torch's current
-    stream IS the stream the C ABI launches on) + algorithmic flops 2*P*Cin*Cout per launch."""
+    """Wraps the backend's fused conv launches (fp32: conv_gather_gemm, half: conv_gather_gemm_h): HIP events on the
+    launch stream (torch's current stream IS the stream the C ABI launches on) + the algorithmic work per launch,
+    2*P*Cin*Cout flop and e*(Nin*Cin + Nout*Cout) + 8P + e*K*Cin*Cout bytes."""
 
     def __init__(self, be):
-        self.be, self.orig = be, be.conv_gather_gemm
+        self.be = be
+        self.orig = {"f32": be.conv_gather_gemm, "half": be.conv_gather_gemm_h}
         self.records, self.enabled = [], False
 
     def __enter__(self):
-        def wrapped(src, weight, kmap, bias=None, tile_rows=None):
+        def timed(call, kind, kmap, k, cin, cout, n_src):
             if not self.enabled:
-                return self.orig(src, weight, kmap, bias, tile_rows)
+                return call()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = self.orig(src, weight, kmap, bias, tile_rows)
+            out = call()
             e1.record()
-            self.records.append((e0, e1, kmap, tuple(weight.shape), src.shape[0]))  # pair counts are read at summary time
+            self.records.append((e0, e1, kmap, (k, cin, cout), n_src, kind))  # pair counts are read at summary time
             return out
-        self.be.conv_gather_gemm = wrapped
+
+        def wrapped32(src, weight, kmap, bias=None, tile_rows=None):
+            k, cin, cout = weight.shape
+            return timed(lambda: self.orig["f32"](src, weight, kmap, bias, tile_rows), "f32", kmap, k, cin, cout, src.shape[0])
+
+        def wrapped16(src, wp, k, cout, kmap, bias=None, tile_rows=None):
+            return timed(lambda: self.orig["half"](src, wp, k, cout, kmap, bias, tile_rows), "half", kmap, k, src.shape[1],
+                         cout, src.shape[0])
+        self.be.conv_gather_gemm, self.be.conv_gather_gemm_h = wrapped32, wrapped16
         return self
 
     def __exit__(self, *a):
-        self.be.conv_gather_gemm = self.orig
+        self.be.conv_gather_gemm, self.be.conv_gather_gemm_h = self.orig["f32"], self.orig["half"]
 
-    def summary(self):
-        if not self.records:
+    def summary(self, amp):
+        kind = "half" if amp else "f32"
+        recs = [r for r in self.records if r[5] == kind]
+        if not recs:
             return None
-        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        e = 2.0 if amp else 4.0
+        ms = sum(r[0].elapsed_time(r[1]) for r in recs)
         flops = abytes = 0.0
-        for _, _, kmap, (k, cin, cout), n_src in self.records:
+        for _, _, kmap, (k, cin, cout), n_src, _ in recs:
             p = kmap.num_pairs
             flops += 2.0 * p * cin * cout
-            abytes += 4.0 * (n_src * cin + kmap.n_dst * cout) + 8.0 * p + 4.0 * k * cin * cout
-        n = len(self.records)
-        achieved = flops / (ms * 1e-3) / 1e12
-        traffic = None  # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside bench.py)
-        tfile = os.path.join(ROOT, "profiles", "round1_conv_traffic.json")
+            abytes += e * (n_src * cin + kmap.n_dst * cout) + 8.0 * p + e * k * cin * cout
+        n = len(recs)
+        tflops = flops / (ms * 1e-3) / 1e12
+        common = {"launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": round(flops / n),
+                  "algorithmic_bytes_per_launch": round(abytes / n)}
+        if amp:
+            # 16-bit MFMA is 16x the fp32 rate: the fused conv is bound by bytes (SURVEY.md 8d: "HBM-bound in bf16"),
+            # priced on its ALGORITHMIC bytes (each feature row once, weights once, rulebook once)
+            gbs = abytes / (ms * 1e-3) / 1e9
+            return dict({"kernel": "conv_os5h_kernel (pcs_conv_gather_gemm_h: fwd + dgrad, %s)" % amp, "bound": "hbm",
+                         "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                         "traffic": None, "mfma_tflops": round(tflops, 1),
+                         "traffic_note": "no PMC pass for the half kernels yet; the operand stream (gathered rows re-read "
+                                         "per offset, weights per row-block group) comes out of L2"}, **common)
+        traffic, note = None, "no PMC traffic file matches this build"
+        tfile = os.path.join(ROOT, "profiles", "round2_conv_traffic.json")
         if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-        return {"kernel": "conv_os5_kernel / conv_os4_kernel (pcs_conv_gather_gemm_f32: fwd + dgrad)", "bound": "mfma",
-                "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, FETCH "
-                                "doubled per the gfx950 note), profiles/round1_conv_traffic.json",
-                "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
-                "flops_per_launch": round(flops / n), "algorithmic_bytes_per_launch": round(abytes / n)}
+            tj = json.load(open(tfile))
+            traffic = tj.get("hbm_bytes_per_launch")
+            note = tj.get("note", "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, FETCH doubled "
+                                  "per the gfx950 note), profiles/round2_conv_traffic.json")
+        return dict({"kernel": "conv_os5_kernel / conv_os4_kernel (pcs_conv_gather_gemm_f32: fwd + dgrad)", "bound": "mfma",
+                     "achieved": round(tflops, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": note}, **common)
 
 
 class ClockSampler:
@@ -278,6 +302,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-gpu", type=int, default=12)  # BATCH_SIZE_PER_GPU of minkunet_mk34_cr10.yaml
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--amp", choices=["off", "bf16", "fp16"], default="off",
+                    help="mixed precision like the reference's --amp (second bench line; the headline metric is fp32)")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -314,10 +340,26 @@ def main():
     batch = to_device(make_batch(seeds), dev)
     n_vox = batch["lidar"].C.shape[0]
 
+    amp = None if args.amp == "off" else args.amp
+    amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.amp)
+    scaler = torch.amp.GradScaler("cuda") if args.amp == "fp16" else None  # the reference scales fp16 losses (train.py)
+
     def step():
         opt.zero_grad(set_to_none=True)
-        out = model(fresh(batch))
-        out["loss"].backward()
+        if amp is None:
+            out = model(fresh(batch))
+            out["loss"].backward()
+        else:
+            with torch.autocast("cuda", dtype=amp_dtype):
+                out = model(fresh(batch))
+            if scaler is not None:
+                scaler.scale(out["loss"]).backward()
+                scaler.unscale_(opt)
+                torch.nn.utils.clip_grad_norm_(params, 10.0)
+                scaler.step(opt)
+                scaler.update()
+                return out["loss"]
+            out["loss"].backward()
         torch.nn.utils.clip_grad_norm_(params, 10.0)
         opt.step()
         return out["loss"]
@@ -340,11 +382,11 @@ def main():
                 dist.barrier()
             dt = time.perf_counter() - t0
         meter.enabled = False
-        roof = meter.summary()
+        roof = meter.summary(amp)
         clk = clocks.summary()
         if roof is not None:
             roof["clock"] = clk
-            if clk.get("sclk_mhz_mean"):
+            if clk.get("sclk_mhz_mean") and roof["bound"] == "mfma":
                 # the nominal peak is quoted at 2400 MHz; what the MFMA pipe could deliver at the clock this box held
                 roof["peak_at_measured_clock"] = round(PEAK_FP32_MFMA_TFLOPS * clk["sclk_mhz_mean"] / 2400.0, 1)
                 roof["frac_at_measured_clock"] = round(roof["achieved"] / roof["peak_at_measured_clock"], 4)
@@ -359,14 +401,16 @@ def main():
             "metric": "LiDAR frames/sec training MinkUNet-34 SemanticKITTI",
             "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": amp or "f32", "data": "synthetic",
             "config": {"workload": "MinkUNet-34 cr1.0 train step (fwd + CE/Lovasz + bwd + SGD), SemanticKITTI-shape "
-                                   "synthetic scans (120k pts, 0.05 m voxels), fp32",
+                                   "synthetic scans (120k pts, 0.05 m voxels), %s"
+                                   % ("fp32" if amp is None else "autocast %s (16-bit MFMA convs, fp32 accumulate / master "
+                                                                 "weights / wgrad / statistics)" % amp),
                        "frames_per_gpu": args.frames_per_gpu, "global_batch": args.frames_per_gpu * world,
                        "voxels_per_gpu_batch": n_vox, "parallelism": "dp%d" % world, "loss": round(float(loss.detach()), 4)},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and amp is None:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if distributed:

@@ -294,6 +294,17 @@ int pcs_bn_bwd_stats_f32(const float *dy, const float *x, const float *y, const 
 int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const uint32_t *mask, const double *stat,
                          const double *sums2, double count, const double *count_dev, const float *w, int64_t n,
                          int32_t c, int32_t relu, float *dx, float *dres, void *stream);
+/* the same four passes over bf16 (dtype 1) / fp16 (dtype 2) feature tensors (x, res, y, dy, dx, dres all in `dtype`):
+ * the mixed-precision pipeline of the reference (`--amp`), where the convolutions hand on halfs. Statistics,
+ * scale / shift and the arithmetic stay fp32 / double; rows need 8-byte alignment for the vector path. */
+int pcs_bn_stats_h(const void *x, int64_t n, int32_t c, int32_t dtype, float *partial_ws, double *sums, void *stream);
+int pcs_bn_apply_h(const void *x, const void *res, const double *stat, const float *w, const float *b, int64_t n,
+                   int32_t c, int32_t relu, int32_t dtype, void *y, uint32_t *mask, void *stream);
+int pcs_bn_bwd_stats_h(const void *dy, const void *x, const void *y, const uint32_t *mask, const double *stat, int64_t n,
+                       int32_t c, int32_t relu, int32_t dtype, float *partial_ws, double *sums2, void *stream);
+int pcs_bn_bwd_apply_h(const void *dy, const void *x, const void *y, const uint32_t *mask, const double *stat,
+                       const double *sums2, double count, const double *count_dev, const float *w, int64_t n,
+                       int32_t c, int32_t relu, int32_t dtype, void *dx, void *dres, void *stream);
 
 /* ---- device-side sparse_quantize ---------------------------------------------------------------
  * Replaces the dataloader-side NumPy voxel dedup TS:torchsparse/utils/quantize.py:9-46
@@ -321,8 +332,8 @@ int pcs_quantize_emit(const int32_t *flags, const int64_t *rank, const int64_t *
  * The mixed-precision path of the reference: under `--amp` its ops cast their inputs to half
  * (TS:torchsparse/nn/functional/conv.py:19) and convolution_cuda.cu:61,120-127 runs gather / mm / scatter
  * in half. dtype: 1 = bfloat16, 2 = float16 (features, prepared weights and outputs share it).
- * Served shapes: pcs_conv_h_applies(cin, cout, K) != 0 (cin % 32 == 0, cin >= 64, cout % 4 == 0, K <= 32) --
- * the >= 64-channel layers; callers convert other shapes to fp32 and use the _f32 entries.
+ * Served shapes: pcs_conv_h_applies(cin, cout, K) != 0 (cin % 32 == 0, cout % 4 == 0, an even number of
+ * 16-column tiles, K <= 32); callers convert other shapes (4/5-channel stems) to fp32 and use the _f32 entries.
  *   prepare : W (K, A, B) fp32 master weights -> Wp, the weights in MFMA fragment order, converted to `dtype`.
  *             transpose = 0: forward (contraction over A = cin, columns B = cout); transpose = 1: dgrad
  *             (contraction over B, columns A). Wp bytes = pcs_conv_prepared_weights_bytes(K, contraction, columns).

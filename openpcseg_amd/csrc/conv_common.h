@@ -71,6 +71,12 @@ inline bool conv5_applies(int cin, int cout, int K) {
   return cin % 32 == 0 && cin >= 64 && cout % 4 == 0 && K <= 32 && conv_nctt(cout) % 2 == 0;
 }
 
+// the half-precision wave kernel (conv_wave5h.hip) steps 32 channels per MFMA and needs no second pipeline stage:
+// every 16-byte-granular shape with a 32-channel contraction granule and an even column tile
+inline bool convh_applies(int cin, int cout, int K) {
+  return cin % 32 == 0 && cin >= 32 && cout % 4 == 0 && K <= 32 && conv_nctt(cout) % 2 == 0;
+}
+
 // launchers (each picks its template instance from the shape; `a.ncoltiles` is set inside)
 int launch_conv_block(ConvArgs a, bool vec, hipStream_t st);   // any shape; tile_rows 64 / 128
 int launch_conv_wave4(ConvArgs a, hipStream_t st);              // cin % 4 == 0, cout % 4 == 0, K <= 32; tile_rows 64 / 128

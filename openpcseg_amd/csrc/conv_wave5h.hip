@@ -13,8 +13,9 @@
 //     weights are converted in the same pass (no separate cast kernel), stored column-major per offset ([column][contraction]) for the forward pass and for dgrad alike;
 //   * column tile f of a 64-column quad owns columns 64 q + 4 n + f (as in the fp32 kernel), so the commit and the
 //     epilogue move 16-byte LDS words.
-// Requires cin % 32 == 0, cin >= 64, cout % 4 == 0 (conv5_applies): the >= 64-channel layers; other shapes are
-// converted to fp32 by the host layer and take the fp32 kernels.
+// Requires cin % 32 == 0, cout % 4 == 0 and an even number of 16-column tiles (convh_applies): every layer of the
+// segmentors except the 4/5-channel stems and the 1x1x1 convolutions; other shapes are converted to fp32 by the host
+// layer and take the fp32 kernels.
 #include "conv_common.h"
 
 using namespace pcs;
@@ -391,12 +392,12 @@ extern "C" size_t pcs_conv_prepared_weights_bytes(int32_t K, int32_t ccon, int32
   return (size_t)K * (size_t)ceil_div(ccols, 16 * conv_nctt(ccols)) * conv_nctt(ccols) * (size_t)(ccon / 32) * 1024;
 }
 
-extern "C" int pcs_conv_h_applies(int32_t cin, int32_t cout, int32_t K) { return conv5_applies(cin, cout, K) ? 1 : 0; }
+extern "C" int pcs_conv_h_applies(int32_t cin, int32_t cout, int32_t K) { return convh_applies(cin, cout, K) ? 1 : 0; }
 
 extern "C" int pcs_conv_prepare_weights_h(const float *W, int32_t K, int32_t A, int32_t B, int32_t transpose, int32_t dtype,
                                           void *Wp, void *stream) {
   const int ccon = transpose ? B : A, ccols = transpose ? A : B;
-  if (K <= 0 || A <= 0 || B <= 0 || !W || !Wp || (dtype != 1 && dtype != 2) || !conv5_applies(ccon, ccols, K)) {
+  if (K <= 0 || A <= 0 || B <= 0 || !W || !Wp || (dtype != 1 && dtype != 2) || !convh_applies(ccon, ccols, K)) {
     set_error("pcs_conv_prepare_weights_h: bad args / shape not served by the half kernels");
     return PCS_EINVAL;
   }
@@ -419,7 +420,7 @@ extern "C" int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t ci
     set_error("pcs_conv_gather_gemm_h: bad sizes");
     return PCS_EINVAL;
   }
-  if (!conv5_applies(cin, cout, K)) { set_error("pcs_conv_gather_gemm_h: shape not served by the half kernels (needs cin %% 32 == 0, cin >= 64, cout %% 4 == 0)"); return PCS_EUNSUPPORTED; }
+  if (!convh_applies(cin, cout, K)) { set_error("pcs_conv_gather_gemm_h: shape not served by the half kernels (needs cin %% 32 == 0, cout %% 4 == 0, an even number of 16-column tiles)"); return PCS_EUNSUPPORTED; }
   if (n_dst == 0) return PCS_OK;
   if (!Wp || !seg || !dst || (n_src > 0 && !src)) { set_error("pcs_conv_gather_gemm_h: null pointer"); return PCS_EINVAL; }
   if ((((uintptr_t)src | (uintptr_t)Wp | (uintptr_t)bias) & 15) || ((uintptr_t)dst & 7)) { set_error("pcs_conv_gather_gemm_h: misaligned pointer"); return PCS_EINVAL; }

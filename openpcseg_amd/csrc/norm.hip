@@ -5,6 +5,8 @@
 // single write); backward = one reduction pass + one apply pass producing dx and (optionally) the residual grad.
 // Statistics are two-level (per-workgroup partials, then a fixed-order reduction): deterministic, and the
 // (sum, sumsq) vector is what a multi-GPU run all-reduces between the two kernels (SyncBN semantics).
+#include <type_traits>
+
 #include "pcs_common.h"
 
 using namespace pcs;
@@ -12,6 +14,46 @@ using namespace pcs;
 namespace {
 
 constexpr int kStatBlocks = 1024;  // partial rows; each workgroup strides over the feature rows
+
+// storage format of the feature tensors (x, residual, y, dy, dx, dres): fp32, or bf16 / fp16 under mixed precision
+// (statistics, scale / shift and all arithmetic stay fp32 / double)
+struct F32 {};
+struct B16 {};
+struct H16 {};
+__device__ __forceinline__ float h2f(B16, uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ float h2f(H16, uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t f2h(B16, float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint16_t f2h(H16, float f) { const _Float16 h = (_Float16)f; return __builtin_bit_cast(uint16_t, h); }
+// element `e` (a multiple of V) of a tensor -> V floats; and back
+template <int V> __device__ __forceinline__ typename std::conditional<V == 4, float4, float>::type ldv(F32, const void *p, int64_t e) {
+  return *reinterpret_cast<const typename std::conditional<V == 4, float4, float>::type *>(reinterpret_cast<const float *>(p) + e);
+}
+template <int V, typename HT> __device__ __forceinline__ typename std::conditional<V == 4, float4, float>::type ldv(HT, const void *p, int64_t e) {
+  const uint16_t *h = reinterpret_cast<const uint16_t *>(p) + e;
+  if constexpr (V == 4) {
+    const uint2 r = *reinterpret_cast<const uint2 *>(h);
+    return make_float4(h2f(HT{}, (uint16_t)(r.x & 0xFFFFu)), h2f(HT{}, (uint16_t)(r.x >> 16)),
+                       h2f(HT{}, (uint16_t)(r.y & 0xFFFFu)), h2f(HT{}, (uint16_t)(r.y >> 16)));
+  } else {
+    return h2f(HT{}, h[0]);
+  }
+}
+__device__ __forceinline__ void stv(F32, void *p, int64_t e, const float4 &v) { *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p) + e) = v; }
+__device__ __forceinline__ void stv(F32, void *p, int64_t e, const float &v) { reinterpret_cast<float *>(p)[e] = v; }
+template <typename HT> __device__ __forceinline__ void stv(HT, void *p, int64_t e, const float4 &v) {
+  uint2 o;
+  o.x = f2h(HT{}, v.x) | ((uint32_t)f2h(HT{}, v.y) << 16);
+  o.y = f2h(HT{}, v.z) | ((uint32_t)f2h(HT{}, v.w) << 16);
+  *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(p) + e) = o;
+}
+template <typename HT> __device__ __forceinline__ void stv(HT, void *p, int64_t e, const float &v) {
+  reinterpret_cast<uint16_t *>(p)[e] = f2h(HT{}, v);
+}
 
 template <int V> struct NV;
 template <> struct NV<4> { using T = float4; };
@@ -24,9 +66,9 @@ __device__ __forceinline__ void setc(float &v, int, float s) { v = s; }
 
 // block = (TX lanes over channel VECTORS, TY rows); partial[b][0][c] = sum x, partial[b][1][c] = sum x^2
 // (backward: sum g, sum g*xhat with g = dy * [y > 0]). V = 4: 16-byte loads.
-template <bool BWD, int V>
-__global__ void __launch_bounds__(256) bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
-                                                         const float *__restrict__ y, const uint32_t *__restrict__ mask,
+template <bool BWD, int V, typename ET>
+__global__ void __launch_bounds__(256) bn_partial_kernel(const void *__restrict__ x, const void *__restrict__ dy,
+                                                         const void *__restrict__ y, const uint32_t *__restrict__ mask,
                                                          const double *__restrict__ stat,
                                                          int64_t n, int c, int cv, int relu, float *__restrict__ partial) {
   using VT = typename NV<V>::T;
@@ -44,17 +86,19 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float *__restrict
       float mean[V], invstd[V];
 #pragma unroll
       for (int q = 0; q < V; ++q) {
-        mean[q] = BWD ? (float)stat[j * V + q] : (n > 0 ? x[j * V + q] : 0.f);
+        mean[q] = BWD ? (float)stat[j * V + q] : (n > 0 ? ldv<1>(ET{}, x, j * V + q) : 0.f);
         invstd[q] = BWD ? (float)stat[c + j * V + q] : 0.f;
+        // forward: workgroup 0 leaves the pivot row, widened to fp32, in partial row gridDim.x for the reduce kernel
+        if (!BWD && blockIdx.x == 0 && ty == 0) partial[(int64_t)gridDim.x * 2 * c + j * V + q] = mean[q];
       }
       for (int64_t i = (int64_t)blockIdx.x * TY + ty; i < n; i += (int64_t)gridDim.x * TY) {
-        const VT xv = reinterpret_cast<const VT *>(x + i * c)[j];
+        const VT xv = ldv<V>(ET{}, x, i * c + (int64_t)j * V);
         if (BWD) {
-          const VT gv = reinterpret_cast<const VT *>(dy + i * c)[j];
+          const VT gv = ldv<V>(ET{}, dy, i * c + (int64_t)j * V);
           VT yv; unsigned bits = 0xFu;
           if (relu) {
             if (V == 4 && mask) bits = (mask[i * (c >> 5) + (j >> 3)] >> (4 * (j & 7))) & 0xFu;
-            else yv = reinterpret_cast<const VT *>(y + i * c)[j];
+            else yv = ldv<V>(ET{}, y, i * c + (int64_t)j * V);
           }
 #pragma unroll
           for (int q = 0; q < V; ++q) {
@@ -154,11 +198,11 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const double *__restri
 }
 
 // y = act((x - mean) * invstd * w + b [+ res])
-template <int V>
-__global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ res,
+template <int V, typename ET>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const void *__restrict__ x, const void *__restrict__ res,
                                                        const double *__restrict__ stat, const float *__restrict__ w,
                                                        const float *__restrict__ b, int64_t n, int c, int cv, int relu,
-                                                       float *__restrict__ y, uint32_t *__restrict__ mask) {
+                                                       void *__restrict__ y, uint32_t *__restrict__ mask) {
   using VT = typename NV<V>::T;
   for (int j = threadIdx.x; j < cv; j += blockDim.x) {
     float sc[V], sh[V];
@@ -170,8 +214,8 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__
       sh[q] = (b ? b[ch] : 0.f) - mean * sc[q];
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; i < n; i += (int64_t)gridDim.x * blockDim.y) {
-      const VT xv = reinterpret_cast<const VT *>(x + i * c)[j];
-      VT rv; if (res) rv = reinterpret_cast<const VT *>(res + i * c)[j];
+      const VT xv = ldv<V>(ET{}, x, i * c + (int64_t)j * V);
+      VT rv; if (res) rv = ldv<V>(ET{}, res, i * c + (int64_t)j * V);
       VT o;
       unsigned bits = 0;
 #pragma unroll
@@ -182,7 +226,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__
         bits |= (t > 0.f ? 1u : 0u) << q;
         setc(o, q, t);
       }
-      reinterpret_cast<VT *>(y + i * c)[j] = o;
+      stv(ET{}, y, i * c + (int64_t)j * V, o);
       if (V == 4 && mask) {  // c % 32 == 0: 8 consecutive lanes (4 channels each) of one row make one word
         unsigned m = bits << (4 * (j & 7));
         m |= __shfl_xor(m, 1, 64); m |= __shfl_xor(m, 2, 64); m |= __shfl_xor(m, 4, 64);
@@ -193,14 +237,14 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__
 }
 
 // g = dy * [y > 0];  dx = (g - sum_g/N - xhat * sum_gxhat/N) * invstd * w ;  dres = g
-template <int V>
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
-                                                           const float *__restrict__ y, const uint32_t *__restrict__ mask,
+template <int V, typename ET>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const void *__restrict__ dy, const void *__restrict__ x,
+                                                           const void *__restrict__ y, const uint32_t *__restrict__ mask,
                                                            const double *__restrict__ stat,
                                                            const double *__restrict__ sums2, double count,
                                                            const double *__restrict__ count_dev,
                                                            const float *__restrict__ w, int64_t n, int c, int cv,
-                                                           int relu, float *__restrict__ dx, float *__restrict__ dres) {
+                                                           int relu, void *__restrict__ dx, void *__restrict__ dres) {
   using VT = typename NV<V>::T;
   if (count_dev) count = *count_dev;
   if (!(count > 0.0)) count = 1.0;
@@ -215,12 +259,12 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *__restri
       ws[q] = invstd[q] * (w ? w[ch] : 1.f);
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; i < n; i += (int64_t)gridDim.x * blockDim.y) {
-      const VT gv = reinterpret_cast<const VT *>(dy + i * c)[j];
-      const VT xv = reinterpret_cast<const VT *>(x + i * c)[j];
+      const VT gv = ldv<V>(ET{}, dy, i * c + (int64_t)j * V);
+      const VT xv = ldv<V>(ET{}, x, i * c + (int64_t)j * V);
       VT yv; unsigned bits = 0xFu;
       if (relu) {
         if (V == 4 && mask) bits = (mask[i * (c >> 5) + (j >> 3)] >> (4 * (j & 7))) & 0xFu;
-        else yv = reinterpret_cast<const VT *>(y + i * c)[j];
+        else yv = ldv<V>(ET{}, y, i * c + (int64_t)j * V);
       }
       VT o, r;
 #pragma unroll
@@ -231,8 +275,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *__restri
         setc(o, q, (g - k1[q] - xh * k2[q]) * ws[q]);
         setc(r, q, g);
       }
-      reinterpret_cast<VT *>(dx + i * c)[j] = o;
-      if (dres) reinterpret_cast<VT *>(dres + i * c)[j] = r;
+      stv(ET{}, dx, i * c + (int64_t)j * V, o);
+      if (dres) stv(ET{}, dres, i * c + (int64_t)j * V, r);
     }
   }
 }
@@ -247,35 +291,88 @@ template <int V> Geo geo(int64_t n, int c) {
   g.grid = dim3((unsigned)gr);
   return g;
 }
-bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
-extern "C" int32_t pcs_bn_num_partials(void) { return kStatBlocks; }
+extern "C" int32_t pcs_bn_num_partials(void) { return kStatBlocks + 1; }  // + the widened pivot row
 
-static int bn_partial(bool bwd, const float *x, const float *dy, const float *y, const uint32_t *mask, const double *stat,
+// dtype of the feature tensors: 0 fp32, 1 bf16, 2 fp16. alignment unit of a V = 4 access: 16 B (fp32) / 8 B (halfs)
+#define PCS_BN_DISPATCH(DT, CALL)                         \
+  do {                                                    \
+    if ((DT) == 0) { using ET = F32; CALL; }              \
+    else if ((DT) == 1) { using ET = B16; CALL; }         \
+    else { using ET = H16; CALL; }                        \
+  } while (0)
+
+static bool al_v4(int dtype, const void *p) { return ((uintptr_t)p & (dtype == 0 ? 15 : 7)) == 0; }
+
+static int bn_partial(bool bwd, int dtype, const void *x, const void *dy, const void *y, const uint32_t *mask, const double *stat,
                       int64_t n, int c, int relu, float *partial, double *sums, hipStream_t st) {
-  const bool vec = (c & 3) == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)y) & 15) == 0;
-  if (mask && (!vec || (c & 31))) { set_error("pcs_bn: the ReLU bit mask needs c % 32 == 0 and 16-byte aligned rows"); return PCS_EUNSUPPORTED; }
+  const bool vec = (c & 3) == 0 && al_v4(dtype, x) && al_v4(dtype, dy) && al_v4(dtype, y);
+  if (mask && (!vec || (c & 31))) { set_error("pcs_bn: the ReLU bit mask needs c % 32 == 0 and aligned rows"); return PCS_EUNSUPPORTED; }
   const int V = vec ? 4 : 1, cv = c / V;
   int tx = 1; while (tx < cv && tx < 64) tx <<= 1;
   dim3 block(tx, 256 / tx);
   const size_t lds = (size_t)(256 / tx) * 2 * tx * V * sizeof(float);
   if (vec) {
-    if (bwd) hipLaunchKernelGGL((bn_partial_kernel<true, 4>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial);
-    else hipLaunchKernelGGL((bn_partial_kernel<false, 4>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial);
+    if (bwd) PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_partial_kernel<true, 4, ET>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial));
+    else PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_partial_kernel<false, 4, ET>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial));
   } else {
-    if (bwd) hipLaunchKernelGGL((bn_partial_kernel<true, 1>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial);
-    else hipLaunchKernelGGL((bn_partial_kernel<false, 1>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial);
+    if (bwd) PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_partial_kernel<true, 1, ET>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial));
+    else PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_partial_kernel<false, 1, ET>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial));
   }
+    const float *pivot = bwd ? nullptr : partial + (size_t)kStatBlocks * 2 * c;  // written by workgroup 0 above
   hipLaunchKernelGGL(bn_reduce_kernel<float>, dim3((unsigned)ceil_div(c, 16)), dim3(16, 64), 0, st, partial, kStatBlocks, c,
-                     bwd ? nullptr : x, n, sums);
+                     pivot, n, sums);
   return check_launch("pcs_bn_partial");
 }
 
+static int bn_apply_any(int dtype, const void *x, const void *res, const double *stat, const float *w, const float *b,
+                        int64_t n, int32_t c, int32_t relu, void *y, uint32_t *mask, void *stream) {
+  if (n < 0 || c <= 0) { set_error("pcs_bn_apply: bad sizes"); return PCS_EINVAL; }
+  if (n == 0) return PCS_OK;
+  if (!x || !stat || !y) { set_error("pcs_bn_apply: null pointer"); return PCS_EINVAL; }
+  hipStream_t st = as_stream(stream);
+  const bool vec = (c & 3) == 0 && al_v4(dtype, x) && al_v4(dtype, y) && al_v4(dtype, res);
+  if (mask && (!vec || (c & 31))) { set_error("pcs_bn_apply: the ReLU bit mask needs c % 32 == 0 and aligned rows"); return PCS_EUNSUPPORTED; }
+  if (vec) {
+    Geo g = geo<4>(n, c);
+    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_apply_kernel<4, ET>), g.grid, g.block, 0, st, x, res, stat, w, b, n, c, g.cv, relu, y, mask));
+  } else {
+    Geo g = geo<1>(n, c);
+    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_apply_kernel<1, ET>), g.grid, g.block, 0, st, x, res, stat, w, b, n, c, g.cv, relu, y, mask));
+  }
+  return check_launch("pcs_bn_apply");
+}
+
+static int bn_bwd_apply_any(int dtype, const void *dy, const void *x, const void *y, const uint32_t *mask,
+                            const double *stat, const double *sums2, double count, const double *count_dev,
+                            const float *w, int64_t n, int32_t c, int32_t relu, void *dx, void *dres, void *stream) {
+  if (n < 0 || c <= 0 || (!count_dev && !(count > 0))) { set_error("pcs_bn_bwd_apply: bad sizes"); return PCS_EINVAL; }
+  if (n == 0) return PCS_OK;
+  if (!dy || !x || !stat || !sums2 || !dx || (relu && !y && !mask)) { set_error("pcs_bn_bwd_apply: null pointer"); return PCS_EINVAL; }
+  hipStream_t st = as_stream(stream);
+  const bool vec = (c & 3) == 0 && al_v4(dtype, dy) && al_v4(dtype, x) && al_v4(dtype, y) && al_v4(dtype, dx) && al_v4(dtype, dres);
+  if (mask && (!vec || (c & 31))) { set_error("pcs_bn_bwd_apply: the ReLU bit mask needs c % 32 == 0 and aligned rows"); return PCS_EUNSUPPORTED; }
+  if (vec) {
+    Geo g = geo<4>(n, c);
+    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<4, ET>), g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, g.cv, relu, dx, dres));
+  } else {
+    Geo g = geo<1>(n, c);
+    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<1, ET>), g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, g.cv, relu, dx, dres));
+  }
+  return check_launch("pcs_bn_bwd_apply");
+}
+
+static bool bad_half(int32_t dtype) { return dtype != 1 && dtype != 2; }
+
 extern "C" int pcs_bn_stats_f32(const float *x, int64_t n, int32_t c, float *partial_ws, double *sums, void *stream) {
   if (n < 0 || c <= 0 || !x || !partial_ws || !sums) { set_error("pcs_bn_stats: bad args"); return PCS_EINVAL; }
-  return bn_partial(false, x, nullptr, nullptr, nullptr, nullptr, n, c, 0, partial_ws, sums, as_stream(stream));
+  return bn_partial(false, 0, x, nullptr, nullptr, nullptr, nullptr, n, c, 0, partial_ws, sums, as_stream(stream));
+}
+extern "C" int pcs_bn_stats_h(const void *x, int64_t n, int32_t c, int32_t dtype, float *partial_ws, double *sums, void *stream) {
+  if (n < 0 || c <= 0 || !x || !partial_ws || !sums || bad_half(dtype)) { set_error("pcs_bn_stats_h: bad args"); return PCS_EINVAL; }
+  return bn_partial(false, dtype, x, nullptr, nullptr, nullptr, nullptr, n, c, 0, partial_ws, sums, as_stream(stream));
 }
 
 extern "C" int pcs_bn_finalize_f32(const double *sums, double count, const double *count_dev, int32_t c, double eps,
@@ -288,45 +385,37 @@ extern "C" int pcs_bn_finalize_f32(const double *sums, double count, const doubl
 
 extern "C" int pcs_bn_apply_f32(const float *x, const float *res, const double *stat, const float *w, const float *b,
                                 int64_t n, int32_t c, int32_t relu, float *y, uint32_t *mask, void *stream) {
-  if (n < 0 || c <= 0) { set_error("pcs_bn_apply: bad sizes"); return PCS_EINVAL; }
-  if (n == 0) return PCS_OK;
-  if (!x || !stat || !y) { set_error("pcs_bn_apply: null pointer"); return PCS_EINVAL; }
-  hipStream_t st = as_stream(stream);
-  const bool vec = (c & 3) == 0 && al16(x) && al16(y) && al16(res);
-  if (mask && (!vec || (c & 31))) { set_error("pcs_bn_apply: the ReLU bit mask needs c % 32 == 0 and 16-byte aligned rows"); return PCS_EUNSUPPORTED; }
-  if (vec) {
-    Geo g = geo<4>(n, c);
-    hipLaunchKernelGGL(bn_apply_kernel<4>, g.grid, g.block, 0, st, x, res, stat, w, b, n, c, g.cv, relu, y, mask);
-  } else {
-    Geo g = geo<1>(n, c);
-    hipLaunchKernelGGL(bn_apply_kernel<1>, g.grid, g.block, 0, st, x, res, stat, w, b, n, c, g.cv, relu, y, mask);
-  }
-  return check_launch("pcs_bn_apply");
+  return bn_apply_any(0, x, res, stat, w, b, n, c, relu, y, mask, stream);
+}
+extern "C" int pcs_bn_apply_h(const void *x, const void *res, const double *stat, const float *w, const float *b,
+                              int64_t n, int32_t c, int32_t relu, int32_t dtype, void *y, uint32_t *mask, void *stream) {
+  if (bad_half(dtype)) { set_error("pcs_bn_apply_h: dtype must be 1 (bf16) or 2 (fp16)"); return PCS_EINVAL; }
+  return bn_apply_any(dtype, x, res, stat, w, b, n, c, relu, y, mask, stream);
 }
 
 extern "C" int pcs_bn_bwd_stats_f32(const float *dy, const float *x, const float *y, const uint32_t *mask,
                                     const double *stat, int64_t n, int32_t c, int32_t relu, float *partial_ws,
                                     double *sums2, void *stream) {
   if (n < 0 || c <= 0 || !dy || !x || !stat || !partial_ws || !sums2 || (relu && !y && !mask)) { set_error("pcs_bn_bwd_stats: bad args"); return PCS_EINVAL; }
-  return bn_partial(true, x, dy, y, mask, stat, n, c, relu, partial_ws, sums2, as_stream(stream));
+  return bn_partial(true, 0, x, dy, y, mask, stat, n, c, relu, partial_ws, sums2, as_stream(stream));
+}
+extern "C" int pcs_bn_bwd_stats_h(const void *dy, const void *x, const void *y, const uint32_t *mask,
+                                  const double *stat, int64_t n, int32_t c, int32_t relu, int32_t dtype, float *partial_ws,
+                                  double *sums2, void *stream) {
+  if (n < 0 || c <= 0 || !dy || !x || !stat || !partial_ws || !sums2 || (relu && !y && !mask) || bad_half(dtype)) { set_error("pcs_bn_bwd_stats_h: bad args"); return PCS_EINVAL; }
+  return bn_partial(true, dtype, x, dy, y, mask, stat, n, c, relu, partial_ws, sums2, as_stream(stream));
 }
 
 extern "C" int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const uint32_t *mask,
                                     const double *stat, const double *sums2, double count, const double *count_dev,
                                     const float *w, int64_t n, int32_t c, int32_t relu, float *dx, float *dres,
                                     void *stream) {
-  if (n < 0 || c <= 0 || (!count_dev && !(count > 0))) { set_error("pcs_bn_bwd_apply: bad sizes"); return PCS_EINVAL; }
-  if (n == 0) return PCS_OK;
-  if (!dy || !x || !stat || !sums2 || !dx || (relu && !y && !mask)) { set_error("pcs_bn_bwd_apply: null pointer"); return PCS_EINVAL; }
-  hipStream_t st = as_stream(stream);
-  const bool vec = (c & 3) == 0 && al16(dy) && al16(x) && al16(y) && al16(dx) && al16(dres);
-  if (mask && (!vec || (c & 31))) { set_error("pcs_bn_bwd_apply: the ReLU bit mask needs c % 32 == 0 and 16-byte aligned rows"); return PCS_EUNSUPPORTED; }
-  if (vec) {
-    Geo g = geo<4>(n, c);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, g.cv, relu, dx, dres);
-  } else {
-    Geo g = geo<1>(n, c);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, g.cv, relu, dx, dres);
-  }
-  return check_launch("pcs_bn_bwd_apply");
+  return bn_bwd_apply_any(0, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, relu, dx, dres, stream);
+}
+extern "C" int pcs_bn_bwd_apply_h(const void *dy, const void *x, const void *y, const uint32_t *mask,
+                                  const double *stat, const double *sums2, double count, const double *count_dev,
+                                  const float *w, int64_t n, int32_t c, int32_t relu, int32_t dtype, void *dx, void *dres,
+                                  void *stream) {
+  if (bad_half(dtype)) { set_error("pcs_bn_bwd_apply_h: dtype must be 1 (bf16) or 2 (fp16)"); return PCS_EINVAL; }
+  return bn_bwd_apply_any(dtype, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, relu, dx, dres, stream);
 }

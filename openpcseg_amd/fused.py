@@ -44,6 +44,9 @@ def _stats_group():
 
 
 class _FusedBN(Function):
+    """Feature tensors may be fp32, bf16 or fp16 (mixed precision: the half convolutions hand on halfs); statistics,
+    scale / shift and running stats are fp32 / double whatever the storage format."""
+
     @staticmethod
     def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, sync, cache, level):
         be = native.backend()
@@ -81,8 +84,8 @@ class _FusedBN(Function):
             sums2 = local.clone()
             dist.all_reduce(sums2, group=_stats_group())
         dx, dres = be.bn_bwd_apply(dy, x, gate, stat, sums2, count, weight, relu, has_res, count_dev=count_dev)
-        dw = local[c:].float() if weight is not None else None   # local sums: DDP averages parameter grads
-        db = local[:c].float() if weight is not None else None
+        dw = local[c:].to(weight.dtype) if weight is not None else None   # local sums: DDP averages parameter grads
+        db = local[:c].to(weight.dtype) if weight is not None else None
         return dx, dres, dw, db, None, None, None, None, None, None, None, None
 
 

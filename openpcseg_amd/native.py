@@ -61,6 +61,11 @@ SIGNATURES = {
     "pcs_bn_apply_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
     "pcs_bn_bwd_stats_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
     "pcs_bn_bwd_apply_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_double, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
+    "pcs_bn_stats_h": (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
+    "pcs_bn_apply_h": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "pcs_bn_bwd_stats_h": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "pcs_bn_bwd_apply_h": (c_int32, [_P, _P, _P, _P, _P, _P, c_double, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P,
+                                     _P]),
     "pcs_quantize_floor": (c_int32, [_P, c_int32, c_int64, c_int32, _P, _P, _P, _P]),
     "pcs_quantize_keys": (c_int32, [_P, c_int64, _P, _P, _P]),
     "pcs_quantize_flags": (c_int32, [_P, c_int64, _P, _P]),
@@ -422,11 +427,17 @@ class HipBackend:
             rc = self.lib.pcs_downsample_pack(_ptr(coords), n, ss, 1, _ptr(offsets), k,
                                               _ptr(coords_min), _ptr(keys), _ptr(err), _stream())
         _check(rc, "pcs_downsample_pack")
-        uniq = torch.unique(keys)  # sorted ascending == reference's lexicographic (b,x,y,z)
-        if err.item():
+        uniq = torch.unique(keys)  # sorted ascending == reference's lexicographic (b,x,y,z); sizes its output on the host
+        # one host read for the two flags (the unique above already waited for the queue): range error, and whether the
+        # general branch left its "rejected candidate" sentinel at the end
+        if offsets is None or uniq.numel() == 0:
+            bad, has_sentinel = bool(err.item()), False
+        else:
+            bad, has_sentinel = torch.stack([err[0] != 0, uniq[-1] == 0x7FFFFFFFFFFFFFFF]).tolist()
+        if bad:
             raise RuntimeError("openpcseg_amd: spdownsample coordinate out of the packed range "
                                "(|x|,|y|,|z| < 2^17, 0 <= batch < 512)")
-        if uniq.numel() and offsets is not None and uniq[-1].item() == 0x7FFFFFFFFFFFFFFF:
+        if offsets is not None and has_sentinel:
             uniq = uniq[:-1]
         m = uniq.numel()
         out = torch.empty((m, 4), dtype=torch.int32, device=coords.device)
@@ -664,13 +675,27 @@ class HipBackend:
         return gfeat
 
     # -- fused BatchNorm (+residual, +ReLU) -------------------------------------------------------
+    @staticmethod
+    def _feat(t, name, like=None):
+        """A feature tensor of the BN passes: fp32, bf16 or fp16 on the device (and of `like`'s dtype when given)."""
+        t = _dev(t, name)
+        if t.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise TypeError("openpcseg_amd: `%s` must be float32 / bfloat16 / float16, got %s" % (name, t.dtype))
+        if like is not None and t.dtype != like.dtype:
+            t = t.to(like.dtype)
+        return t
+
     def bn_stats(self, x):
         """-> sums (2c + 1,) float64 = [sum x | sum x^2 | n] (the vector SyncBN all-reduces; the count rides along)."""
-        x = _dev(x, "input", torch.float32)
+        x = self._feat(x, "input")
         n, c = x.shape
         ws = torch.empty(self.lib.pcs_bn_num_partials() * 2 * c, dtype=torch.float32, device=x.device)
         sums = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
-        _check(self.lib.pcs_bn_stats_f32(_ptr(x), n, c, _ptr(ws), _ptr(sums), _stream()), "pcs_bn_stats_f32")
+        if x.dtype == torch.float32:
+            _check(self.lib.pcs_bn_stats_f32(_ptr(x), n, c, _ptr(ws), _ptr(sums), _stream()), "pcs_bn_stats_f32")
+        else:
+            _check(self.lib.pcs_bn_stats_h(_ptr(x), n, c, self._HALF[x.dtype], _ptr(ws), _ptr(sums), _stream()),
+                   "pcs_bn_stats_h")
         return sums
 
     def bn_finalize(self, sums, count, eps, momentum, running_mean, running_var, count_dev=None):
@@ -685,46 +710,62 @@ class HipBackend:
         return stat
 
     def bn_apply(self, x, res, stat, w, b, relu, want_mask=False):
-        """y = act((x - mean) * invstd * w + b [+ res]). want_mask (c % 32 == 0): also the ReLU gate as n x c/32 int32
-        words (bit ch % 32 of word ch / 32 = [y > 0]) -- what the backward passes read instead of y."""
-        x = _dev(x, "input", torch.float32)
+        """y = act((x - mean) * invstd * w + b [+ res]) in x's dtype (fp32 / bf16 / fp16). want_mask (c % 32 == 0): also
+        the ReLU gate as n x c/32 int32 words (bit ch % 32 of word ch / 32 = [y > 0]) -- what the backward passes read
+        instead of y."""
+        x = self._feat(x, "input")
+        res = self._feat(res, "residual", x) if res is not None else None
         n, c = x.shape
         if want_mask and c % 32:
             raise RuntimeError("openpcseg_amd: the ReLU bit mask needs a channel count that is a multiple of 32")
         y = torch.empty_like(x)
         mask = torch.empty((n, c // 32), dtype=torch.int32, device=x.device) if want_mask else None
-        _check(self.lib.pcs_bn_apply_f32(_ptr(x), _ptr(res) if res is not None else None, _ptr(stat),
-                                         _ptr(w) if w is not None else None, _ptr(b) if b is not None else None,
-                                         n, c, int(relu), _ptr(y), _ptr(mask) if want_mask else None, _stream()),
-               "pcs_bn_apply_f32")
+        args = [_ptr(x), _ptr(res) if res is not None else None, _ptr(stat), _ptr(w) if w is not None else None,
+                _ptr(b) if b is not None else None, n, c, int(relu)]
+        if x.dtype == torch.float32:
+            _check(self.lib.pcs_bn_apply_f32(*args, _ptr(y), _ptr(mask) if want_mask else None, _stream()),
+                   "pcs_bn_apply_f32")
+        else:
+            _check(self.lib.pcs_bn_apply_h(*args, self._HALF[x.dtype], _ptr(y), _ptr(mask) if want_mask else None,
+                                           _stream()), "pcs_bn_apply_h")
         return (y, mask) if want_mask else y
 
     @staticmethod
     def _gate(gate, relu):
-        """(y pointer, mask pointer) of the ReLU gate: the output tensor (float32) or its bit mask (int32)."""
+        """(y pointer, mask pointer) of the ReLU gate: the output tensor (features dtype) or its bit mask (int32)."""
         if not relu or gate is None:
             return None, None
         return (None, _ptr(gate)) if gate.dtype == torch.int32 else (_ptr(gate), None)
 
     def bn_bwd_stats(self, dy, x, gate, stat, relu):
+        x = self._feat(x, "input")
+        dy = self._feat(dy, "grad_output", x)
         n, c = x.shape
         ws = torch.empty(self.lib.pcs_bn_num_partials() * 2 * c, dtype=torch.float32, device=x.device)
         sums2 = torch.empty(2 * c, dtype=torch.float64, device=x.device)
         yp, mp = self._gate(gate, relu)
-        _check(self.lib.pcs_bn_bwd_stats_f32(_ptr(dy), _ptr(x), yp, mp, _ptr(stat), n, c, int(relu),
-                                             _ptr(ws), _ptr(sums2), _stream()), "pcs_bn_bwd_stats_f32")
+        if x.dtype == torch.float32:
+            _check(self.lib.pcs_bn_bwd_stats_f32(_ptr(dy), _ptr(x), yp, mp, _ptr(stat), n, c, int(relu),
+                                                 _ptr(ws), _ptr(sums2), _stream()), "pcs_bn_bwd_stats_f32")
+        else:
+            _check(self.lib.pcs_bn_bwd_stats_h(_ptr(dy), _ptr(x), yp, mp, _ptr(stat), n, c, int(relu), self._HALF[x.dtype],
+                                               _ptr(ws), _ptr(sums2), _stream()), "pcs_bn_bwd_stats_h")
         return sums2
 
     def bn_bwd_apply(self, dy, x, gate, stat, sums2, count, w, relu, want_res, count_dev=None):
+        x = self._feat(x, "input")
+        dy = self._feat(dy, "grad_output", x)
         n, c = x.shape
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if want_res else None
         yp, mp = self._gate(gate, relu)
-        _check(self.lib.pcs_bn_bwd_apply_f32(_ptr(dy), _ptr(x), yp, mp, _ptr(stat), _ptr(sums2),
-                                             float(count), _ptr(count_dev) if count_dev is not None else None,
-                                             _ptr(w) if w is not None else None, n, c, int(relu),
-                                             _ptr(dx), _ptr(dres) if want_res else None, _stream()),
-               "pcs_bn_bwd_apply_f32")
+        head = [_ptr(dy), _ptr(x), yp, mp, _ptr(stat), _ptr(sums2), float(count),
+                _ptr(count_dev) if count_dev is not None else None, _ptr(w) if w is not None else None, n, c, int(relu)]
+        tail = [_ptr(dx), _ptr(dres) if want_res else None, _stream()]
+        if x.dtype == torch.float32:
+            _check(self.lib.pcs_bn_bwd_apply_f32(*head, *tail), "pcs_bn_bwd_apply_f32")
+        else:
+            _check(self.lib.pcs_bn_bwd_apply_h(*head, self._HALF[x.dtype], *tail), "pcs_bn_bwd_apply_h")
         return dx, dres
 
     # -- device-side sparse_quantize --------------------------------------------------------------------

@@ -612,3 +612,82 @@ def test_fused_batchnorm_large_mean_statistics(hip):
     # the device-resident count path (what SyncBN uses) gives the same statistics
     stat2 = hip.bn_finalize(sums, 0.0, 1e-5, 0.1, None, None, count_dev=sums[2 * c:])
     assert torch.equal(stat, stat2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("c,relu,with_res", [(32, True, False), (96, True, True), (256, False, False), (20, True, True)])
+def test_fused_batchnorm_half_io(hip, dtype, c, relu, with_res):
+    """FusedBatchNorm over bf16 / fp16 features (mixed precision): statistics and arithmetic in fp32 / double on the
+    half-rounded inputs, one rounding at each store -- vs nn.BatchNorm1d in fp32 on the same half-rounded tensors."""
+    from openpcseg_amd.fused import FusedBatchNorm
+    from openpcseg_amd.sparse import SparseTensor
+    g = torch.Generator(device=DEV).manual_seed(c)
+    n = 30000
+    xh = (torch.randn(n, c, device=DEV, generator=g) * 1.5 + 0.3).to(dtype)
+    rh = torch.randn(n, c, device=DEV, generator=g).to(dtype) if with_res else None
+    gyh = torch.randn(n, c, device=DEV, generator=g).to(dtype)
+    bn = FusedBatchNorm(c).to(DEV).train()
+    ref = torch.nn.BatchNorm1d(c).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+        ref.weight.copy_(bn.weight); ref.bias.copy_(bn.bias)
+    x1 = xh.clone().requires_grad_(True)
+    r1 = rh.clone().requires_grad_(True) if with_res else None
+    coords = torch.zeros(n, 4, dtype=torch.int32, device=DEV)
+    y = bn(SparseTensor(x1, coords), residual=r1, relu=relu).F
+    assert y.dtype == dtype
+    y.backward(gyh)
+    x2 = xh.float().requires_grad_(True)
+    r2 = rh.float().requires_grad_(True) if with_res else None
+    yr = ref(x2)
+    if with_res:
+        yr = yr + r2
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(gyh.float())
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert (y.float() - yr).abs().max() <= eps * yr.abs().max() + 1e-6
+    # the ReLU gate of a value that rounds to zero in half may differ from the fp32 gate: compare where |y| is not tiny
+    live = yr.abs() > 4 * eps if relu else torch.ones_like(yr, dtype=torch.bool)
+    assert x1.grad.dtype == dtype
+    d = (x1.grad.float() - x2.grad).abs()
+    assert d[live].max() <= 2 * eps * x2.grad.abs().max() + 1e-6
+    if with_res:
+        assert (r1.grad.float() - r2.grad).abs()[live].max() <= eps * r2.grad.abs().max() + 1e-6
+    assert torch.allclose(bn.weight.grad, ref.weight.grad, rtol=2e-2, atol=2e-2 * float(ref.weight.grad.abs().max()))
+    assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-4) and torch.allclose(bn.running_mean, ref.running_mean, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_minkunet_step_under_autocast(hip, dtype):
+    """One training step of the MinkUNet workload under torch.autocast (what `bench.py --amp` times): the convolutions
+    run on the 16-bit MFMA kernels, BatchNorm on half features, master weights / statistics / loss in fp32; the loss
+    agrees with the fp32 step to half precision and every parameter receives a finite fp32 gradient."""
+    from openpcseg_amd.sparse import SparseTensor
+    from openpcseg_amd.workloads.minkunet import MinkUNet
+    from openpcseg_amd.workloads.synthetic import make_batch
+    from seeded import seeded_state
+    b = make_batch([0, 1], n_points=20000)
+    coords = b["lidar"].C.to(DEV)
+
+    def batch():
+        return {"lidar": SparseTensor(b["lidar"].F.to(DEV), coords), "targets": SparseTensor(b["targets"].F.to(DEV), coords)}
+    model = MinkUNet(num_class=20, cr=0.5)
+    seeded_state(model)
+    model.to(DEV).train()
+    l32 = model(batch())["loss"]
+    l32.backward()
+    g32 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=dtype):
+        out = model(batch())
+    out["loss"].backward()
+    assert abs(float(out["loss"]) - float(l32)) <= 0.05 * abs(float(l32)), (float(out["loss"]), float(l32))
+    cos = []
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        assert p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), n
+        if p.dim() >= 2 and g32[n].abs().max() > 0:
+            cos.append(float(torch.nn.functional.cosine_similarity(p.grad.flatten(), g32[n].flatten(), dim=0)))
+    assert np.median(cos) > 0.9, np.median(cos)
