@@ -422,6 +422,214 @@ __global__ void __launch_bounds__(256, 3) wgrad2_kernel(Wgrad2Args w) {
 #undef PCS_WG_CASE
 }
 
+// ================================================================================================
+// wgrad3: the weight gradient on the 16-bit MFMAs (v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulate).
+//   gW[k][a][b] = sum over the pairs p of offset k:  fa[ia_p][a] * fb[ib_p][b]
+// The contraction runs over PAIRS, and a 16-bit MFMA wants 8 consecutive contraction indices packed in each lane's
+// registers -- 8 pairs of ONE channel -- while a gathered row holds consecutive channels of ONE pair. So the rows of a
+// 32-pair batch are staged through LDS row-major (coalesced 16-byte row pieces in, one batch shared by the four waves
+// of the workgroup = a 128 x 128 block of the weight gradient instead of four private 64 x 64 gathers) and the operand
+// fragments are read TRANSPOSED, eight 2-byte reads per fragment, from a chunk-swizzled image (16-channel chunk c of
+// pair p sits at chunk c ^ ((p >> 3) & 3): the four lane groups of a read land in four distinct 8-bank ranges).
+//   * half operands (bf16 / fp16, mixed precision): one plane, 16 MFMAs per wave and batch;
+//   * fp32 operands: each value is split on the fly into THREE bf16 planes (hi, mid, lo with RNE at every step: exact
+//     to 2^-26) and six of the nine plane products are accumulated (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the
+//     three dropped ones are below 2^-25 relative) -- fp32-grade results (measured error vs fp64 below the fp32 MFMA's
+//     own) at 6/16 of the fp32-MFMA cost: gfx950 has no TF32 path, its fp32 MFMA runs at 1/16 of the bf16 rate.
+// Split plan, workspace layout and the fixed-order split reduction are those of wgrad2 (deterministic).
+// ================================================================================================
+constexpr int W3_PB = 32;    // pairs per batch = one MFMA contraction step
+constexpr int W3_ROW = 128;  // halfs per staged row and operand (two channel groups of <= 64)
+
+typedef __bf16 w3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float w3_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 w3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 w3_f16x8 __attribute__((ext_vector_type(8)));
+
+struct Wgrad3Args {
+  const void *fa;
+  const void *fb;
+  const int32_t *pairs;
+  const int32_t *koff;
+  float *partial;  // [nsplit_total][ca][cb]
+  int ca, cb, K, a_col, pch;
+  int aw, bw, nag, nbg, nsb;  // group widths, group counts, b super-groups (pairs of groups) per row of super-blocks
+};
+
+template <typename ET> struct W3Mode;
+template <> struct W3Mode<Fp32> { static constexpr int PLANES = 3; using MT = Bf16; };
+template <> struct W3Mode<Bf16> { static constexpr int PLANES = 1; using MT = Bf16; };
+template <> struct W3Mode<Fp16> { static constexpr int PLANES = 1; using MT = Fp16; };
+
+__device__ __forceinline__ f32x4 w3_mfma(Bf16, const uint4 &a, const uint4 &b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w3_bf16x8, a), __builtin_bit_cast(w3_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 w3_mfma(Fp16, const uint4 &a, const uint4 &b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(w3_f16x8, a), __builtin_bit_cast(w3_f16x8, b), c, 0, 0, 0);
+}
+
+// (x, y) fp32 -> packed bf16 pairs of the three planes (v_cvt_pk_bf16_f32: round to nearest even)
+__device__ __forceinline__ void w3_split(float x, float y, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+  const w3_f32x2 v = {x, y};
+  const w3_bf16x2 h = __builtin_convertvector(v, w3_bf16x2);
+  const w3_f32x2 r1 = v - __builtin_convertvector(h, w3_f32x2);
+  const w3_bf16x2 m = __builtin_convertvector(r1, w3_bf16x2);
+  const w3_f32x2 r2 = r1 - __builtin_convertvector(m, w3_f32x2);
+  const w3_bf16x2 l = __builtin_convertvector(r2, w3_bf16x2);
+  hi = __builtin_bit_cast(uint32_t, h); mid = __builtin_bit_cast(uint32_t, m); lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// swizzled position (in halfs) of channel ch of staged pair p
+__device__ __forceinline__ int w3_pos(int p, int ch) { return p * W3_ROW + ((((ch >> 4) ^ (p >> 3)) & 7) << 4) + (ch & 15); }
+
+template <typename ET, int NA, int NB>
+__global__ void __launch_bounds__(256, 2) wgrad3_kernel(Wgrad3Args w) {
+  constexpr int PL = W3Mode<ET>::PLANES;
+  using MT = typename W3Mode<ET>::MT;
+  constexpr bool F32IN = std::is_same<ET, Fp32>::value;
+  __shared__ __attribute__((aligned(16))) uint16_t lds[PL * 2 * W3_PB * W3_ROW];  // [plane][A | B][pair][128]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  int beg, end;
+  find_split_wave(w.koff, w.K, w.pch, blockIdx.x, lane, &beg, &end);  // the same answer in every wave
+  if (beg >= end) return;  // workgroup-uniform
+  const int sa = blockIdx.y / w.nsb, sb = blockIdx.y - sa * w.nsb;  // super-block = 2 x 2 channel groups
+  const int a_base = 2 * sa * w.aw, b_base = 2 * sb * w.bw;
+  const int a_stage = (w.ca - a_base) < 2 * w.aw ? (w.ca - a_base) : 2 * w.aw;  // channels staged per operand
+  const int b_stage = (w.cb - b_base) < 2 * w.bw ? (w.cb - b_base) : 2 * w.bw;
+  const int ag = 2 * sa + (wid >> 1), bg = 2 * sb + (wid & 1);
+  const bool active = ag < w.nag && bg < w.nbg;  // wave-uniform: this wave owns an output block
+  const int aoff = (wid >> 1) * w.aw, boff = (wid & 1) * w.bw;
+
+  f32x4 acc[NA][NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+
+  // staging: each thread moves PIECES 16-byte pieces per operand and batch (fp32: 4 channels, halfs: 8 channels each)
+  constexpr int CPP = F32IN ? 4 : 8;           // channels per piece
+  constexpr int PPR = W3_ROW / CPP;            // pieces per staged row: 32 / 16
+  constexpr int PIECES = W3_PB * PPR / 256;    // per thread: 4 / 2
+  uint4 ra[PIECES], rb[PIECES];
+  auto fetch = [&](int p0) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int e = tid + 256 * i, p = e / PPR, c = (e % PPR) * CPP;
+      const bool pv = p0 + p < end;
+      int2 pr = make_int2(0, 0);
+      if (pv) pr = reinterpret_cast<const int2 *>(w.pairs)[p0 + p];
+      const int ia = w.a_col ? pr.y : pr.x, ib = w.a_col ? pr.x : pr.y;
+      ra[i] = make_uint4(0u, 0u, 0u, 0u);
+      rb[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (pv && c < a_stage) {
+        if (F32IN) ra[i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(w.fa) + (int64_t)ia * w.ca + a_base + c);
+        else ra[i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(w.fa) + (int64_t)ia * w.ca + a_base + c);
+      }
+      if (pv && c < b_stage) {
+        if (F32IN) rb[i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(w.fb) + (int64_t)ib * w.cb + b_base + c);
+        else rb[i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(w.fb) + (int64_t)ib * w.cb + b_base + c);
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int e = tid + 256 * i, p = e / PPR, c = (e % PPR) * CPP;
+      const int pos = w3_pos(p, c);
+#pragma unroll
+      for (int op = 0; op < 2; ++op) {
+        const uint4 v = op ? rb[i] : ra[i];
+        uint16_t *base = lds + op * (W3_PB * W3_ROW) + pos;
+        if (F32IN) {
+          uint32_t h0, m0, l0, h1, m1, l1;
+          w3_split(__uint_as_float(v.x), __uint_as_float(v.y), h0, m0, l0);
+          w3_split(__uint_as_float(v.z), __uint_as_float(v.w), h1, m1, l1);
+          *reinterpret_cast<uint2 *>(base) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2 *>(base + 2 * W3_PB * W3_ROW) = make_uint2(m0, m1);
+          *reinterpret_cast<uint2 *>(base + 4 * W3_PB * W3_ROW) = make_uint2(l0, l1);
+        } else {
+          *reinterpret_cast<uint4 *>(base) = v;
+        }
+      }
+    }
+  };
+  // transposed fragment: lane (n = l15, g) <- channel ch of the 8 staged pairs 8 g .. 8 g + 7
+  auto frag = [&](int plane, int op, int ch) {
+    const uint16_t *q = lds + (plane * 2 + op) * (W3_PB * W3_ROW) + w3_pos(8 * g, ch);
+    uint4 f;
+    f.x = (uint32_t)q[0 * W3_ROW] | ((uint32_t)q[1 * W3_ROW] << 16);
+    f.y = (uint32_t)q[2 * W3_ROW] | ((uint32_t)q[3 * W3_ROW] << 16);
+    f.z = (uint32_t)q[4 * W3_ROW] | ((uint32_t)q[5 * W3_ROW] << 16);
+    f.w = (uint32_t)q[6 * W3_ROW] | ((uint32_t)q[7 * W3_ROW] << 16);
+    return f;
+  };
+
+  fetch(beg);
+  for (int p0 = beg; p0 < end; p0 += W3_PB) {
+    stage();
+    __syncthreads();
+    if (p0 + W3_PB < end) fetch(p0 + W3_PB);  // next batch's rows fly during this batch's MFMAs
+    if (active) {
+      uint4 bf[NB][PL];
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) bf[j][pl] = frag(pl, 1, boff + 16 * j + l15);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        uint4 af[PL];
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) af[pl] = frag(pl, 0, aoff + 16 * i + l15);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          if (PL == 3) {  // smallest products first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+            acc[i][j] = w3_mfma(MT{}, af[2], bf[j][0], acc[i][j]);
+            acc[i][j] = w3_mfma(MT{}, af[0], bf[j][2], acc[i][j]);
+            acc[i][j] = w3_mfma(MT{}, af[1], bf[j][1], acc[i][j]);
+            acc[i][j] = w3_mfma(MT{}, af[1], bf[j][0], acc[i][j]);
+            acc[i][j] = w3_mfma(MT{}, af[0], bf[j][1], acc[i][j]);
+          }
+          acc[i][j] = w3_mfma(MT{}, af[0], bf[j][0], acc[i][j]);
+        }
+      }
+    }
+    __syncthreads();  // all fragment reads done before the next batch overwrites the image
+  }
+  if (!active) return;
+  // tile (i, j), register r: row a0 + 16 i + 4 g + r, column b0 + 16 j + l15
+  const int a0 = a_base + aoff, b0 = b_base + boff;
+  float *out = w.partial + (int64_t)blockIdx.x * w.ca * w.cb;
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = a0 + 16 * i + 4 * g + r;
+      if (row < w.ca && 16 * i + 4 * g + r < w.aw) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int col = b0 + 16 * j + l15;
+          if (col < w.cb && 16 * j + l15 < w.bw) out[(int64_t)row * w.cb + col] = acc[i][j][r];
+        }
+      }
+    }
+}
+
+template <typename ET>
+int launch_wgrad3(const Wgrad3Args &w, int ns, hipStream_t st) {
+  const int nsa = (w.nag + 1) / 2;
+  const dim3 grid((unsigned)ns, (unsigned)(nsa * w.nsb));
+  const int na = w.aw / 16, nb = w.bw / 16;
+#define PCS_W3_CASE(A, B) if (na == A && nb == B) { hipLaunchKernelGGL((wgrad3_kernel<ET, A, B>), grid, dim3(256), 0, st, w); return check_launch("pcs_conv_wgrad(wgrad3)"); }
+  PCS_W3_CASE(4, 4) PCS_W3_CASE(4, 3) PCS_W3_CASE(4, 2) PCS_W3_CASE(4, 1)
+  PCS_W3_CASE(3, 4) PCS_W3_CASE(3, 3) PCS_W3_CASE(3, 2) PCS_W3_CASE(3, 1)
+  PCS_W3_CASE(2, 4) PCS_W3_CASE(2, 3) PCS_W3_CASE(2, 2) PCS_W3_CASE(2, 1)
+  PCS_W3_CASE(1, 4) PCS_W3_CASE(1, 3) PCS_W3_CASE(1, 2) PCS_W3_CASE(1, 1)
+#undef PCS_W3_CASE
+  set_error("pcs_conv_wgrad(wgrad3): unreachable");
+  return PCS_EINVAL;
+}
+
 int wgrad_plan(const int32_t *koff_host, int K, int ca, int cb, int *pch_out) {
   // workgroup = 4 output blocks of one split; >= 64 pairs per split
   const int nbq = (wg_ngroups(ca) * wg_ngroups(cb) + 3) / 4;
@@ -474,7 +682,17 @@ static int conv_wgrad_any(const void *fa_v, int32_t ca, const void *fb_v, int32_
   w.ca = ca; w.cb = cb; w.K = K; w.a_col = a_col; w.pch = pch;
   const bool vec = (ca % 4 == 0) && (cb % 4 == 0) && (((uintptr_t)fa | (uintptr_t)fb) & 15) == 0;
   if (dtype != 0 && !vec) { set_error("pcs_conv_wgrad_h: half operands need channel counts that are multiples of 4 and 16-byte aligned tensors"); return PCS_EUNSUPPORTED; }
-  if (vec) {
+  // 16-bit MFMA path (wgrad3): 16-byte row pieces in both operands. PCS_WGRAD3=0 keeps the fp32-MFMA kernel (A/B, debug).
+  static const int use3 = getenv("PCS_WGRAD3") ? atoi(getenv("PCS_WGRAD3")) : 1;
+  const int cgran = dtype == 0 ? 4 : 8;
+  if (vec && use3 && ca % cgran == 0 && cb % cgran == 0) {
+    Wgrad3Args w3;
+    w3.fa = fa_v; w3.fb = fb_v; w3.pairs = pairs; w3.koff = koff_dev; w3.partial = reinterpret_cast<float *>(ws);
+    w3.ca = ca; w3.cb = cb; w3.K = K; w3.a_col = a_col; w3.pch = pch;
+    w3.aw = wg_gwidth(ca); w3.bw = wg_gwidth(cb); w3.nag = wg_ngroups(ca); w3.nbg = wg_ngroups(cb); w3.nsb = (w3.nbg + 1) / 2;
+    int rc3 = dtype == 0 ? launch_wgrad3<Fp32>(w3, ns, st) : (dtype == 1 ? launch_wgrad3<Bf16>(w3, ns, st) : launch_wgrad3<Fp16>(w3, ns, st));
+    if (rc3) return rc3;
+  } else if (vec) {
     Wgrad2Args w2;
     w2.fa = fa; w2.fb = fb; w2.pairs = pairs; w2.koff = koff_dev; w2.partial = reinterpret_cast<float *>(ws);
     w2.ca = ca; w2.cb = cb; w2.K = K; w2.a_col = a_col; w2.pch = pch; w2.nbg = wg_ngroups(cb);

@@ -1,5 +1,16 @@
+# rocprofv3 --kernel-trace --stats of bench.py (3 steps in the trace) + the plain bench line of the same configuration:
+#   bash tools/profile_bench.sh <tag> [bench args, e.g. --amp bf16]  ->  gpurun_out/<tag>_kernel_stats.csv, <tag>_bench.log
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rm -rf /tmp/prof && PCS_BENCH_PREHEAT=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof19.log 2>&1
-f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); cp "$f" $R/gpurun_out/r19_kernel_stats.csv
-cd $R && timeout 200 python bench.py > gpurun_out/bench19.log 2>&1; tail -1 gpurun_out/bench19.log | cut -c1-300
+TAG=$1; shift
+rm -rf /tmp/prof_$TAG && PCS_BENCH_PREHEAT=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $R/gpurun_out/${TAG}_prof.log 2>&1
+f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1); cp "$f" $R/gpurun_out/${TAG}_kernel_stats.csv
+cd $R && timeout 400 python bench.py "$@" > gpurun_out/${TAG}_bench.log 2> gpurun_out/${TAG}_bench.err; tail -1 gpurun_out/${TAG}_bench.log | cut -c1-400
+python - <<PY
+import csv
+rows = list(csv.DictReader(open("$R/gpurun_out/${TAG}_kernel_stats.csv")))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+for r in rows[:24]:
+    print("%-84s %5s %8.2f ms/step %5.1f%%" % (r["Name"][:84], r["Calls"], float(r["TotalDurationNs"]) / 3e6, 100 * float(r["TotalDurationNs"]) / tot))
+print("kernels per step: %.1f ms" % (tot / 3e6))
+PY
