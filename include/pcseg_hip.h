@@ -348,6 +348,10 @@ int pcs_conv_prepare_weights_h(const float *W, int32_t K, int32_t A, int32_t B, 
 int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t cin, const void *Wp, int32_t K, int32_t cout,
                            const int32_t *pairs, int32_t src_col, const int32_t *seg, int32_t tile_rows,
                            int64_t n_dst, const float *bias, void *dst, int32_t dtype, void *stream);
+/* fp32 operands through the bf16 MFMAs (three-plane split, six products, fp32-grade result); same arguments as _f32 */
+int pcs_conv_wgrad_f32_bf16x3(const float *fa, int32_t ca, const float *fb, int32_t cb, const int32_t *pairs,
+                              int32_t a_col, const int32_t *koff_dev, const int32_t *koff_host, int32_t K, float *gW,
+                              void *ws, size_t ws_bytes, void *stream);
 int pcs_conv_wgrad_h(const void *fa, int32_t ca, const void *fb, int32_t cb, const int32_t *pairs, int32_t a_col,
                      const int32_t *koff_dev, const int32_t *koff_host, int32_t K, float *gW, void *ws,
                      size_t ws_bytes, int32_t dtype, void *stream);

@@ -483,11 +483,13 @@ __device__ __forceinline__ void w3_split(float x, float y, uint32_t &hi, uint32_
 __device__ __forceinline__ int w3_pos(int p, int ch) { return p * W3_ROW + ((((ch >> 4) ^ (p >> 3)) & 7) << 4) + (ch & 15); }
 
 template <typename ET, int NA, int NB>
-__global__ void __launch_bounds__(256, 2) wgrad3_kernel(Wgrad3Args w) {
+__global__ void __launch_bounds__(256, W3Mode<ET>::PLANES == 1 ? 3 : 2) wgrad3_kernel(Wgrad3Args w) {
   constexpr int PL = W3Mode<ET>::PLANES;
   using MT = typename W3Mode<ET>::MT;
   constexpr bool F32IN = std::is_same<ET, Fp32>::value;
-  __shared__ __attribute__((aligned(16))) uint16_t lds[PL * 2 * W3_PB * W3_ROW];  // [plane][A | B][pair][128]
+  constexpr int NBUF = PL == 1 ? 2 : 1;  // halfs: two images (16 KB each), one barrier per batch; fp32: one 48 KB image
+  constexpr int IMG = PL * 2 * W3_PB * W3_ROW;  // halfs per image: [plane][A | B][pair][128]
+  __shared__ __attribute__((aligned(16))) uint16_t lds[NBUF * IMG];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
   int beg, end;
@@ -511,15 +513,23 @@ __global__ void __launch_bounds__(256, 2) wgrad3_kernel(Wgrad3Args w) {
   constexpr int CPP = F32IN ? 4 : 8;           // channels per piece
   constexpr int PPR = W3_ROW / CPP;            // pieces per staged row: 32 / 16
   constexpr int PIECES = W3_PB * PPR / 256;    // per thread: 4 / 2
+  // the dependent chain pair -> row address -> row is cut in two: the pair indices run one batch ahead of the rows
+  int2 prs[PIECES];
   uint4 ra[PIECES], rb[PIECES];
-  auto fetch = [&](int p0) {
+  auto fetch_pairs = [&](int p0) {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-      const int e = tid + 256 * i, p = e / PPR, c = (e % PPR) * CPP;
-      const bool pv = p0 + p < end;
-      int2 pr = make_int2(0, 0);
-      if (pv) pr = reinterpret_cast<const int2 *>(w.pairs)[p0 + p];
-      const int ia = w.a_col ? pr.y : pr.x, ib = w.a_col ? pr.x : pr.y;
+      const int p = (tid + 256 * i) / PPR;
+      prs[i] = make_int2(-1, -1);
+      if (p0 + p < end) prs[i] = reinterpret_cast<const int2 *>(w.pairs)[p0 + p];
+    }
+  };
+  auto fetch_rows = [&]() {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int c = ((tid + 256 * i) % PPR) * CPP;
+      const bool pv = prs[i].x >= 0;
+      const int ia = w.a_col ? prs[i].y : prs[i].x, ib = w.a_col ? prs[i].x : prs[i].y;
       ra[i] = make_uint4(0u, 0u, 0u, 0u);
       rb[i] = make_uint4(0u, 0u, 0u, 0u);
       if (pv && c < a_stage) {
@@ -532,7 +542,7 @@ __global__ void __launch_bounds__(256, 2) wgrad3_kernel(Wgrad3Args w) {
       }
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
       const int e = tid + 256 * i, p = e / PPR, c = (e % PPR) * CPP;
@@ -540,7 +550,7 @@ __global__ void __launch_bounds__(256, 2) wgrad3_kernel(Wgrad3Args w) {
 #pragma unroll
       for (int op = 0; op < 2; ++op) {
         const uint4 v = op ? rb[i] : ra[i];
-        uint16_t *base = lds + op * (W3_PB * W3_ROW) + pos;
+        uint16_t *base = lds + buf * IMG + op * (W3_PB * W3_ROW) + pos;
         if (F32IN) {
           uint32_t h0, m0, l0, h1, m1, l1;
           w3_split(__uint_as_float(v.x), __uint_as_float(v.y), h0, m0, l0);
@@ -555,8 +565,8 @@ __global__ void __launch_bounds__(256, 2) wgrad3_kernel(Wgrad3Args w) {
     }
   };
   // transposed fragment: lane (n = l15, g) <- channel ch of the 8 staged pairs 8 g .. 8 g + 7
-  auto frag = [&](int plane, int op, int ch) {
-    const uint16_t *q = lds + (plane * 2 + op) * (W3_PB * W3_ROW) + w3_pos(8 * g, ch);
+  auto frag = [&](int buf, int plane, int op, int ch) {
+    const uint16_t *q = lds + buf * IMG + (plane * 2 + op) * (W3_PB * W3_ROW) + w3_pos(8 * g, ch);
     uint4 f;
     f.x = (uint32_t)q[0 * W3_ROW] | ((uint32_t)q[1 * W3_ROW] << 16);
     f.y = (uint32_t)q[2 * W3_ROW] | ((uint32_t)q[3 * W3_ROW] << 16);
@@ -564,37 +574,57 @@ __global__ void __launch_bounds__(256, 2) wgrad3_kernel(Wgrad3Args w) {
     f.w = (uint32_t)q[6 * W3_ROW] | ((uint32_t)q[7 * W3_ROW] << 16);
     return f;
   };
-
-  fetch(beg);
-  for (int p0 = beg; p0 < end; p0 += W3_PB) {
-    stage();
-    __syncthreads();
-    if (p0 + W3_PB < end) fetch(p0 + W3_PB);  // next batch's rows fly during this batch's MFMAs
-    if (active) {
-      uint4 bf[NB][PL];
+  auto compute = [&](int buf) {
+    uint4 bf[NB][PL];
 #pragma unroll
-      for (int j = 0; j < NB; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
-        for (int pl = 0; pl < PL; ++pl) bf[j][pl] = frag(pl, 1, boff + 16 * j + l15);
+      for (int pl = 0; pl < PL; ++pl) bf[j][pl] = frag(buf, pl, 1, boff + 16 * j + l15);
 #pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        uint4 af[PL];
+    for (int i = 0; i < NA; ++i) {
+      uint4 af[PL];
 #pragma unroll
-        for (int pl = 0; pl < PL; ++pl) af[pl] = frag(pl, 0, aoff + 16 * i + l15);
+      for (int pl = 0; pl < PL; ++pl) af[pl] = frag(buf, pl, 0, aoff + 16 * i + l15);
+      // term-major, column-minor: NB independent accumulators between two MFMAs on the same one
+      if (PL == 3) {  // smallest products first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, then hi*hi
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          if (PL == 3) {  // smallest products first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
-            acc[i][j] = w3_mfma(MT{}, af[2], bf[j][0], acc[i][j]);
-            acc[i][j] = w3_mfma(MT{}, af[0], bf[j][2], acc[i][j]);
-            acc[i][j] = w3_mfma(MT{}, af[1], bf[j][1], acc[i][j]);
-            acc[i][j] = w3_mfma(MT{}, af[1], bf[j][0], acc[i][j]);
-            acc[i][j] = w3_mfma(MT{}, af[0], bf[j][1], acc[i][j]);
-          }
-          acc[i][j] = w3_mfma(MT{}, af[0], bf[j][0], acc[i][j]);
-        }
+        for (int j = 0; j < NB; ++j) acc[i][j] = w3_mfma(MT{}, af[PL - 1], bf[j][0], acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = w3_mfma(MT{}, af[0], bf[j][PL - 1], acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = w3_mfma(MT{}, af[PL / 2], bf[j][PL / 2], acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = w3_mfma(MT{}, af[PL / 2], bf[j][0], acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = w3_mfma(MT{}, af[0], bf[j][PL / 2], acc[i][j]);
       }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = w3_mfma(MT{}, af[0], bf[j][0], acc[i][j]);
     }
-    __syncthreads();  // all fragment reads done before the next batch overwrites the image
+  };
+
+  fetch_pairs(beg);
+  fetch_rows();
+  fetch_pairs(beg + W3_PB);
+  stage(0);
+  __syncthreads();
+  int cur = 0;
+  for (int p0 = beg; p0 < end; p0 += W3_PB) {
+    const bool more = p0 + W3_PB < end;  // workgroup-uniform
+    if (more) {  // next batch's rows fly during this batch's MFMAs; the pair indices of the one after behind them
+      fetch_rows();
+      fetch_pairs(p0 + 2 * W3_PB);
+    }
+    if (active) compute(cur);
+    if (NBUF == 2) {
+      if (more) stage(cur ^ 1);  // the other image: everybody left it before the previous barrier
+      __syncthreads();
+      cur ^= 1;
+    } else {
+      __syncthreads();  // all fragment reads done before the image is overwritten
+      if (more) stage(0);
+      __syncthreads();
+    }
   }
   if (!active) return;
   // tile (i, j), register r: row a0 + 16 i + 4 g + r, column b0 + 16 j + l15
@@ -605,11 +635,11 @@ __global__ void __launch_bounds__(256, 2) wgrad3_kernel(Wgrad3Args w) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = a0 + 16 * i + 4 * g + r;
-      if (row < w.ca && 16 * i + 4 * g + r < w.aw) {
+      if (row < w.ca) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           const int col = b0 + 16 * j + l15;
-          if (col < w.cb && 16 * j + l15 < w.bw) out[(int64_t)row * w.cb + col] = acc[i][j][r];
+          if (col < w.cb) out[(int64_t)row * w.cb + col] = acc[i][j][r];
         }
       }
     }
@@ -661,7 +691,7 @@ extern "C" size_t pcs_conv_wgrad_ws_bytes(const int32_t *koff_host, int32_t K, i
 static int conv_wgrad_any(const void *fa_v, int32_t ca, const void *fb_v, int32_t cb,
                           const int32_t *pairs, int32_t a_col, const int32_t *koff_dev,
                           const int32_t *koff_host, int32_t K, float *gW, void *ws,
-                          size_t ws_bytes, int dtype, void *stream) {
+                          size_t ws_bytes, int dtype, void *stream, bool force_split = false) {
   const float *fa = reinterpret_cast<const float *>(fa_v), *fb = reinterpret_cast<const float *>(fb_v);
   if (ca <= 0 || cb <= 0 || K <= 0 || !koff_dev || !koff_host || !gW || (a_col != 0 && a_col != 1) || dtype < 0 || dtype > 2) {
     set_error("pcs_conv_wgrad_f32: bad args");
@@ -683,9 +713,13 @@ static int conv_wgrad_any(const void *fa_v, int32_t ca, const void *fb_v, int32_
   const bool vec = (ca % 4 == 0) && (cb % 4 == 0) && (((uintptr_t)fa | (uintptr_t)fb) & 15) == 0;
   if (dtype != 0 && !vec) { set_error("pcs_conv_wgrad_h: half operands need channel counts that are multiples of 4 and 16-byte aligned tensors"); return PCS_EUNSUPPORTED; }
   // 16-bit MFMA path (wgrad3): 16-byte row pieces in both operands. PCS_WGRAD3=0 keeps the fp32-MFMA kernel (A/B, debug).
+  // Policy (tools/wgrad_microbench.py): half operands with >= 4 output blocks (all four waves of a super-block busy)
+  // take wgrad3 -- 1.5-2.5x the fp32-MFMA kernel; fp32 operands (three bf16 planes) stay on wgrad2 unless
+  // PCS_WGRAD3=2 asks for the split path. PCS_WGRAD3=0: wgrad2 always (A/B).
   static const int use3 = getenv("PCS_WGRAD3") ? atoi(getenv("PCS_WGRAD3")) : 1;
   const int cgran = dtype == 0 ? 4 : 8;
-  if (vec && use3 && ca % cgran == 0 && cb % cgran == 0) {
+  const bool want3 = dtype == 0 ? (use3 == 2 || force_split) : (use3 >= 1 && (use3 == 2 || wg_ngroups(ca) * wg_ngroups(cb) >= 4));
+  if (vec && want3 && ca % cgran == 0 && cb % cgran == 0) {
     Wgrad3Args w3;
     w3.fa = fa_v; w3.fb = fb_v; w3.pairs = pairs; w3.koff = koff_dev; w3.partial = reinterpret_cast<float *>(ws);
     w3.ca = ca; w3.cb = cb; w3.K = K; w3.a_col = a_col; w3.pch = pch;
@@ -732,4 +766,15 @@ extern "C" int pcs_conv_wgrad_h(const void *fa, int32_t ca, const void *fb, int3
                                 size_t ws_bytes, int32_t dtype, void *stream) {
   if (dtype != 1 && dtype != 2) { set_error("pcs_conv_wgrad_h: dtype must be 1 (bf16) or 2 (fp16)"); return PCS_EINVAL; }
   return conv_wgrad_any(fa, ca, fb, cb, pairs, a_col, koff_dev, koff_host, K, gW, ws, ws_bytes, dtype, stream);
+}
+
+// fp32 operands on the 16-bit MFMAs: every value split into three bf16 planes, six plane products accumulated in fp32
+// (wgrad3). Same arguments and fp32-grade results as pcs_conv_wgrad_f32 (needs ca % 4 == 0, cb % 4 == 0, 16-byte
+// aligned tensors); kept as its own entry because the fp32-MFMA kernel is the faster one at today's staging cost.
+extern "C" int pcs_conv_wgrad_f32_bf16x3(const float *fa, int32_t ca, const float *fb, int32_t cb,
+                                         const int32_t *pairs, int32_t a_col, const int32_t *koff_dev,
+                                         const int32_t *koff_host, int32_t K, float *gW, void *ws,
+                                         size_t ws_bytes, void *stream) {
+  if ((ca % 4) || (cb % 4) || (((uintptr_t)fa | (uintptr_t)fb) & 15)) { set_error("pcs_conv_wgrad_f32_bf16x3: needs 16-byte granular rows"); return PCS_EUNSUPPORTED; }
+  return conv_wgrad_any(fa, ca, fb, cb, pairs, a_col, koff_dev, koff_host, K, gW, ws, ws_bytes, 0, stream, true);
 }

@@ -75,6 +75,8 @@ SIGNATURES = {
     "pcs_conv_prepare_weights_h": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_conv_gather_gemm_h": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32, _P, c_int32, c_int64,
                                          _P, _P, c_int32, _P]),
+    "pcs_conv_wgrad_f32_bf16x3": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P,
+                                            _P, c_size_t, _P]),
     "pcs_conv_wgrad_h": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P, _P, c_size_t, c_int32, _P]),
     "pcs_cylinder_partition_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "pcs_voxel_label_vote": (c_int32, [_P, _P, c_int64, c_int64, c_int32, c_int64, _P, _P, _P, _P]),
@@ -570,17 +572,18 @@ class HipBackend:
         _check(self.lib.pcs_transpose_kab_f32(_ptr(w), k, a, b, _ptr(out), _stream()), "pcs_transpose_kab_f32")
         return out
 
-    def conv_wgrad(self, fa, fb, kmap, a_col):
-        """gW[k] = sum_{pairs of k} fa[pair[a_col]]^T (x) fb[pair[1-a_col]] -> (K, ca, cb)."""
+    def conv_wgrad(self, fa, fb, kmap, a_col, split=False):
+        """gW[k] = sum_{pairs of k} fa[pair[a_col]]^T (x) fb[pair[1-a_col]] -> (K, ca, cb). split=True: the operands go
+        through the bf16 MFMAs as three bf16 planes each (fp32-grade result, pcs_conv_wgrad_f32_bf16x3)."""
         fa = _dev(fa, "input", torch.float32)
         fb = _dev(fb, "grad_output", torch.float32)
         ca, cb = fa.shape[1], fb.shape[1]
         gw = torch.empty((kmap.K, ca, cb), dtype=torch.float32, device=fa.device)
         ws_bytes = self.lib.pcs_conv_wgrad_ws_bytes(kmap._koff_c, kmap.K, ca, cb)
         ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=fa.device)
-        _check(self.lib.pcs_conv_wgrad_f32(_ptr(fa), ca, _ptr(fb), cb, _ptr(kmap.pairs), a_col,
-                                           _ptr(kmap.koff), kmap._koff_c, kmap.K, _ptr(gw), _ptr(ws),
-                                           ws_bytes, _stream()), "pcs_conv_wgrad_f32")
+        fn = self.lib.pcs_conv_wgrad_f32_bf16x3 if split else self.lib.pcs_conv_wgrad_f32
+        _check(fn(_ptr(fa), ca, _ptr(fb), cb, _ptr(kmap.pairs), a_col, _ptr(kmap.koff), kmap._koff_c, kmap.K, _ptr(gw),
+                  _ptr(ws), ws_bytes, _stream()), "pcs_conv_wgrad_f32")
         return gw
 
 

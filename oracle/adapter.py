@@ -113,7 +113,7 @@ class OracleBackend:
         out = torch.from_numpy(out)
         return out + bias if bias is not None else out
 
-    def conv_wgrad(self, fa, fb, kmap, a_col):
+    def conv_wgrad(self, fa, fb, kmap, a_col, split=False):
         k, ca, cb = kmap.K, fa.shape[1], fb.shape[1]
         w0 = np.zeros((k, ca, cb), dtype=np.float32)
         _, gw = orc.conv_bwd(_np(fa), _np(fb), w0, _np(kmap.pairs), _np(kmap.nbsizes), transposed=bool(a_col))
@@ -229,7 +229,7 @@ class RefBackend(OracleBackend):
                                          kmap.nbsizes.int(), False)
         return out + bias if bias is not None else out
 
-    def conv_wgrad(self, fa, fb, kmap, a_col):
+    def conv_wgrad(self, fa, fb, kmap, a_col, split=False):
         k, ca, cb = kmap.K, fa.shape[1], fb.shape[1]
         gin = torch.zeros_like(fa)
         gw = torch.zeros(k, ca, cb)

@@ -115,6 +115,10 @@ def test_conv_backward_dense_map(hip, levels, stride, cin, cout):
     gw = hip.conv_wgrad(t(x), t(gy), entry.fwd, 0)
     close(gw, ogw, 2e-5)
     assert torch.equal(gw, hip.conv_wgrad(t(x), t(gy), entry.fwd, 0))
+    # the same gradient through the bf16 MFMAs (three bf16 planes per operand, six products): fp32-grade, same bound
+    gws = hip.conv_wgrad(t(x), t(gy), entry.fwd, 0, split=True)
+    close(gws, ogw, 2e-5)
+    assert torch.equal(gws, hip.conv_wgrad(t(x), t(gy), entry.fwd, 0, split=True))
 
 
 def test_strided_maps_full_frame_bit_exact(hip, levels):

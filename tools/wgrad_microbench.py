@@ -24,8 +24,8 @@ def main():
     shapes = [(1, 32, 32), (1, 96, 96), (1, 128, 96), (2, 64, 64), (2, 96, 96), (4, 128, 128), (4, 192, 128), (8, 256, 256),
               (8, 384, 256), (16, 256, 256)]
     print("wgrad kernel: %s" % ("wgrad2 (fp32 MFMA)" if os.environ.get("PCS_WGRAD3") == "0" else "wgrad3 (16-bit MFMA)"))
-    print("| stride | N | P | cin x cout | fp32 ms | fp32 TFLOP/s | bf16 ms | bf16 TFLOP/s |")
-    print("|---|---|---|---|---|---|---|---|")
+    print("| stride | N | P | cin x cout | fp32 ms | fp32 TFLOP/s | fp32 via bf16x3 ms | bf16 ms | bf16 TFLOP/s |")
+    print("|---|---|---|---|---|---|---|---|---|")
     tot32 = tot16 = 0.0
     for s, cin, cout in shapes:
         c = lv[s]
@@ -34,12 +34,13 @@ def main():
         x = torch.randn(n, cin, device=dev)
         gy = torch.randn(n, cout, device=dev)
         t32 = timed(lambda: be.conv_wgrad(x, gy, entry.fwd, 0))
+        t3 = timed(lambda: be.conv_wgrad(x, gy, entry.fwd, 0, split=True))
         xh, gh = x.bfloat16(), gy.bfloat16()
         t16 = timed(lambda: be.conv_wgrad_h(xh, gh, entry.fwd, 0))
         fl = 2.0 * p * cin * cout
         tot32 += t32
         tot16 += t16
-        print("| %d | %d | %d | %d x %d | %.3f | %.1f | %.3f | %.1f |" % (s, n, p, cin, cout, t32, fl / t32 / 1e9, t16, fl / t16 / 1e9))
+        print("| %d | %d | %d | %d x %d | %.3f | %.1f | %.3f | %.3f | %.1f |" % (s, n, p, cin, cout, t32, fl / t32 / 1e9, t3, t16, fl / t16 / 1e9))
     print("total: fp32 %.2f ms, bf16 %.2f ms" % (tot32, tot16))
 
 
