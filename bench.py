@@ -58,13 +58,14 @@ class ConvMeter:
             self.records.append((e0, e1, kmap, (k, cin, cout), n_src, kind))  # pair counts are read at summary time
             return out
 
-        def wrapped32(src, weight, kmap, bias=None, tile_rows=None):
+        def wrapped32(src, weight, kmap, bias=None, tile_rows=None, **kw):
             k, cin, cout = weight.shape
-            return timed(lambda: self.orig["f32"](src, weight, kmap, bias, tile_rows), "f32", kmap, k, cin, cout, src.shape[0])
+            return timed(lambda: self.orig["f32"](src, weight, kmap, bias, tile_rows, **kw), "f32", kmap, k, cin, cout,
+                         src.shape[0])
 
-        def wrapped16(src, wp, k, cout, kmap, bias=None, tile_rows=None):
-            return timed(lambda: self.orig["half"](src, wp, k, cout, kmap, bias, tile_rows), "half", kmap, k, src.shape[1],
-                         cout, src.shape[0])
+        def wrapped16(src, wp, k, cout, kmap, bias=None, tile_rows=None, **kw):
+            return timed(lambda: self.orig["half"](src, wp, k, cout, kmap, bias, tile_rows, **kw), "half", kmap, k,
+                         src.shape[1], cout, src.shape[0])
         self.be.conv_gather_gemm, self.be.conv_gather_gemm_h = wrapped32, wrapped16
         return self
 

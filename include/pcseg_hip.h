@@ -202,10 +202,17 @@ int pcs_rulebook_tile_segments(const int32_t *pairs, const int32_t *koff, int32_
  */
 int32_t pcs_conv_tile_rows(int32_t cin, int32_t cout);
 int32_t pcs_conv_pick_tile_rows(int64_t n_dst, int64_t n_pairs, int32_t K, int32_t cin, int32_t cout);
+/* *   bn_partial (may be NULL): [ceil(n_dst / tile_rows)][2][cout] doubles. When given, the write-back also leaves, per
+ *   tile and column, sum(x) and sum(x^2) of the rows it stored: the statistics pass of the BatchNorm that follows
+ *   the convolution (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:31-129) costs no extra read of the tensor;
+ *   pcs_bn_reduce_partials turns them into the `sums` vector of pcs_bn_finalize_f32. Only for shapes / tile heights
+ *   with pcs_conv_emits_bn_partials(...) != 0 (PCS_EUNSUPPORTED otherwise).
+ */
+int32_t pcs_conv_emits_bn_partials(int32_t cin, int32_t cout, int32_t K, int32_t tile_rows, int32_t dtype);
 int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t cin, const float *W,
                              int32_t K, int32_t cout, const int32_t *pairs, int32_t src_col,
                              const int32_t *seg, int32_t tile_rows, int64_t n_dst,
-                             const float *bias, float *dst, void *stream);
+                             const float *bias, float *dst, double *bn_partial, void *stream);
 
 /* dst[k][b][a] = src[k][a][b]: the per-offset transposed weights dgrad contracts with (the reference transposes
  * inside torch::mm_out per offset, convolution_cuda.cu:259-263). */
@@ -285,6 +292,7 @@ int pcs_denselize_bwd_f32(const float *gout, const int32_t *count_map, const int
  */
 int32_t pcs_bn_num_partials(void);
 int pcs_bn_stats_f32(const float *x, int64_t n, int32_t c, float *partial_ws, double *sums, void *stream);
+int pcs_bn_reduce_partials(const double *partial, int64_t nrows, int32_t c, int64_t n, double *sums, void *stream);
 int pcs_bn_finalize_f32(const double *sums, double count, const double *count_dev, int32_t c, double eps,
                         double momentum, float *running_mean, float *running_var, double *stat, void *stream);
 int pcs_bn_apply_f32(const float *x, const float *res, const double *stat, const float *w, const float *b,
@@ -347,7 +355,7 @@ int pcs_conv_prepare_weights_h(const float *W, int32_t K, int32_t A, int32_t B, 
                                void *Wp, void *stream);
 int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t cin, const void *Wp, int32_t K, int32_t cout,
                            const int32_t *pairs, int32_t src_col, const int32_t *seg, int32_t tile_rows,
-                           int64_t n_dst, const float *bias, void *dst, int32_t dtype, void *stream);
+                           int64_t n_dst, const float *bias, void *dst, int32_t dtype, double *bn_partial, void *stream);
 /* fp32 operands through the bf16 MFMAs (three-plane split, six products, fp32-grade result); same arguments as _f32 */
 int pcs_conv_wgrad_f32_bf16x3(const float *fa, int32_t ca, const float *fb, int32_t cb, const int32_t *pairs,
                               int32_t a_col, const int32_t *koff_dev, const int32_t *koff_host, int32_t K, float *gW,

@@ -100,11 +100,32 @@ extern "C" int32_t pcs_conv_pick_tile_rows(int64_t n_dst, int64_t n_pairs, int32
   return best;
 }
 
+// 1 when the fused convolution of this shape can leave per-tile BatchNorm partial sums in its write-back (the wave
+// kernels; the tile must hold the reduction scratch). dtype 0: fp32 kernels, 1 / 2: half kernels.
+extern "C" int32_t pcs_conv_emits_bn_partials(int32_t cin, int32_t cout, int32_t K, int32_t tile_rows, int32_t dtype) {
+  if (cin <= 0 || cout <= 0 || K <= 0 || K > 32 || (cin % 4) || (cout % 4) || tile_rows < 16) return 0;
+  int nctt = conv_nctt(cout), nt = 256;
+  if (dtype == 0) {
+    if (conv5_applies(cin, cout, K)) {
+      if (cout >= 192 && tile_rows >= 192) nctt = 4;
+      const size_t lds = (size_t)((tile_rows + 1) * (16 * nctt + 4)) * 4 + 1024;
+      nt = 2 * lds > 160 * 1024 ? 512 : 256;
+    } else if (tile_rows != 64 && tile_rows != 128) {
+      return 0;
+    }
+  } else {
+    if (!convh_applies(cin, cout, K)) return 0;
+    const size_t lds = (size_t)((tile_rows + 1) * (16 * nctt + 4)) * 4 + 1024;
+    nt = 2 * lds > 160 * 1024 ? 512 : 256;
+  }
+  return conv_stats_fit(tile_rows, 16 * nctt, nt) ? 1 : 0;
+}
+
 extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t cin,
                                         const float *W, int32_t K, int32_t cout,
                                         const int32_t *pairs, int32_t src_col,
                                         const int32_t *seg, int32_t tile_rows, int64_t n_dst,
-                                        const float *bias, float *dst, void *stream) {
+                                        const float *bias, float *dst, double *bn_partial, void *stream) {
   if (cin <= 0 || cout <= 0 || K <= 0 || n_dst < 0 || n_src < 0 || (src_col != 0 && src_col != 1)) {
     set_error("pcs_conv_gather_gemm_f32: bad sizes");
     return PCS_EINVAL;
@@ -115,12 +136,20 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
   ConvArgs a;
   a.src = src; a.W = W; a.bias = bias; a.dst = dst; a.pairs = pairs; a.seg = seg;
   a.n_dst = n_dst; a.ntiles = ceil_div(n_dst, tile_rows); a.tile_rows = tile_rows;
-  a.cin = cin; a.cout = cout; a.K = K; a.src_col = src_col; a.ncoltiles = 1;
+  a.cin = cin; a.cout = cout; a.K = K; a.src_col = src_col; a.ncoltiles = 1; a.stats = bn_partial;
+  if (bn_partial && !pcs_conv_emits_bn_partials(cin, cout, K, tile_rows, 0)) {
+    set_error("pcs_conv_gather_gemm_f32: this shape / tile height does not produce BatchNorm partials (ask pcs_conv_emits_bn_partials)");
+    return PCS_EUNSUPPORTED;
+  }
   static const int xcd = getenv("PCS_CONV_XCD") ? atoi(getenv("PCS_CONV_XCD")) : 1;  // 0: no XCD-contiguous tile order (debug)
   a.xcd_remap = xcd;
   const bool vec = (cin % 4 == 0) && (cout % 4 == 0) && (((uintptr_t)src | (uintptr_t)W | (uintptr_t)dst | (uintptr_t)bias) & 15) == 0;
   hipStream_t st = as_stream(stream);
   static const int generic = getenv("PCS_CONV_V1") ? atoi(getenv("PCS_CONV_V1")) : 0;  // 1: generic kernel only (debug)
+  if (bn_partial && (!vec || generic || (!conv5_applies(cin, cout, K) && K > 32))) {
+    set_error("pcs_conv_gather_gemm_f32: BatchNorm partials need the 16-byte-granular wave kernels");
+    return PCS_EUNSUPPORTED;
+  }
   if (vec && !generic && conv5_applies(cin, cout, K)) return launch_conv_wave5(a, st);
   if (tile_rows != 64 && tile_rows != 128) { set_error("pcs_conv_gather_gemm_f32: this shape takes tile_rows 64 or 128"); return PCS_EUNSUPPORTED; }
   if (vec && !generic && K <= 32) return launch_conv_wave4(a, st);

@@ -37,6 +37,7 @@ struct ConvArgs {
   int64_t n_dst;
   int64_t ntiles;
   int cin, cout, K, src_col, ncoltiles, xcd_remap, tile_rows;
+  double *stats;  // optional [ntiles][2][cout]: per-tile column sums / sums of squares of the rows written (BatchNorm)
 };
 
 // storage-format tags of the half-precision kernels (features / prepared weights / outputs)
@@ -76,6 +77,57 @@ inline bool conv5_applies(int cin, int cout, int K) {
 inline bool convh_applies(int cin, int cout, int K) {
   return cin % 32 == 0 && cin >= 32 && cout % 4 == 0 && K <= 32 && conv_nctt(cout) % 2 == 0;
 }
+
+// Tile epilogue of the wave kernels. The fp32 accumulator tile acc_l[T+1][ACS] is complete (the caller has passed its
+// __syncthreads()). A thread owns one 4-column quad and every NRG-th row: each row is stored once (+bias) through
+// `store(r, cq, v)`, which returns the value AS STORED (the rounded one for half outputs). With `stats` the kernel also
+// leaves, per tile and column, sum(x) and sum(x^2) over the rows it wrote -- the statistics pass of the BatchNorm that
+// follows the convolution: the sums are taken about the tile's first row in fp32, reduced over
+// the row groups in a fixed order through the (now free) tile, and un-shifted in double (deterministic; needs
+// T >= 2 NRG rows of scratch, conv_stats_fit()).
+template <int CT, int NT, typename Store>
+__device__ __forceinline__ void conv_tile_epilogue(float *acc_l, int ACS, int rows, int n0, int cout, const float *bias,
+                                                   double *stats, int tid, Store store) {
+  constexpr int Q = CT / 4, NRG = NT / Q;
+  const int q = tid % Q, rg = tid / Q, cq = 4 * q;
+  const bool on = rg < NRG && n0 + cq < cout;
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f), piv = b, s0 = b, s1 = b;
+  if (on) {
+    if (bias) b = *reinterpret_cast<const float4 *>(bias + n0 + cq);
+    if (stats) {
+      piv = *reinterpret_cast<const float4 *>(acc_l + cq);
+      piv.x += b.x; piv.y += b.y; piv.z += b.z; piv.w += b.w;
+    }
+    for (int r = rg; r < rows; r += NRG) {
+      float4 v = *reinterpret_cast<const float4 *>(acc_l + r * ACS + cq);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      const float4 sv = store(r, cq, v);
+      if (stats) {
+        const float dx = sv.x - piv.x, dy = sv.y - piv.y, dz = sv.z - piv.z, dw = sv.w - piv.w;
+        s0.x += dx; s0.y += dy; s0.z += dz; s0.w += dw;
+        s1.x += dx * dx; s1.y += dy * dy; s1.z += dz * dz; s1.w += dw * dw;
+      }
+    }
+  }
+  if (stats) {  // kernel argument: uniform over the launch
+    __syncthreads();
+    if (on) {
+      *reinterpret_cast<float4 *>(acc_l + (2 * rg) * ACS + cq) = s0;
+      *reinterpret_cast<float4 *>(acc_l + (2 * rg + 1) * ACS + cq) = s1;
+      if (rg == 0) *reinterpret_cast<float4 *>(acc_l + (2 * NRG) * ACS + cq) = piv;
+    }
+    __syncthreads();
+    if (tid < CT && n0 + tid < cout) {
+      double t0 = 0.0, t1 = 0.0;
+      for (int h = 0; h < NRG; ++h) { t0 += (double)acc_l[(2 * h) * ACS + tid]; t1 += (double)acc_l[(2 * h + 1) * ACS + tid]; }
+      const double p = (double)acc_l[(2 * NRG) * ACS + tid], dn = (double)rows;
+      stats[n0 + tid] = t0 + dn * p;
+      stats[cout + n0 + tid] = t1 + 2.0 * p * t0 + dn * p * p;
+    }
+  }
+}
+// rows of tile scratch the statistics need: 2 per row group + the pivot row
+inline bool conv_stats_fit(int tile_rows, int ct, int nt) { return tile_rows + 1 >= 2 * (nt / (ct / 4)) + 1; }
 
 // launchers (each picks its template instance from the shape; `a.ncoltiles` is set inside)
 int launch_conv_block(ConvArgs a, bool vec, hipStream_t st);   // any shape; tile_rows 64 / 128

@@ -272,17 +272,13 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os4_kernel(ConvArgs a) {
   __syncthreads();
   // ---- epilogue: every dst row written once ---------------------------------------------------------
   const int rows = (int)((a.n_dst - row0) < (int64_t)T ? (a.n_dst - row0) : (int64_t)T);
-  for (int e = tid; e < rows * (C::CT / 4); e += C::NT) {
-    const int r = e / (C::CT / 4), cq = (e % (C::CT / 4)) * 4;
-    if (n0 + cq < a.cout) {
-      float4 v = *reinterpret_cast<const float4 *>(acc_l + r * C::ACS + cq);
-      if (a.bias) {
-        const float4 b = *reinterpret_cast<const float4 *>(a.bias + n0 + cq);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-      }
-      *reinterpret_cast<float4 *>(a.dst + (row0 + r) * a.cout + n0 + cq) = v;
-    }
-  }
+  float *drow = a.dst + row0 * a.cout + n0;
+  const int ldd = a.cout;
+  conv_tile_epilogue<C::CT, C::NT>(acc_l, C::ACS, rows, n0, a.cout, a.bias, a.stats ? a.stats + tile * 2 * a.cout : nullptr, tid,
+                                   [&](int r, int cq, const float4 &v) {
+                                     *reinterpret_cast<float4 *>(drow + (int64_t)r * ldd + cq) = v;
+                                     return v;
+                                   });
 }
 
 template <int NCTT, int T, int NW, int MINW>

@@ -83,6 +83,7 @@ struct ConvArgsH {
   int64_t n_dst;
   int64_t ntiles;
   int cin, cout, K, src_col, ncoltiles, xcd_remap, tile_rows, nt16, ns;
+  double *stats;  // optional [ntiles][2][cout], as ConvArgs::stats (over the ROUNDED values stored)
 };
 
 template <int NCTT, int NW_, int R_>
@@ -327,20 +328,17 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
   __syncthreads();
   // epilogue: fp32 tile (+ fp32 bias) -> halfs, 8-byte stores, every dst row written once
   const int rows = (int)((a.n_dst - row0) < (int64_t)T ? (a.n_dst - row0) : (int64_t)T);
-  for (int e = tid; e < rows * (C::CT / 4); e += C::NT) {
-    const int r = e / (C::CT / 4), cq = (e % (C::CT / 4)) * 4;
-    if (n0 + cq < a.cout) {
-      float4 v = *reinterpret_cast<const float4 *>(acc_l + r * C::ACS + cq);
-      if (a.bias) {
-        const float4 b = *reinterpret_cast<const float4 *>(a.bias + n0 + cq);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-      }
-      uint2 o;
-      o.x = f2h(HT{}, v.x) | ((uint32_t)f2h(HT{}, v.y) << 16);
-      o.y = f2h(HT{}, v.z) | ((uint32_t)f2h(HT{}, v.w) << 16);
-      *reinterpret_cast<uint2 *>(a.dst + (row0 + r) * a.cout + n0 + cq) = o;
-    }
-  }
+  uint16_t *drow = a.dst + row0 * a.cout + n0;
+  const int ldd = a.cout;
+  conv_tile_epilogue<C::CT, C::NT>(acc_l, C::ACS, rows, n0, a.cout, a.bias, a.stats ? a.stats + tile * 2 * a.cout : nullptr, tid,
+                                   [&](int r, int cq, const float4 &v) {
+                                     const uint16_t hx = f2h(HT{}, v.x), hy = f2h(HT{}, v.y), hz = f2h(HT{}, v.z), hw = f2h(HT{}, v.w);
+                                     uint2 o;
+                                     o.x = hx | ((uint32_t)hy << 16);
+                                     o.y = hz | ((uint32_t)hw << 16);
+                                     *reinterpret_cast<uint2 *>(drow + (int64_t)r * ldd + cq) = o;
+                                     return make_float4(h2f(HT{}, hx), h2f(HT{}, hy), h2f(HT{}, hz), h2f(HT{}, hw));
+                                   });
 }
 
 template <typename HT, int NCTT, int NW, int MINW, int R>
@@ -415,7 +413,8 @@ extern "C" int pcs_conv_prepare_weights_h(const float *W, int32_t K, int32_t A, 
 
 extern "C" int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t cin, const void *Wp, int32_t K, int32_t cout,
                                       const int32_t *pairs, int32_t src_col, const int32_t *seg, int32_t tile_rows,
-                                      int64_t n_dst, const float *bias, void *dst, int32_t dtype, void *stream) {
+                                      int64_t n_dst, const float *bias, void *dst, int32_t dtype, double *bn_partial,
+                                      void *stream) {
   if (cin <= 0 || cout <= 0 || K <= 0 || n_dst < 0 || n_src < 0 || (src_col != 0 && src_col != 1) || (dtype != 1 && dtype != 2)) {
     set_error("pcs_conv_gather_gemm_h: bad sizes");
     return PCS_EINVAL;
@@ -429,7 +428,11 @@ extern "C" int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t ci
   a.src = reinterpret_cast<const char *>(src); a.Wp = reinterpret_cast<const char *>(Wp); a.bias = bias;
   a.dst = reinterpret_cast<uint16_t *>(dst); a.pairs = pairs; a.seg = seg;
   a.n_dst = n_dst; a.ntiles = ceil_div(n_dst, tile_rows); a.tile_rows = tile_rows;
-  a.cin = cin; a.cout = cout; a.K = K; a.src_col = src_col; a.ncoltiles = 1; a.xcd_remap = 1;
+  a.cin = cin; a.cout = cout; a.K = K; a.src_col = src_col; a.ncoltiles = 1; a.xcd_remap = 1; a.stats = bn_partial;
+  if (bn_partial && !pcs_conv_emits_bn_partials(cin, cout, K, tile_rows, dtype)) {
+    set_error("pcs_conv_gather_gemm_h: this shape / tile height does not produce BatchNorm partials");
+    return PCS_EUNSUPPORTED;
+  }
   const int nctt = conv_nctt(cout);
   a.nt16 = (int)ceil_div(cout, 16 * nctt) * nctt;
   a.ns = cin / 32;

@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const void *__restrict_
 template <typename PT>
 __global__ void __launch_bounds__(1024) bn_reduce_kernel(const PT *__restrict__ partial, int nblk, int c,
                                                          const float *__restrict__ pivot, int64_t n,
-                                                         double *__restrict__ sums) {
+                                                         double *__restrict__ sums, int write_count) {
   __shared__ double red[2][64][17];
   const int ch = blockIdx.x * 16 + threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(1024) bn_reduce_kernel(const PT *__restrict__ 
     sums[ch] = t0;
     sums[c + ch] = t1;
   }
-  if (pivot && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) sums[2 * c] = (double)n;
+  if (write_count && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) sums[2 * c] = (double)n;
 }
 
 // stat[0..c) = mean, stat[c..2c) = invstd; running stats updated like nn.BatchNorm1d (unbiased var, momentum)
@@ -323,7 +323,7 @@ static int bn_partial(bool bwd, int dtype, const void *x, const void *dy, const 
   }
     const float *pivot = bwd ? nullptr : partial + (size_t)kStatBlocks * 2 * c;  // written by workgroup 0 above
   hipLaunchKernelGGL(bn_reduce_kernel<float>, dim3((unsigned)ceil_div(c, 16)), dim3(16, 64), 0, st, partial, kStatBlocks, c,
-                     pivot, n, sums);
+                     pivot, n, sums, bwd ? 0 : 1);
   return check_launch("pcs_bn_partial");
 }
 
@@ -373,6 +373,15 @@ extern "C" int pcs_bn_stats_f32(const float *x, int64_t n, int32_t c, float *par
 extern "C" int pcs_bn_stats_h(const void *x, int64_t n, int32_t c, int32_t dtype, float *partial_ws, double *sums, void *stream) {
   if (n < 0 || c <= 0 || !x || !partial_ws || !sums || bad_half(dtype)) { set_error("pcs_bn_stats_h: bad args"); return PCS_EINVAL; }
   return bn_partial(false, dtype, x, nullptr, nullptr, nullptr, nullptr, n, c, 0, partial_ws, sums, as_stream(stream));
+}
+
+// sums (2c + 1) from the per-tile double partials a fused convolution left in its write-back
+// (pcs_conv_gather_gemm_*'s bn_partial: [nrows][2][c] raw sums) -- replaces the pcs_bn_stats_* pass over the tensor
+extern "C" int pcs_bn_reduce_partials(const double *partial, int64_t nrows, int32_t c, int64_t n, double *sums, void *stream) {
+  if (nrows < 0 || nrows > 0x7FFFFFFF || c <= 0 || n < 0 || !partial || !sums) { set_error("pcs_bn_reduce_partials: bad args"); return PCS_EINVAL; }
+  hipLaunchKernelGGL(bn_reduce_kernel<double>, dim3((unsigned)ceil_div(c, 16)), dim3(16, 64), 0, as_stream(stream), partial,
+                     (int)nrows, c, (const float *)nullptr, n, sums, 1);
+  return check_launch("pcs_bn_reduce_partials");
 }
 
 extern "C" int pcs_bn_finalize_f32(const double *sums, double count, const double *count_dev, int32_t c, double eps,

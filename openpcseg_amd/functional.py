@@ -191,26 +191,35 @@ class _SparseConv(Function):
     computed in fp32 and their output rounded to the half dtype, like the reference's half pipeline would hand on."""
 
     @staticmethod
-    def forward(ctx, input, weight, entry, transposed):
+    def forward(ctx, input, weight, entry, transposed, want_stats=False):
+        """want_stats: also return the BatchNorm statistics vector of the output ([sum x | sum x^2 | n], float64) when
+        the kernel produced it in its write-back, else an empty tensor (the BatchNorm then runs its own pass)."""
         be = _be()
         hd = _amp_dtype(input)
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
         k, cin, cout = w3.shape
         kmap = entry.rev if transposed else entry.fwd
+        got = [] if want_stats else None
+        kw = {"bn_sums": got} if want_stats else {}
         if hd is not None and input.is_cuda and be.conv_h_applies(cin, cout, k):
             x = input.contiguous().to(hd)
             wp = be.prepare_weights_h(w3.detach().float().contiguous(), hd, transpose=False)
-            out = be.conv_gather_gemm_h(x, wp, k, cout, kmap)
+            out = be.conv_gather_gemm_h(x, wp, k, cout, kmap, **kw)
         else:
             x = input.contiguous().float()
-            out = be.conv_gather_gemm(x, w3.float().contiguous(), kmap)
+            out = be.conv_gather_gemm(x, w3.float().contiguous(), kmap, **kw)
             if hd is not None:
                 out = out.to(hd)
+                got = [] if want_stats else None  # statistics of the fp32 values, not of the rounded ones: not used
         ctx.for_backwards = (x, weight, entry, transposed, hd)
-        return out
+        if not want_stats:
+            return out
+        sums = got[0] if got else torch.empty(0, dtype=torch.float64, device=out.device)
+        ctx.mark_non_differentiable(sums)
+        return out, sums
 
     @staticmethod
-    def backward(ctx, grad_output):
+    def backward(ctx, grad_output, *_unused):
         be = _be()
         x, weight, entry, transposed, hd = ctx.for_backwards
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
@@ -235,7 +244,7 @@ class _SparseConv(Function):
             else:
                 grad_weight = be.conv_wgrad(x.float(), grad_output.contiguous().float(), entry.fwd, a_col)
             grad_weight = grad_weight.view_as(weight).to(weight.dtype)
-        return grad_input, grad_weight, None, None
+        return grad_input, grad_weight, None, None, None
 
 
 def _identity_map(n, device, cache):
@@ -287,11 +296,21 @@ class _PointwiseConv(Function):
         return gin, gw, None
 
 
-def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transposed=False):
+def _sparse_conv(feats, weight, entry, transposed, bn_stats):
+    if not bn_stats:
+        return _SparseConv.apply(feats, weight, entry, transposed), None
+    out, sums = _SparseConv.apply(feats, weight, entry, transposed, True)
+    return out, (sums if sums.numel() else None)
+
+
+def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transposed=False, bn_stats=False):
+    """bn_stats (not in the reference's signature; used by the fused blocks): ask the convolution for the BatchNorm
+    statistics of its output; they are attached to the returned tensor as `.bn_sums` when the kernel produced them."""
     kernel_size = make_ntuple(kernel_size, ndim=3)
     stride = make_ntuple(stride, ndim=3)
     dilation = make_ntuple(dilation, ndim=3)
     ones = (1, 1, 1)
+    bn_sums = None
 
     if kernel_size == ones and stride == ones and dilation == ones:
         output_stride = input.stride
@@ -312,12 +331,12 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
         if key not in input.kmaps:
             input.kmaps[key] = build_kernel_map(input.coords, output_coords, kernel_size,
                                                 input.stride, dilation)
-        output_feats = _SparseConv.apply(input.feats, weight, input.kmaps[key], False)
+        output_feats, bn_sums = _sparse_conv(input.feats, weight, input.kmaps[key], False, bn_stats and bias is None)
     else:
         output_stride = tuple(input.stride[k] // stride[k] for k in range(3))
         output_coords = input.cmaps[output_stride]
         key = (output_stride, kernel_size, stride, dilation)
-        output_feats = _SparseConv.apply(input.feats, weight, input.kmaps[key], True)
+        output_feats, bn_sums = _sparse_conv(input.feats, weight, input.kmaps[key], True, bn_stats and bias is None)
 
     if bias is not None:
         output_feats += bias
@@ -326,6 +345,8 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
     output.cmaps = input.cmaps
     output.cmaps.setdefault(output_stride, output_coords)
     output.kmaps = input.kmaps
+    if bn_sums is not None:
+        output.bn_sums = bn_sums
     return output
 
 

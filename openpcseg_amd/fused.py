@@ -48,12 +48,13 @@ class _FusedBN(Function):
     scale / shift and running stats are fp32 / double whatever the storage format."""
 
     @staticmethod
-    def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, sync, cache, level):
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, sync, cache, level, pre=None):
         be = native.backend()
         x = x.contiguous()
         res = res.contiguous() if res is not None else None
         n, c = x.shape
-        sums = be.bn_stats(x)  # [sum x | sum x^2 | n]
+        # [sum x | sum x^2 | n]: handed over by the producing convolution (its write-back computed them), else one pass
+        sums = pre.clone() if pre is not None and pre.numel() == 2 * c + 1 else be.bn_stats(x)
         count, count_dev = float(n), None
         if sync and _world() > 1:
             # ONE collective per layer and direction: the row count rides in the statistics vector and the global
@@ -86,7 +87,7 @@ class _FusedBN(Function):
         dx, dres = be.bn_bwd_apply(dy, x, gate, stat, sums2, count, weight, relu, has_res, count_dev=count_dev)
         dw = local[c:].to(weight.dtype) if weight is not None else None   # local sums: DDP averages parameter grads
         db = local[:c].to(weight.dtype) if weight is not None else None
-        return dx, dres, dw, db, None, None, None, None, None, None, None, None
+        return dx, dres, dw, db, None, None, None, None, None, None, None, None, None
 
 
 class FusedBatchNorm(nn.Module):
@@ -111,7 +112,7 @@ class FusedBatchNorm(nn.Module):
         if self.training:
             self.num_batches_tracked += 1
             y = _FusedBN.apply(x, r, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                               self.momentum, relu, self.sync, input.cmaps, input.stride)
+                               self.momentum, relu, self.sync, input.cmaps, input.stride, getattr(input, "bn_sums", None))
         else:
             inv = torch.rsqrt(self.running_var.double() + self.eps)
             stat = torch.cat([self.running_mean.double(), inv]).contiguous()

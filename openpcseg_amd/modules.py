@@ -37,6 +37,9 @@ class Conv3d(nn.Module):
             self.bias = nn.Parameter(torch.zeros(out_channels))
         else:
             self.register_parameter("bias", None)
+        # fused blocks (openpcseg_amd.fused) set this on convolutions that feed a FusedBatchNorm: the convolution then
+        # also hands over the BatchNorm statistics of its output (computed in its write-back)
+        self.emit_bn_stats = False
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -59,6 +62,9 @@ class Conv3d(nn.Module):
         return s.format(**self.__dict__)
 
     def forward(self, input):
+        if self.emit_bn_stats and self.training:
+            return F.conv3d(input, self.kernel, kernel_size=self.kernel_size, bias=self.bias, stride=self.stride,
+                            dilation=self.dilation, transposed=self.transposed, bn_stats=True)
         return F.conv3d(input, self.kernel, kernel_size=self.kernel_size, bias=self.bias,
                         stride=self.stride, dilation=self.dilation, transposed=self.transposed)
 

@@ -42,8 +42,10 @@ SIGNATURES = {
     "pcs_rulebook_tile_segments": (c_int32, [_P, _P, c_int32, c_int64, c_int32, c_int32, _P, _P]),
     "pcs_conv_tile_rows": (c_int32, [c_int32, c_int32]),
     "pcs_conv_pick_tile_rows": (c_int32, [c_int64, c_int64, c_int32, c_int32, c_int32]),
+    "pcs_conv_emits_bn_partials": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "pcs_conv_gather_gemm_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32,
-                                           _P, c_int32, c_int64, _P, _P, _P]),
+                                           _P, c_int32, c_int64, _P, _P, _P, _P]),
+    "pcs_bn_reduce_partials": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P]),
     "pcs_transpose_kab_f32": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_conv_wgrad_ws_bytes": (c_size_t, [_P, c_int32, c_int32, c_int32]),
     "pcs_conv_wgrad_f32": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P,
@@ -74,7 +76,7 @@ SIGNATURES = {
     "pcs_conv_prepared_weights_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "pcs_conv_prepare_weights_h": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_conv_gather_gemm_h": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32, _P, c_int32, c_int64,
-                                         _P, _P, c_int32, _P]),
+                                         _P, _P, c_int32, _P, _P]),
     "pcs_conv_wgrad_f32_bf16x3": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P,
                                             _P, c_size_t, _P]),
     "pcs_conv_wgrad_h": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P, _P, c_size_t, c_int32, _P]),
@@ -492,8 +494,26 @@ class HipBackend:
         return seg
 
     # -- convolution ----------------------------------------------------------------------------
-    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None):
-        """dst[d] = sum_{(s,d) in offset k} src[s] @ weight[k] (+bias); kmap dst-sorted."""
+    def _bn_partial(self, kmap, t, cin, cout, k, dtype_code, bn_sums, device):
+        """Workspace for the BatchNorm partials of one conv launch, or None when not asked for / not produced."""
+        if bn_sums is None or kmap.n_dst == 0:
+            return None
+        if not self.lib.pcs_conv_emits_bn_partials(cin, cout, k, t, dtype_code):
+            return None
+        ntiles = (kmap.n_dst + t - 1) // t
+        return torch.empty(ntiles * 2 * cout, dtype=torch.float64, device=device)
+
+    def _bn_reduce(self, partial, t, kmap, cout, bn_sums):
+        ntiles = (kmap.n_dst + t - 1) // t
+        sums = torch.empty(2 * cout + 1, dtype=torch.float64, device=partial.device)
+        _check(self.lib.pcs_bn_reduce_partials(_ptr(partial), ntiles, cout, kmap.n_dst, _ptr(sums), _stream()),
+               "pcs_bn_reduce_partials")
+        bn_sums.append(sums)
+
+    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None, bn_sums=None):
+        """dst[d] = sum_{(s,d) in offset k} src[s] @ weight[k] (+bias); kmap dst-sorted. bn_sums: a list; when the
+        kernel can, the [sum x | sum x^2 | n] vector of dst (what bn_stats(dst) returns) is appended to it, computed in
+        the convolution's write-back instead of by a pass over dst."""
         src = _dev(src, "input", torch.float32)
         weight = _dev(weight, "weight", torch.float32)
         k, cin, cout = weight.shape
@@ -506,10 +526,14 @@ class HipBackend:
         t = tile_rows or self.tile_rows(cin, cout, kmap)
         seg = self._segments(kmap, t)
         dst = torch.empty((kmap.n_dst, cout), dtype=torch.float32, device=src.device)
+        part = self._bn_partial(kmap, t, cin, cout, k, 0, bn_sums, src.device)
         _check(self.lib.pcs_conv_gather_gemm_f32(_ptr(src), src.shape[0], cin, _ptr(weight), k, cout,
                                                  _ptr(kmap._pairs_raw), 0, _ptr(seg), t, kmap.n_dst,
                                                  _ptr(bias) if bias is not None else None, _ptr(dst),
+                                                 _ptr(part) if part is not None else None,
                                                  _stream()), "pcs_conv_gather_gemm_f32")
+        if part is not None:
+            self._bn_reduce(part, t, kmap, cout, bn_sums)
         return dst
 
     # -- half-precision convolution (bf16 / fp16 MFMA) ------------------------------------------------------
@@ -532,7 +556,7 @@ class HipBackend:
                                                    _stream()), "pcs_conv_prepare_weights_h")
         return wp
 
-    def conv_gather_gemm_h(self, src, wp, k, cout, kmap, bias=None, tile_rows=None):
+    def conv_gather_gemm_h(self, src, wp, k, cout, kmap, bias=None, tile_rows=None, bn_sums=None):
         """Half-precision fused conv: src (n, cin) bf16 / fp16, wp = prepare_weights_h(...) of the same dtype."""
         if src.dtype not in self._HALF:
             raise TypeError("openpcseg_amd: conv_gather_gemm_h wants bfloat16 / float16 features, got %s" % src.dtype)
@@ -545,9 +569,13 @@ class HipBackend:
         t = tile_rows or self.tile_rows(cin, cout, kmap)
         seg = self._segments(kmap, t)
         dst = torch.empty((kmap.n_dst, cout), dtype=src.dtype, device=src.device)
+        part = self._bn_partial(kmap, t, cin, cout, k, self._HALF[src.dtype], bn_sums, src.device)
         _check(self.lib.pcs_conv_gather_gemm_h(_ptr(src), src.shape[0], cin, _ptr(wp), k, cout, _ptr(kmap._pairs_raw), 0,
                                                _ptr(seg), t, kmap.n_dst, _ptr(bias) if bias is not None else None,
-                                               _ptr(dst), self._HALF[src.dtype], _stream()), "pcs_conv_gather_gemm_h")
+                                               _ptr(dst), self._HALF[src.dtype], _ptr(part) if part is not None else None,
+                                               _stream()), "pcs_conv_gather_gemm_h")
+        if part is not None:
+            self._bn_reduce(part, t, kmap, cout, bn_sums)
         return dst
 
     def conv_wgrad_h(self, fa, fb, kmap, a_col):

@@ -7,6 +7,8 @@ concat skip, n residual blocks]; point branch = trilinear devoxelise at strides 
 Linear classifier over the concatenated point features. mk34 = NUM_LAYER [2,3,4,6,2,2,2,2],
 mk18 = [2,2,2,2,2,2,2,2]; PLANES [32,32,64,128,256,256,128,96,96] x cr.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -40,6 +42,12 @@ def _norm(c, dist):
     return _SyncBN(c) if dist else _BN(c)
 
 
+def _link(conv, bn):
+    """A convolution that feeds a FusedBatchNorm hands over the statistics of its output (conv write-back)."""
+    if isinstance(bn, FusedBatchNorm) and isinstance(conv, spnn.Conv3d):
+        conv.emit_bn_stats = os.environ.get("PCS_CONV_BN_STATS", "1") != "0"
+
+
 def _bn_act(bn, x, residual=None, relu=True, act=None):
     """BN (+residual) (+ReLU): one fused pass, or the reference's separate torch modules."""
     if isinstance(bn, FusedBatchNorm):
@@ -57,6 +65,7 @@ class ConvBlock(nn.Module):
         super().__init__()
         self.net = nn.Sequential(spnn.Conv3d(cin, cout, kernel_size=ks, stride=stride, transposed=transposed),
                                  _norm(cout, dist), spnn.ReLU(True))
+        _link(self.net[0], self.net[1])
 
     def forward(self, x):
         return _bn_act(self.net[1], self.net[0](x), act=self.net[2])
@@ -72,6 +81,8 @@ class ResBlock(nn.Module):
         else:
             self.downsample = nn.Sequential(spnn.Conv3d(cin, cout, kernel_size=1), _norm(cout, dist))
         self.relu = spnn.ReLU(True)
+        _link(self.net[0], self.net[1])
+        _link(self.net[3], self.net[4])
 
     def forward(self, x):
         h = _bn_act(self.net[1], self.net[0](x), act=self.net[2])
@@ -94,6 +105,8 @@ class MinkUNet(nn.Module):
         self.in_dim, self.pres, self.vres = in_dim, pres, vres
         self.stem = nn.Sequential(spnn.Conv3d(in_dim, cs[0], kernel_size=3), _norm(cs[0], dist), spnn.ReLU(True),
                                   spnn.Conv3d(cs[0], cs[0], kernel_size=3), _norm(cs[0], dist), spnn.ReLU(True))
+        _link(self.stem[0], self.stem[1])
+        _link(self.stem[3], self.stem[4])
         enc_in = [cs[0], cs[1], cs[2], cs[3]]
         for i in range(4):
             setattr(self, "stage%d" % (i + 1), nn.Sequential(

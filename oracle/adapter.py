@@ -105,7 +105,7 @@ class OracleBackend:
     def tile_rows(self, cin, cout):
         return 128
 
-    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None):
+    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None, bn_sums=None):
         if src.shape[1] != weight.shape[1]:
             raise ValueError("Input feature size and kernel size mismatch")
         out = orc.conv_fwd(_np(src), _np(weight), _np(kmap.pairs), _np(kmap.nbsizes),
@@ -223,7 +223,7 @@ class RefBackend(OracleBackend):
     def devoxelize_fwd(self, feats, idx8, w8):
         return self.ref.devoxelize_forward_cpu(feats.contiguous(), idx8.contiguous(), w8.contiguous())
 
-    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None):
+    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None, bn_sums=None):
         out = torch.zeros(kmap.n_dst, weight.shape[-1])
         self.ref.convolution_forward_cpu(src.contiguous(), out, weight.contiguous(), kmap.pairs,
                                          kmap.nbsizes.int(), False)

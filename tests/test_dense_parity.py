@@ -261,3 +261,43 @@ def test_conv3d_under_autocast(hip, levels, dtype):
     tol = 40 * _HALF_TOL[dtype]
     for a, b in ((hh, h32), (yh, y32), (g1h, g1), (g2h, g2), (gxh, gx)):
         assert (a.float() - b).abs().max() <= tol * b.abs().max(), ((a.float() - b).abs().max(), b.abs().max())
+
+
+# ---- BatchNorm statistics from the convolution write-back (SURVEY.md section 8 f2) ---------------------------------
+@pytest.mark.parametrize("stride,cin,cout,tile", [(4, 128, 128, None), (8, 256, 256, None), (1, 96, 96, 384), (1, 32, 32, None),
+                                                   (2, 32, 64, 128), (4, 128, 96, 112), (1, 4, 32, None)])
+def test_conv_epilogue_bn_statistics(hip, levels, stride, cin, cout, tile):
+    """[sum x | sum x^2 | n] of the conv output, produced per tile in the write-back and reduced in double, equals the
+    float64 sums over the stored tensor (what pcs_bn_stats_f32 computes with one more read) -- and the output itself
+    is bit-identical with and without the statistics."""
+    entry, nbmaps, nbsizes, n = level_map(levels, stride)
+    g = torch.Generator(device=DEV).manual_seed(cin + cout)
+    x = torch.randn(n, cin, device=DEV, generator=g) + 0.5
+    w = torch.randn(27, cin, cout, device=DEV, generator=g) / np.sqrt(cin * 27)
+    got = []
+    y = hip.conv_gather_gemm(x, w, entry.fwd, tile_rows=tile, bn_sums=got)
+    assert torch.equal(y, hip.conv_gather_gemm(x, w, entry.fwd, tile_rows=tile))
+    assert len(got) == 1 and got[0].shape == (2 * cout + 1,) and float(got[0][-1]) == n
+    yd = y.double()
+    assert torch.allclose(got[0][:cout], yd.sum(0), rtol=0, atol=1e-6 * float(yd.abs().sum(0).max()))
+    assert torch.allclose(got[0][cout:2 * cout], (yd * yd).sum(0), rtol=1e-6)
+    ref = hip.bn_stats(y)
+    stat_a = hip.bn_finalize(got[0], float(n), 1e-5, 0.1, None, None)
+    stat_b = hip.bn_finalize(ref, float(n), 1e-5, 0.1, None, None)
+    assert torch.allclose(stat_a, stat_b, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_half_conv_epilogue_bn_statistics(hip, levels, dtype):
+    """Half kernel: the statistics are those of the ROUNDED values it stored."""
+    entry, nbmaps, nbsizes, n = level_map(levels, 4)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = (torch.randn(n, 128, device=DEV, generator=g) + 0.5).to(dtype)
+    w = torch.randn(27, 128, 96, device=DEV, generator=g) / np.sqrt(128 * 27)
+    wp = hip.prepare_weights_h(w, dtype, transpose=False)
+    got = []
+    y = hip.conv_gather_gemm_h(x, wp, 27, 96, entry.fwd, bn_sums=got)
+    assert torch.equal(y, hip.conv_gather_gemm_h(x, wp, 27, 96, entry.fwd)) and len(got) == 1
+    yd = y.double()
+    assert torch.allclose(got[0][:96], yd.sum(0), rtol=0, atol=1e-6 * float(yd.abs().sum(0).max()))
+    assert torch.allclose(got[0][96:192], (yd * yd).sum(0), rtol=1e-6)
