@@ -97,13 +97,20 @@ class ConvMeter:
                          "traffic": None, "mfma_tflops": round(tflops, 1),
                          "traffic_note": "no PMC pass for the half kernels yet; the operand stream (gathered rows re-read "
                                          "per offset, weights per row-block group) comes out of L2"}, **common)
-        traffic, note = None, "no PMC traffic file matches this build"
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/conv_traffic.sh; rocprofv3 cannot run
+        # inside bench.py). The file names the kernel revision it was measured on; a stale file is refused.
+        traffic, note = None, "no PMC traffic file for this kernel revision (run tools/conv_traffic.sh)"
         tfile = os.path.join(ROOT, "profiles", "round2_conv_traffic.json")
+        rev = native.load_library().pcs_conv_kernel_revision().decode()
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
-            traffic = tj.get("hbm_bytes_per_launch")
-            note = tj.get("note", "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, FETCH doubled "
-                                  "per the gfx950 note), profiles/round2_conv_traffic.json")
+            if tj.get("kernel_revision") == rev:
+                traffic = tj.get("hbm_bytes_per_launch")
+                note = ("HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, FETCH doubled per the "
+                        "gfx950 note), profiles/round2_conv_traffic.json, kernel revision " + rev)
+            else:
+                note = "profiles/round2_conv_traffic.json was measured on kernel revision %s, this build is %s: refused" % (
+                    tj.get("kernel_revision"), rev)
         return dict({"kernel": "conv_os5_kernel / conv_os4_kernel (pcs_conv_gather_gemm_f32: fwd + dgrad)", "bound": "mfma",
                      "achieved": round(tflops, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": note}, **common)

@@ -200,6 +200,7 @@ int pcs_rulebook_tile_segments(const int32_t *pairs, const int32_t *koff, int32_
  * height for one layer call: with few dst rows (deep strides) the launch is only a few waves of
  * workgroups over the CUs, and the height is chosen so that the last wave is full.
  */
+const char *pcs_conv_kernel_revision(void); /* identifies the fused-conv kernels a measurement file was taken on */
 int32_t pcs_conv_tile_rows(int32_t cin, int32_t cout);
 int32_t pcs_conv_pick_tile_rows(int64_t n_dst, int64_t n_pairs, int32_t K, int32_t cin, int32_t cout);
 /* *   bn_partial (may be NULL): [ceil(n_dst / tile_rows)][2][cout] doubles. When given, the write-back also leaves, per

@@ -40,6 +40,7 @@ SIGNATURES = {
     "pcs_rulebook_probe": (c_int32, [_P, c_int64, _P, c_int32, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "pcs_rulebook_fill": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P]),
     "pcs_rulebook_tile_segments": (c_int32, [_P, _P, c_int32, c_int64, c_int32, c_int32, _P, _P]),
+    "pcs_conv_kernel_revision": (c_char_p, []),
     "pcs_conv_tile_rows": (c_int32, [c_int32, c_int32]),
     "pcs_conv_pick_tile_rows": (c_int32, [c_int64, c_int64, c_int32, c_int32, c_int32]),
     "pcs_conv_emits_bn_partials": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),

@@ -14,12 +14,25 @@ from .. import native
 from ..sparse import PointTensor, SparseTensor, get_kernel_offsets
 
 
+VOXEL_ORDER = os.environ.get("PCS_VOXEL_ORDER", "spatial")  # "spatial" | "hash" (the reference's row order)
+
+
 def initial_voxelize(z, init_res, after_res):
-    """Points -> stride-1 voxels ordered by ascending 60-bit hash (utils.py:11-36)."""
+    """Points -> stride-1 voxels (utils.py:11-36). Row order: the reference sorts the voxels by their 60-bit hash
+    (`torch.unique(pc_hash)`), which scatters spatial neighbours over the whole tensor, so every row a stride-1
+    convolution gathers is its own HBM fetch (3.7x the algorithmic bytes, profiles/round1_conv_traffic.json). This
+    workload orders them by (batch, x, y, z) instead -- the order spdownsample gives every coarser level -- so that the
+    rows of neighbouring voxels share L2 lines; the voxel SET, the per-voxel means and the per-point results are the
+    same (PCS_VOXEL_ORDER=hash restores the reference's order; the reference's own utils.py is untouched)."""
     fc = torch.cat([(z.C[:, :3] * init_res) / after_res, z.C[:, -1:].clone()], dim=1)
     cell = torch.floor(fc)
-    pc_hash = F.sphash(cell.int())
-    voxel_hash = torch.unique(pc_hash)
+    icell = cell.int()
+    pc_hash = F.sphash(icell)
+    be = native.backend()
+    if VOXEL_ORDER == "spatial" and icell.is_cuda and hasattr(be, "downsample"):
+        voxel_hash = F.sphash(be.downsample(icell.contiguous(), [1, 1, 1]))  # unique cells in (b, x, y, z) order
+    else:
+        voxel_hash = torch.unique(pc_hash)
     idx_query = F.sphashquery(pc_hash, voxel_hash)
     counts = F.spcount(idx_query.int(), len(voxel_hash))
     coords = torch.round(F.spvoxelize(cell, idx_query, counts)).int()
