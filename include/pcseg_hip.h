@@ -337,6 +337,14 @@ int pcs_quantize_flags(const int64_t *sorted_keys, int64_t n, int32_t *flags, vo
 int pcs_quantize_emit(const int32_t *flags, const int64_t *rank, const int64_t *perm, const int32_t *coords,
                       int64_t n, int32_t *vox, int64_t *index, int64_t *inverse, void *stream);
 
+/* Unique keys + inverse map + CSR row pointers from a STABLY sorted key vector (flags from pcs_quantize_flags, rank =
+ * their inclusive scan, perm = the sort's row permutation): uniq (m), inverse (n) = run index of every original row,
+ * rowptr (m + 1) = first sorted position of every run (rowptr[m] = n). One pass for what initial_voxelize
+ * (R:pcseg/model/segmentor/voxel/minkunet/utils.py:16-19) gets from torch.unique + sphashquery + spcount; the sorted
+ * order doubles as the CSR of the segmented spvoxelize that follows. */
+int pcs_unique_emit(const int32_t *flags, const int64_t *rank, const int64_t *perm, const int64_t *sorted_keys,
+                    int64_t n, int64_t *uniq, int64_t *inverse, int64_t *rowptr, void *stream);
+
 /* ---- half-precision convolution (bf16 / fp16 storage, 16-bit MFMA, fp32 accumulate) --------------
  * The mixed-precision path of the reference: under `--amp` its ops cast their inputs to half
  * (TS:torchsparse/nn/functional/conv.py:19) and convolution_cuda.cu:61,120-127 runs gather / mm / scatter

@@ -80,7 +80,32 @@ __global__ void __launch_bounds__(256) quantize_emit_kernel(const int32_t *__res
   }
 }
 
+// Run heads of a sorted key vector -> unique keys, inverse map and CSR row pointers in one pass (the voxel set of
+// initial_voxelize: R:pcseg/model/segmentor/voxel/minkunet/utils.py:16-19 does torch.unique + a hash-table query + a
+// histogram for the same three results). rank = inclusive scan of the flags.
+__global__ void __launch_bounds__(256) unique_emit_kernel(const int32_t *__restrict__ flags, const int64_t *__restrict__ rank,
+                                                          const int64_t *__restrict__ perm, const int64_t *__restrict__ skeys,
+                                                          int64_t n, int64_t *__restrict__ uniq, int64_t *__restrict__ inverse,
+                                                          int64_t *__restrict__ rowptr) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = rank[i] - 1;
+    inverse[perm[i]] = v;
+    if (flags[i]) { uniq[v] = skeys[i]; rowptr[v] = i; }
+    if (i == n - 1) rowptr[v + 1] = n;
+  }
+}
+
 }  // namespace
+
+extern "C" int pcs_unique_emit(const int32_t *flags, const int64_t *rank, const int64_t *perm, const int64_t *sorted_keys,
+                               int64_t n, int64_t *uniq, int64_t *inverse, int64_t *rowptr, void *stream) {
+  if (n < 0) { set_error("pcs_unique_emit: bad size"); return PCS_EINVAL; }
+  if (n == 0) return PCS_OK;
+  if (!flags || !rank || !perm || !sorted_keys || !uniq || !inverse || !rowptr) { set_error("pcs_unique_emit: null pointer"); return PCS_EINVAL; }
+  hipLaunchKernelGGL(unique_emit_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), flags, rank, perm,
+                     sorted_keys, n, uniq, inverse, rowptr);
+  return check_launch("pcs_unique_emit");
+}
 
 extern "C" int pcs_quantize_floor(const void *points, int32_t is_float, int64_t n, int32_t row_stride,
                                   const double *voxel_size3, int32_t *coords, int32_t *bbox, void *stream) {

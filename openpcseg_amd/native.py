@@ -81,6 +81,7 @@ SIGNATURES = {
     "pcs_conv_wgrad_f32_bf16x3": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P,
                                             _P, c_size_t, _P]),
     "pcs_conv_wgrad_h": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P, _P, c_size_t, c_int32, _P]),
+    "pcs_unique_emit": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "pcs_cylinder_partition_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "pcs_voxel_label_vote": (c_int32, [_P, _P, c_int64, c_int64, c_int32, c_int64, _P, _P, _P, _P]),
     "pcs_rows_argmax_gather_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
@@ -837,6 +838,30 @@ class HipBackend:
                                           _ptr(inverse) if want_inverse else None, _stream()), "pcs_quantize_emit")
         return vox, index, inverse
 
+
+    def unique_inverse_csr(self, keys):
+        """keys (n,) int64 -> (uniq (m,) ascending, inverse (n,) int64, counts (m,) int32); the stable sort behind it is
+        kept as the segmented-reduction CSR of `inverse` (cached on the returned tensor, so spvoxelize over it sorts
+        nothing). One radix sort + three streaming passes for torch.unique + sphashquery + spcount."""
+        keys = _dev(keys, "keys", torch.int64)
+        n = keys.numel()
+        dev = keys.device
+        if n == 0:
+            z = torch.empty(0, dtype=torch.int64, device=dev)
+            return z, z.clone(), torch.empty(0, dtype=torch.int32, device=dev)
+        skeys, perm = torch.sort(keys, stable=True)
+        flags = torch.empty(n, dtype=torch.int32, device=dev)
+        _check(self.lib.pcs_quantize_flags(_ptr(skeys), n, _ptr(flags), _stream()), "pcs_quantize_flags")
+        rank = torch.cumsum(flags, dim=0, dtype=torch.int64)
+        m = int(rank[-1].item())  # the one host sync (torch.unique has the same one): sizes the outputs
+        uniq = torch.empty(m, dtype=torch.int64, device=dev)
+        inverse = torch.empty(n, dtype=torch.int64, device=dev)
+        rowptr = torch.empty(m + 1, dtype=torch.int64, device=dev)
+        _check(self.lib.pcs_unique_emit(_ptr(flags), _ptr(rank), _ptr(perm), _ptr(skeys), n, _ptr(uniq), _ptr(inverse),
+                                        _ptr(rowptr), _stream()), "pcs_unique_emit")
+        counts = (rowptr[1:] - rowptr[:-1]).int()
+        inverse._pcs_vox_csr = (_cache_key(inverse) + (m, n), (perm, rowptr))  # what voxelize_fwd would sort for
+        return uniq, inverse, counts
 
     # -- cylinder front-end ------------------------------------------------------------------------------
     def cylinder_partition(self, points, space_min, space_max, grid_size, want_polar=True, want_feat=True):

@@ -31,10 +31,17 @@ def initial_voxelize(z, init_res, after_res):
     be = native.backend()
     if VOXEL_ORDER == "spatial" and icell.is_cuda and hasattr(be, "downsample"):
         voxel_hash = F.sphash(be.downsample(icell.contiguous(), [1, 1, 1]))  # unique cells in (b, x, y, z) order
+        idx_query = F.sphashquery(pc_hash, voxel_hash)
+        counts = F.spcount(idx_query.int(), len(voxel_hash))
+    elif icell.is_cuda and hasattr(be, "unique_inverse_csr") and os.environ.get("PCS_FUSED_VOXELIZE", "1") != "0":
+        # torch.unique + sphashquery + spcount of the reference (utils.py:17-19) from ONE stable sort of the point
+        # hashes: unique hashes (ascending), point -> voxel map, counts; the sort is also the CSR of the two
+        # segmented spvoxelize passes below (no table build + probe, no second sort)
+        voxel_hash, idx_query, counts = be.unique_inverse_csr(pc_hash)
     else:
         voxel_hash = torch.unique(pc_hash)
-    idx_query = F.sphashquery(pc_hash, voxel_hash)
-    counts = F.spcount(idx_query.int(), len(voxel_hash))
+        idx_query = F.sphashquery(pc_hash, voxel_hash)
+        counts = F.spcount(idx_query.int(), len(voxel_hash))
     coords = torch.round(F.spvoxelize(cell, idx_query, counts)).int()
     feats = F.spvoxelize(z.F, idx_query, counts)
     x = SparseTensor(feats, coords, 1)

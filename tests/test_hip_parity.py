@@ -691,3 +691,21 @@ def test_minkunet_step_under_autocast(hip, dtype):
         if p.dim() >= 2 and g32[n].abs().max() > 0:
             cos.append(float(torch.nn.functional.cosine_similarity(p.grad.flatten(), g32[n].flatten(), dim=0)))
     assert np.median(cos) > 0.9, np.median(cos)
+
+
+def test_unique_inverse_csr(hip):
+    """torch.unique + sphashquery + spcount of initial_voxelize (utils.py:17-19) from one stable sort: unique hashes
+    ascending, point -> voxel map, counts -- bit-exact; and the sort reused as the CSR of spvoxelize."""
+    from openpcseg_amd import functional as F
+    rng = np.random.default_rng(4)
+    cells = np.concatenate([rng.integers(0, 40, size=(200000, 3)), rng.integers(0, 3, size=(200000, 1))], axis=1).astype(np.int32)
+    h = hip.hash(t(cells))
+    uniq, inv, counts = hip.unique_inverse_csr(h)
+    ru, rinv, rc = torch.unique(h, return_inverse=True, return_counts=True)
+    assert torch.equal(uniq, ru) and torch.equal(inv, rinv) and torch.equal(counts.long(), rc)
+    assert torch.equal(F.sphashquery(h, uniq), inv) and torch.equal(F.spcount(inv.int(), uniq.numel()), counts)
+    feats = t(rng.normal(size=(200000, 7)).astype(np.float32))
+    out = F.spvoxelize(feats, inv, counts)                      # uses the cached sort
+    close(out, orc.voxelize_fwd(feats.cpu().numpy(), inv.cpu().numpy().astype(np.int32), counts.cpu().numpy()), 1e-5)
+    e = hip.unique_inverse_csr(torch.zeros(0, dtype=torch.int64, device=DEV))
+    assert e[0].numel() == 0 and e[1].numel() == 0 and e[2].numel() == 0
