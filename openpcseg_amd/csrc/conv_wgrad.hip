@@ -479,9 +479,6 @@ __device__ __forceinline__ void w3_split(float x, float y, uint32_t &hi, uint32_
   hi = __builtin_bit_cast(uint32_t, h); mid = __builtin_bit_cast(uint32_t, m); lo = __builtin_bit_cast(uint32_t, l);
 }
 
-// swizzled position (in halfs) of channel ch of staged pair p
-__device__ __forceinline__ int w3_pos(int p, int ch) { return p * W3_ROW + ((((ch >> 4) ^ (p >> 3)) & 7) << 4) + (ch & 15); }
-
 template <typename ET, int NA, int NB>
 __global__ void __launch_bounds__(256, W3Mode<ET>::PLANES == 1 ? 3 : 2) wgrad3_kernel(Wgrad3Args w) {
   constexpr int PL = W3Mode<ET>::PLANES;
@@ -509,69 +506,89 @@ __global__ void __launch_bounds__(256, W3Mode<ET>::PLANES == 1 ? 3 : 2) wgrad3_k
 #pragma unroll
     for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
 
-  // staging: each thread moves PIECES 16-byte pieces per operand and batch (fp32: 4 channels, halfs: 8 channels each)
-  constexpr int CPP = F32IN ? 4 : 8;           // channels per piece
-  constexpr int PPR = W3_ROW / CPP;            // pieces per staged row: 32 / 16
-  constexpr int PIECES = W3_PB * PPR / 256;    // per thread: 4 / 2
+  // staging: the image is PAIR-INTERLEAVED -- one 32-bit word holds channel ch of the two pairs (2q, 2q + 1) -- so that a
+  // transposed fragment is FOUR ds_read_b32 (8 pairs of one channel) instead of eight 2-byte reads plus packing. A thread
+  // therefore moves the same 16-byte channel piece of BOTH rows of a pair couple: halfs are zipped with v_perm_b32, fp32
+  // values are converted two at a time (v_cvt_pk_bf16_f32 packs (pair 2q, pair 2q + 1) into exactly that word).
+  constexpr int CPP = F32IN ? 4 : 8;                 // channels per 16-byte piece
+  constexpr int PPR = W3_ROW / CPP;                  // pieces per staged row: 32 / 16
+  constexpr int PIECES = (W3_PB / 2) * PPR / 256;    // (couple, piece) items per thread and operand: 2 / 1
+  uint32_t *ldw = reinterpret_cast<uint32_t *>(lds);
+  constexpr int IMGW = IMG / 2;                      // words per image
+  constexpr int OPW = (W3_PB / 2) * W3_ROW;          // words per (plane, operand): 16 couples x 128 channels
+  // word position of channel ch of couple q: 16-channel chunk c sits at chunk c ^ ((q >> 2) & 3), so the four lane groups
+  // of a fragment read (couples 4 g + j) hit four distinct 16-bank ranges
+  auto wpos = [](int q, int ch) { return q * W3_ROW + ((((ch >> 4) ^ (q >> 2)) & 7) << 4) + (ch & 15); };
   // the dependent chain pair -> row address -> row is cut in two: the pair indices run one batch ahead of the rows
-  int2 prs[PIECES];
-  uint4 ra[PIECES], rb[PIECES];
+  int2 prs[PIECES][2];
+  uint4 ra[PIECES][2], rb[PIECES][2];
   auto fetch_pairs = [&](int p0) {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-      const int p = (tid + 256 * i) / PPR;
-      prs[i] = make_int2(-1, -1);
-      if (p0 + p < end) prs[i] = reinterpret_cast<const int2 *>(w.pairs)[p0 + p];
+      const int q = (tid + 256 * i) / PPR;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        prs[i][h] = make_int2(-1, -1);
+        if (p0 + 2 * q + h < end) prs[i][h] = reinterpret_cast<const int2 *>(w.pairs)[p0 + 2 * q + h];
+      }
     }
   };
   auto fetch_rows = [&]() {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
       const int c = ((tid + 256 * i) % PPR) * CPP;
-      const bool pv = prs[i].x >= 0;
-      const int ia = w.a_col ? prs[i].y : prs[i].x, ib = w.a_col ? prs[i].x : prs[i].y;
-      ra[i] = make_uint4(0u, 0u, 0u, 0u);
-      rb[i] = make_uint4(0u, 0u, 0u, 0u);
-      if (pv && c < a_stage) {
-        if (F32IN) ra[i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(w.fa) + (int64_t)ia * w.ca + a_base + c);
-        else ra[i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(w.fa) + (int64_t)ia * w.ca + a_base + c);
-      }
-      if (pv && c < b_stage) {
-        if (F32IN) rb[i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(w.fb) + (int64_t)ib * w.cb + b_base + c);
-        else rb[i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(w.fb) + (int64_t)ib * w.cb + b_base + c);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool pv = prs[i][h].x >= 0;
+        const int ia = w.a_col ? prs[i][h].y : prs[i][h].x, ib = w.a_col ? prs[i][h].x : prs[i][h].y;
+        ra[i][h] = make_uint4(0u, 0u, 0u, 0u);
+        rb[i][h] = make_uint4(0u, 0u, 0u, 0u);
+        if (pv && c < a_stage) {
+          if (F32IN) ra[i][h] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(w.fa) + (int64_t)ia * w.ca + a_base + c);
+          else ra[i][h] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(w.fa) + (int64_t)ia * w.ca + a_base + c);
+        }
+        if (pv && c < b_stage) {
+          if (F32IN) rb[i][h] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(w.fb) + (int64_t)ib * w.cb + b_base + c);
+          else rb[i][h] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(w.fb) + (int64_t)ib * w.cb + b_base + c);
+        }
       }
     }
   };
   auto stage = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-      const int e = tid + 256 * i, p = e / PPR, c = (e % PPR) * CPP;
-      const int pos = w3_pos(p, c);
+      const int e = tid + 256 * i, q = e / PPR, c = (e % PPR) * CPP;
+      const int pos = wpos(q, c);
 #pragma unroll
       for (int op = 0; op < 2; ++op) {
-        const uint4 v = op ? rb[i] : ra[i];
-        uint16_t *base = lds + buf * IMG + op * (W3_PB * W3_ROW) + pos;
-        if (F32IN) {
-          uint32_t h0, m0, l0, h1, m1, l1;
-          w3_split(__uint_as_float(v.x), __uint_as_float(v.y), h0, m0, l0);
-          w3_split(__uint_as_float(v.z), __uint_as_float(v.w), h1, m1, l1);
-          *reinterpret_cast<uint2 *>(base) = make_uint2(h0, h1);
-          *reinterpret_cast<uint2 *>(base + 2 * W3_PB * W3_ROW) = make_uint2(m0, m1);
-          *reinterpret_cast<uint2 *>(base + 4 * W3_PB * W3_ROW) = make_uint2(l0, l1);
-        } else {
-          *reinterpret_cast<uint4 *>(base) = v;
+        const uint4 v0 = op ? rb[i][0] : ra[i][0], v1 = op ? rb[i][1] : ra[i][1];
+        uint32_t *base = ldw + buf * IMGW + op * OPW + pos;
+        if (F32IN) {  // 4 channels x 2 pairs -> one 16-byte store per plane
+          uint4 hi, mid, lo;
+          w3_split(__uint_as_float(v0.x), __uint_as_float(v1.x), hi.x, mid.x, lo.x);
+          w3_split(__uint_as_float(v0.y), __uint_as_float(v1.y), hi.y, mid.y, lo.y);
+          w3_split(__uint_as_float(v0.z), __uint_as_float(v1.z), hi.z, mid.z, lo.z);
+          w3_split(__uint_as_float(v0.w), __uint_as_float(v1.w), hi.w, mid.w, lo.w);
+          *reinterpret_cast<uint4 *>(base) = hi;
+          *reinterpret_cast<uint4 *>(base + 2 * OPW) = mid;
+          *reinterpret_cast<uint4 *>(base + 4 * OPW) = lo;
+        } else {      // 8 channels x 2 pairs: zip the halfs of the two rows (even pair in the low half of the word)
+          uint4 w0, w1;
+          w0.x = __builtin_amdgcn_perm(v1.x, v0.x, 0x05040100u); w0.y = __builtin_amdgcn_perm(v1.x, v0.x, 0x07060302u);
+          w0.z = __builtin_amdgcn_perm(v1.y, v0.y, 0x05040100u); w0.w = __builtin_amdgcn_perm(v1.y, v0.y, 0x07060302u);
+          w1.x = __builtin_amdgcn_perm(v1.z, v0.z, 0x05040100u); w1.y = __builtin_amdgcn_perm(v1.z, v0.z, 0x07060302u);
+          w1.z = __builtin_amdgcn_perm(v1.w, v0.w, 0x05040100u); w1.w = __builtin_amdgcn_perm(v1.w, v0.w, 0x07060302u);
+          *reinterpret_cast<uint4 *>(base) = w0;
+          *reinterpret_cast<uint4 *>(base + 4) = w1;
         }
       }
     }
   };
-  // transposed fragment: lane (n = l15, g) <- channel ch of the 8 staged pairs 8 g .. 8 g + 7
+  // transposed fragment: lane (n = l15, g) <- channel ch of the staged pairs 8 g .. 8 g + 7 = couples 4 g .. 4 g + 3
   auto frag = [&](int buf, int plane, int op, int ch) {
-    const uint16_t *q = lds + buf * IMG + (plane * 2 + op) * (W3_PB * W3_ROW) + w3_pos(8 * g, ch);
+    const uint32_t *q = ldw + buf * IMGW + (plane * 2 + op) * OPW + wpos(4 * g, ch);
     uint4 f;
-    f.x = (uint32_t)q[0 * W3_ROW] | ((uint32_t)q[1 * W3_ROW] << 16);
-    f.y = (uint32_t)q[2 * W3_ROW] | ((uint32_t)q[3 * W3_ROW] << 16);
-    f.z = (uint32_t)q[4 * W3_ROW] | ((uint32_t)q[5 * W3_ROW] << 16);
-    f.w = (uint32_t)q[6 * W3_ROW] | ((uint32_t)q[7 * W3_ROW] << 16);
+    f.x = q[0 * W3_ROW]; f.y = q[1 * W3_ROW]; f.z = q[2 * W3_ROW]; f.w = q[3 * W3_ROW];
     return f;
   };
   auto compute = [&](int buf) {
