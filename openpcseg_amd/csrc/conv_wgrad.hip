@@ -730,9 +730,11 @@ static int conv_wgrad_any(const void *fa_v, int32_t ca, const void *fb_v, int32_
   const bool vec = (ca % 4 == 0) && (cb % 4 == 0) && (((uintptr_t)fa | (uintptr_t)fb) & 15) == 0;
   if (dtype != 0 && !vec) { set_error("pcs_conv_wgrad_h: half operands need channel counts that are multiples of 4 and 16-byte aligned tensors"); return PCS_EUNSUPPORTED; }
   // 16-bit MFMA path (wgrad3): 16-byte row pieces in both operands. PCS_WGRAD3=0 keeps the fp32-MFMA kernel (A/B, debug).
-  // Policy (tools/wgrad_microbench.py): half operands with >= 4 output blocks (all four waves of a super-block busy)
-  // take wgrad3 -- 1.5-2.5x the fp32-MFMA kernel; fp32 operands (three bf16 planes) stay on wgrad2 unless
-  // PCS_WGRAD3=2 asks for the split path. PCS_WGRAD3=0: wgrad2 always (A/B).
+  // Policy (tools/wgrad_microbench.py, profiles/round2_wgrad3_microbench.md): half operands with >= 4 output blocks
+  // (all four waves of a super-block busy) take wgrad3 -- 2.7-3.4x the fp32-MFMA kernel. fp32 operands keep the exact
+  // fp32-MFMA kernel (wgrad2) by default: the three-plane split is 1.3-1.4x faster on the >= 96-channel layers and
+  // fp32-grade, but the fp32 path of this library stays on fp32 arithmetic unless the caller opts in
+  // (pcs_conv_wgrad_f32_bf16x3, or PCS_WGRAD3=2 for every shape). PCS_WGRAD3=0: wgrad2 always (A/B).
   static const int use3 = getenv("PCS_WGRAD3") ? atoi(getenv("PCS_WGRAD3")) : 1;
   const int cgran = dtype == 0 ? 4 : 8;
   const bool want3 = dtype == 0 ? (use3 == 2 || force_split) : (use3 >= 1 && (use3 == 2 || wg_ngroups(ca) * wg_ngroups(cb) >= 4));
@@ -787,7 +789,8 @@ extern "C" int pcs_conv_wgrad_h(const void *fa, int32_t ca, const void *fb, int3
 
 // fp32 operands on the 16-bit MFMAs: every value split into three bf16 planes, six plane products accumulated in fp32
 // (wgrad3). Same arguments and fp32-grade results as pcs_conv_wgrad_f32 (needs ca % 4 == 0, cb % 4 == 0, 16-byte
-// aligned tensors); kept as its own entry because the fp32-MFMA kernel is the faster one at today's staging cost.
+// aligned tensors); 1.3-1.4x the fp32-MFMA kernel on >= 96-channel layers, slower on thin ones. Its own entry: the
+// default fp32 path does fp32 arithmetic.
 extern "C" int pcs_conv_wgrad_f32_bf16x3(const float *fa, int32_t ca, const float *fb, int32_t cb,
                                          const int32_t *pairs, int32_t a_col, const int32_t *koff_dev,
                                          const int32_t *koff_host, int32_t K, float *gW, void *ws,

@@ -91,6 +91,7 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const void *__restrict_
         // forward: workgroup 0 leaves the pivot row, widened to fp32, in partial row gridDim.x for the reduce kernel
         if (!BWD && blockIdx.x == 0 && ty == 0) partial[(int64_t)gridDim.x * 2 * c + j * V + q] = mean[q];
       }
+#pragma unroll 4  // four rows' loads in flight per thread: one 8/16-byte load per array and iteration left the pass latency-bound
       for (int64_t i = (int64_t)blockIdx.x * TY + ty; i < n; i += (int64_t)gridDim.x * TY) {
         const VT xv = ldv<V>(ET{}, x, i * c + (int64_t)j * V);
         if (BWD) {
@@ -213,6 +214,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const void *__restrict__ 
       sc[q] = invstd * (w ? w[ch] : 1.f);
       sh[q] = (b ? b[ch] : 0.f) - mean * sc[q];
     }
+#pragma unroll 4
     for (int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; i < n; i += (int64_t)gridDim.x * blockDim.y) {
       const VT xv = ldv<V>(ET{}, x, i * c + (int64_t)j * V);
       VT rv; if (res) rv = ldv<V>(ET{}, res, i * c + (int64_t)j * V);
@@ -258,6 +260,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const void *__restric
       k2[q] = (float)(sums2[c + ch] / count);
       ws[q] = invstd[q] * (w ? w[ch] : 1.f);
     }
+#pragma unroll 4
     for (int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; i < n; i += (int64_t)gridDim.x * blockDim.y) {
       const VT gv = ldv<V>(ET{}, dy, i * c + (int64_t)j * V);
       const VT xv = ldv<V>(ET{}, x, i * c + (int64_t)j * V);
