@@ -296,24 +296,33 @@ int pcs_bn_stats_f32(const float *x, int64_t n, int32_t c, float *partial_ws, do
 int pcs_bn_reduce_partials(const double *partial, int64_t nrows, int32_t c, int64_t n, double *sums, void *stream);
 int pcs_bn_finalize_f32(const double *sums, double count, const double *count_dev, int32_t c, double eps,
                         double momentum, float *running_mean, float *running_var, double *stat, void *stream);
+/* concat fusion (torchsparse.cat([bn_relu(up_conv(x)), skip]), TS:torchsparse/operators.py:10-17 as used by
+ * R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:404-416): apply may write y as the left c columns of an (n, ldy)
+ * buffer (ldy = row stride in elements, 0 = c) and copy the skip tensor `tail` (n, ctail; may be NULL / 0) into the
+ * columns right of it in the same launch; the backward passes then read dy with the row stride lddy (0 = c) straight
+ * out of the gradient of that buffer. */
 int pcs_bn_apply_f32(const float *x, const float *res, const double *stat, const float *w, const float *b,
-                     int64_t n, int32_t c, int32_t relu, float *y, uint32_t *mask, void *stream);
+                     int64_t n, int32_t c, int32_t relu, float *y, uint32_t *mask, int64_t ldy, const float *tail,
+                     int32_t ctail, void *stream);
 int pcs_bn_bwd_stats_f32(const float *dy, const float *x, const float *y, const uint32_t *mask, const double *stat,
-                         int64_t n, int32_t c, int32_t relu, float *partial_ws, double *sums2, void *stream);
+                         int64_t n, int32_t c, int32_t relu, float *partial_ws, double *sums2, int64_t lddy,
+                         void *stream);
 int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const uint32_t *mask, const double *stat,
                          const double *sums2, double count, const double *count_dev, const float *w, int64_t n,
-                         int32_t c, int32_t relu, float *dx, float *dres, void *stream);
+                         int32_t c, int32_t relu, float *dx, float *dres, int64_t lddy, void *stream);
 /* the same four passes over bf16 (dtype 1) / fp16 (dtype 2) feature tensors (x, res, y, dy, dx, dres all in `dtype`):
  * the mixed-precision pipeline of the reference (`--amp`), where the convolutions hand on halfs. Statistics,
  * scale / shift and the arithmetic stay fp32 / double; rows need 8-byte alignment for the vector path. */
 int pcs_bn_stats_h(const void *x, int64_t n, int32_t c, int32_t dtype, float *partial_ws, double *sums, void *stream);
 int pcs_bn_apply_h(const void *x, const void *res, const double *stat, const float *w, const float *b, int64_t n,
-                   int32_t c, int32_t relu, int32_t dtype, void *y, uint32_t *mask, void *stream);
+                   int32_t c, int32_t relu, int32_t dtype, void *y, uint32_t *mask, int64_t ldy, const void *tail,
+                   int32_t ctail, void *stream);
 int pcs_bn_bwd_stats_h(const void *dy, const void *x, const void *y, const uint32_t *mask, const double *stat, int64_t n,
-                       int32_t c, int32_t relu, int32_t dtype, float *partial_ws, double *sums2, void *stream);
+                       int32_t c, int32_t relu, int32_t dtype, float *partial_ws, double *sums2, int64_t lddy,
+                       void *stream);
 int pcs_bn_bwd_apply_h(const void *dy, const void *x, const void *y, const uint32_t *mask, const double *stat,
                        const double *sums2, double count, const double *count_dev, const float *w, int64_t n,
-                       int32_t c, int32_t relu, int32_t dtype, void *dx, void *dres, void *stream);
+                       int32_t c, int32_t relu, int32_t dtype, void *dx, void *dres, int64_t lddy, void *stream);
 
 /* ---- device-side sparse_quantize ---------------------------------------------------------------
  * Replaces the dataloader-side NumPy voxel dedup TS:torchsparse/utils/quantize.py:9-46

@@ -70,7 +70,8 @@ template <bool BWD, int V, typename ET>
 __global__ void __launch_bounds__(256) bn_partial_kernel(const void *__restrict__ x, const void *__restrict__ dy,
                                                          const void *__restrict__ y, const uint32_t *__restrict__ mask,
                                                          const double *__restrict__ stat,
-                                                         int64_t n, int c, int cv, int relu, float *__restrict__ partial) {
+                                                         int64_t n, int c, int cv, int relu, float *__restrict__ partial,
+                                                         int64_t lddy) {
   using VT = typename NV<V>::T;
   extern __shared__ float red[];  // [TY][2][TX*V]
   const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const void *__restrict_
       for (int64_t i = (int64_t)blockIdx.x * TY + ty; i < n; i += (int64_t)gridDim.x * TY) {
         const VT xv = ldv<V>(ET{}, x, i * c + (int64_t)j * V);
         if (BWD) {
-          const VT gv = ldv<V>(ET{}, dy, i * c + (int64_t)j * V);
+          const VT gv = ldv<V>(ET{}, dy, i * lddy + (int64_t)j * V);
           VT yv; unsigned bits = 0xFu;
           if (relu) {
             if (V == 4 && mask) bits = (mask[i * (c >> 5) + (j >> 3)] >> (4 * (j & 7))) & 0xFu;
@@ -203,8 +204,16 @@ template <int V, typename ET>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const void *__restrict__ x, const void *__restrict__ res,
                                                        const double *__restrict__ stat, const float *__restrict__ w,
                                                        const float *__restrict__ b, int64_t n, int c, int cv, int relu,
-                                                       void *__restrict__ y, uint32_t *__restrict__ mask) {
+                                                       void *__restrict__ y, uint32_t *__restrict__ mask, int64_t ldy,
+                                                       const void *__restrict__ tail, int ctail) {
   using VT = typename NV<V>::T;
+  // concat fusion (torchsparse.cat([bn_relu(conv(x)), skip])): y is the left c columns of a (n, ldy) buffer and the
+  // skip tensor `tail` (n, ctail) is copied into the columns right of it by the same launch
+  for (int j = threadIdx.x; j < ctail / V; j += blockDim.x) {
+#pragma unroll 4
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; i < n; i += (int64_t)gridDim.x * blockDim.y)
+      stv(ET{}, y, i * ldy + c + (int64_t)j * V, ldv<V>(ET{}, tail, i * ctail + (int64_t)j * V));
+  }
   for (int j = threadIdx.x; j < cv; j += blockDim.x) {
     float sc[V], sh[V];
 #pragma unroll
@@ -228,7 +237,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const void *__restrict__ 
         bits |= (t > 0.f ? 1u : 0u) << q;
         setc(o, q, t);
       }
-      stv(ET{}, y, i * c + (int64_t)j * V, o);
+      stv(ET{}, y, i * ldy + (int64_t)j * V, o);
       if (V == 4 && mask) {  // c % 32 == 0: 8 consecutive lanes (4 channels each) of one row make one word
         unsigned m = bits << (4 * (j & 7));
         m |= __shfl_xor(m, 1, 64); m |= __shfl_xor(m, 2, 64); m |= __shfl_xor(m, 4, 64);
@@ -246,7 +255,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const void *__restric
                                                            const double *__restrict__ sums2, double count,
                                                            const double *__restrict__ count_dev,
                                                            const float *__restrict__ w, int64_t n, int c, int cv,
-                                                           int relu, void *__restrict__ dx, void *__restrict__ dres) {
+                                                           int relu, void *__restrict__ dx, void *__restrict__ dres,
+                                                           int64_t lddy) {
   using VT = typename NV<V>::T;
   if (count_dev) count = *count_dev;
   if (!(count > 0.0)) count = 1.0;
@@ -262,7 +272,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const void *__restric
     }
 #pragma unroll 4
     for (int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; i < n; i += (int64_t)gridDim.x * blockDim.y) {
-      const VT gv = ldv<V>(ET{}, dy, i * c + (int64_t)j * V);
+      const VT gv = ldv<V>(ET{}, dy, i * lddy + (int64_t)j * V);
       const VT xv = ldv<V>(ET{}, x, i * c + (int64_t)j * V);
       VT yv; unsigned bits = 0xFu;
       if (relu) {
@@ -310,19 +320,21 @@ extern "C" int32_t pcs_bn_num_partials(void) { return kStatBlocks + 1; }  // + t
 static bool al_v4(int dtype, const void *p) { return ((uintptr_t)p & (dtype == 0 ? 15 : 7)) == 0; }
 
 static int bn_partial(bool bwd, int dtype, const void *x, const void *dy, const void *y, const uint32_t *mask, const double *stat,
-                      int64_t n, int c, int relu, float *partial, double *sums, hipStream_t st) {
-  const bool vec = (c & 3) == 0 && al_v4(dtype, x) && al_v4(dtype, dy) && al_v4(dtype, y);
+                      int64_t n, int c, int relu, float *partial, double *sums, hipStream_t st, int64_t lddy = 0) {
+  if (lddy == 0) lddy = c;
+  if (lddy < c) { set_error("pcs_bn: row stride of dy smaller than c"); return PCS_EINVAL; }
+  const bool vec = (c & 3) == 0 && (lddy & 3) == 0 && al_v4(dtype, x) && al_v4(dtype, dy) && al_v4(dtype, y);
   if (mask && (!vec || (c & 31))) { set_error("pcs_bn: the ReLU bit mask needs c % 32 == 0 and aligned rows"); return PCS_EUNSUPPORTED; }
   const int V = vec ? 4 : 1, cv = c / V;
   int tx = 1; while (tx < cv && tx < 64) tx <<= 1;
   dim3 block(tx, 256 / tx);
   const size_t lds = (size_t)(256 / tx) * 2 * tx * V * sizeof(float);
   if (vec) {
-    if (bwd) PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_partial_kernel<true, 4, ET>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial));
-    else PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_partial_kernel<false, 4, ET>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial));
+    if (bwd) PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_partial_kernel<true, 4, ET>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial, lddy));
+    else PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_partial_kernel<false, 4, ET>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial, lddy));
   } else {
-    if (bwd) PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_partial_kernel<true, 1, ET>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial));
-    else PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_partial_kernel<false, 1, ET>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial));
+    if (bwd) PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_partial_kernel<true, 1, ET>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial, lddy));
+    else PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_partial_kernel<false, 1, ET>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial, lddy));
   }
     const float *pivot = bwd ? nullptr : partial + (size_t)kStatBlocks * 2 * c;  // written by workgroup 0 above
   hipLaunchKernelGGL(bn_reduce_kernel<float>, dim3((unsigned)ceil_div(c, 16)), dim3(16, 64), 0, st, partial, kStatBlocks, c,
@@ -331,38 +343,45 @@ static int bn_partial(bool bwd, int dtype, const void *x, const void *dy, const 
 }
 
 static int bn_apply_any(int dtype, const void *x, const void *res, const double *stat, const float *w, const float *b,
-                        int64_t n, int32_t c, int32_t relu, void *y, uint32_t *mask, void *stream) {
-  if (n < 0 || c <= 0) { set_error("pcs_bn_apply: bad sizes"); return PCS_EINVAL; }
+                        int64_t n, int32_t c, int32_t relu, void *y, uint32_t *mask, int64_t ldy, const void *tail,
+                        int32_t ctail, void *stream) {
+  if (n < 0 || c <= 0 || ctail < 0) { set_error("pcs_bn_apply: bad sizes"); return PCS_EINVAL; }
   if (n == 0) return PCS_OK;
-  if (!x || !stat || !y) { set_error("pcs_bn_apply: null pointer"); return PCS_EINVAL; }
+  if (!x || !stat || !y || (ctail > 0 && !tail)) { set_error("pcs_bn_apply: null pointer"); return PCS_EINVAL; }
+  if (ldy == 0) ldy = c;
+  if (ldy < (int64_t)c + ctail) { set_error("pcs_bn_apply: row stride of y smaller than c + ctail"); return PCS_EINVAL; }
   hipStream_t st = as_stream(stream);
-  const bool vec = (c & 3) == 0 && al_v4(dtype, x) && al_v4(dtype, y) && al_v4(dtype, res);
+  const bool vec = (c & 3) == 0 && (ldy & 3) == 0 && (ctail & 3) == 0 && al_v4(dtype, x) && al_v4(dtype, y) && al_v4(dtype, res) &&
+                   al_v4(dtype, tail);
   if (mask && (!vec || (c & 31))) { set_error("pcs_bn_apply: the ReLU bit mask needs c % 32 == 0 and aligned rows"); return PCS_EUNSUPPORTED; }
   if (vec) {
     Geo g = geo<4>(n, c);
-    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_apply_kernel<4, ET>), g.grid, g.block, 0, st, x, res, stat, w, b, n, c, g.cv, relu, y, mask));
+    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_apply_kernel<4, ET>), g.grid, g.block, 0, st, x, res, stat, w, b, n, c, g.cv, relu, y, mask, ldy, tail, ctail));
   } else {
     Geo g = geo<1>(n, c);
-    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_apply_kernel<1, ET>), g.grid, g.block, 0, st, x, res, stat, w, b, n, c, g.cv, relu, y, mask));
+    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_apply_kernel<1, ET>), g.grid, g.block, 0, st, x, res, stat, w, b, n, c, g.cv, relu, y, mask, ldy, tail, ctail));
   }
   return check_launch("pcs_bn_apply");
 }
 
 static int bn_bwd_apply_any(int dtype, const void *dy, const void *x, const void *y, const uint32_t *mask,
                             const double *stat, const double *sums2, double count, const double *count_dev,
-                            const float *w, int64_t n, int32_t c, int32_t relu, void *dx, void *dres, void *stream) {
+                            const float *w, int64_t n, int32_t c, int32_t relu, void *dx, void *dres, int64_t lddy,
+                            void *stream) {
   if (n < 0 || c <= 0 || (!count_dev && !(count > 0))) { set_error("pcs_bn_bwd_apply: bad sizes"); return PCS_EINVAL; }
+  if (lddy == 0) lddy = c;
+  if (lddy < c) { set_error("pcs_bn_bwd_apply: row stride of dy smaller than c"); return PCS_EINVAL; }
   if (n == 0) return PCS_OK;
   if (!dy || !x || !stat || !sums2 || !dx || (relu && !y && !mask)) { set_error("pcs_bn_bwd_apply: null pointer"); return PCS_EINVAL; }
   hipStream_t st = as_stream(stream);
-  const bool vec = (c & 3) == 0 && al_v4(dtype, dy) && al_v4(dtype, x) && al_v4(dtype, y) && al_v4(dtype, dx) && al_v4(dtype, dres);
+  const bool vec = (c & 3) == 0 && (lddy & 3) == 0 && al_v4(dtype, dy) && al_v4(dtype, x) && al_v4(dtype, y) && al_v4(dtype, dx) && al_v4(dtype, dres);
   if (mask && (!vec || (c & 31))) { set_error("pcs_bn_bwd_apply: the ReLU bit mask needs c % 32 == 0 and aligned rows"); return PCS_EUNSUPPORTED; }
   if (vec) {
     Geo g = geo<4>(n, c);
-    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<4, ET>), g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, g.cv, relu, dx, dres));
+    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<4, ET>), g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, g.cv, relu, dx, dres, lddy));
   } else {
     Geo g = geo<1>(n, c);
-    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<1, ET>), g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, g.cv, relu, dx, dres));
+    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<1, ET>), g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, g.cv, relu, dx, dres, lddy));
   }
   return check_launch("pcs_bn_bwd_apply");
 }
@@ -396,38 +415,40 @@ extern "C" int pcs_bn_finalize_f32(const double *sums, double count, const doubl
 }
 
 extern "C" int pcs_bn_apply_f32(const float *x, const float *res, const double *stat, const float *w, const float *b,
-                                int64_t n, int32_t c, int32_t relu, float *y, uint32_t *mask, void *stream) {
-  return bn_apply_any(0, x, res, stat, w, b, n, c, relu, y, mask, stream);
+                                int64_t n, int32_t c, int32_t relu, float *y, uint32_t *mask, int64_t ldy, const float *tail,
+                                int32_t ctail, void *stream) {
+  return bn_apply_any(0, x, res, stat, w, b, n, c, relu, y, mask, ldy, tail, ctail, stream);
 }
 extern "C" int pcs_bn_apply_h(const void *x, const void *res, const double *stat, const float *w, const float *b,
-                              int64_t n, int32_t c, int32_t relu, int32_t dtype, void *y, uint32_t *mask, void *stream) {
+                              int64_t n, int32_t c, int32_t relu, int32_t dtype, void *y, uint32_t *mask, int64_t ldy,
+                              const void *tail, int32_t ctail, void *stream) {
   if (bad_half(dtype)) { set_error("pcs_bn_apply_h: dtype must be 1 (bf16) or 2 (fp16)"); return PCS_EINVAL; }
-  return bn_apply_any(dtype, x, res, stat, w, b, n, c, relu, y, mask, stream);
+  return bn_apply_any(dtype, x, res, stat, w, b, n, c, relu, y, mask, ldy, tail, ctail, stream);
 }
 
 extern "C" int pcs_bn_bwd_stats_f32(const float *dy, const float *x, const float *y, const uint32_t *mask,
                                     const double *stat, int64_t n, int32_t c, int32_t relu, float *partial_ws,
-                                    double *sums2, void *stream) {
+                                    double *sums2, int64_t lddy, void *stream) {
   if (n < 0 || c <= 0 || !dy || !x || !stat || !partial_ws || !sums2 || (relu && !y && !mask)) { set_error("pcs_bn_bwd_stats: bad args"); return PCS_EINVAL; }
-  return bn_partial(true, 0, x, dy, y, mask, stat, n, c, relu, partial_ws, sums2, as_stream(stream));
+  return bn_partial(true, 0, x, dy, y, mask, stat, n, c, relu, partial_ws, sums2, as_stream(stream), lddy);
 }
 extern "C" int pcs_bn_bwd_stats_h(const void *dy, const void *x, const void *y, const uint32_t *mask,
                                   const double *stat, int64_t n, int32_t c, int32_t relu, int32_t dtype, float *partial_ws,
-                                  double *sums2, void *stream) {
+                                  double *sums2, int64_t lddy, void *stream) {
   if (n < 0 || c <= 0 || !dy || !x || !stat || !partial_ws || !sums2 || (relu && !y && !mask) || bad_half(dtype)) { set_error("pcs_bn_bwd_stats_h: bad args"); return PCS_EINVAL; }
-  return bn_partial(true, dtype, x, dy, y, mask, stat, n, c, relu, partial_ws, sums2, as_stream(stream));
+  return bn_partial(true, dtype, x, dy, y, mask, stat, n, c, relu, partial_ws, sums2, as_stream(stream), lddy);
 }
 
 extern "C" int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const uint32_t *mask,
                                     const double *stat, const double *sums2, double count, const double *count_dev,
                                     const float *w, int64_t n, int32_t c, int32_t relu, float *dx, float *dres,
-                                    void *stream) {
-  return bn_bwd_apply_any(0, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, relu, dx, dres, stream);
+                                    int64_t lddy, void *stream) {
+  return bn_bwd_apply_any(0, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, relu, dx, dres, lddy, stream);
 }
 extern "C" int pcs_bn_bwd_apply_h(const void *dy, const void *x, const void *y, const uint32_t *mask,
                                   const double *stat, const double *sums2, double count, const double *count_dev,
                                   const float *w, int64_t n, int32_t c, int32_t relu, int32_t dtype, void *dx, void *dres,
-                                  void *stream) {
+                                  int64_t lddy, void *stream) {
   if (bad_half(dtype)) { set_error("pcs_bn_bwd_apply_h: dtype must be 1 (bf16) or 2 (fp16)"); return PCS_EINVAL; }
-  return bn_bwd_apply_any(dtype, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, relu, dx, dres, stream);
+  return bn_bwd_apply_any(dtype, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, relu, dx, dres, lddy, stream);
 }

@@ -48,7 +48,11 @@ class _FusedBN(Function):
     scale / shift and running stats are fp32 / double whatever the storage format."""
 
     @staticmethod
-    def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, sync, cache, level, pre=None):
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, sync, cache, level, pre=None,
+                tail=None):
+        """tail (n, ct): concat fusion -- the output is cat([bn(x), tail], 1), the BN result written straight into the left
+        columns and `tail` copied to the right ones by the apply launch (no torch.cat pass); backward reads its dy out of
+        the gradient of that buffer through a row stride and hands the right columns on as tail's gradient."""
         be = native.backend()
         x = x.contiguous()
         res = res.contiguous() if res is not None else None
@@ -64,21 +68,26 @@ class _FusedBN(Function):
         stat = be.bn_finalize(sums, count, eps, momentum, running_mean, running_var, count_dev=count_dev)
         # c % 32 == 0: the backward passes read the ReLU gate as a bit mask (1/32 of a tensor) instead of y
         if relu and c % 32 == 0 and c % 4 == 0:
-            y, gate = be.bn_apply(x, res, stat, weight, bias, relu, want_mask=True)
+            y, gate = be.bn_apply(x, res, stat, weight, bias, relu, want_mask=True, tail=tail)
         else:
-            y = be.bn_apply(x, res, stat, weight, bias, relu)
-            gate = y if relu else None
+            y = be.bn_apply(x, res, stat, weight, bias, relu, tail=tail)
+            gate = (y if tail is None else y[:, :c].contiguous()) if relu else None
         ctx.save_for_backward(x, gate, stat, weight, count_dev)
-        ctx.cfg = (count, relu, sync, res is not None)
+        ctx.cfg = (count, relu, sync, res is not None, tail is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         be = native.backend()
         x, gate, stat, weight, count_dev = ctx.saved_tensors
-        count, relu, sync, has_res = ctx.cfg
-        dy = dy.contiguous()
+        count, relu, sync, has_res, has_tail = ctx.cfg
         c = x.shape[1]
+        dtail = None
+        if has_tail:
+            dtail = dy[:, c:]   # the skip tensor's gradient: a view, summed into its other gradients by autograd
+            dy = dy[:, :c]      # read in place through the row stride
+        else:
+            dy = dy.contiguous()
         local = be.bn_bwd_stats(dy, x, gate, stat, relu)
         sums2 = local
         if sync and _world() > 1:
@@ -87,7 +96,7 @@ class _FusedBN(Function):
         dx, dres = be.bn_bwd_apply(dy, x, gate, stat, sums2, count, weight, relu, has_res, count_dev=count_dev)
         dw = local[c:].to(weight.dtype) if weight is not None else None   # local sums: DDP averages parameter grads
         db = local[:c].to(weight.dtype) if weight is not None else None
-        return dx, dres, dw, db, None, None, None, None, None, None, None, None, None
+        return dx, dres, dw, db, None, None, None, None, None, None, None, None, None, dtail
 
 
 class FusedBatchNorm(nn.Module):
@@ -106,18 +115,22 @@ class FusedBatchNorm(nn.Module):
     def extra_repr(self):
         return "%d, eps=%g, momentum=%g, sync=%s" % (self.num_features, self.eps, self.momentum, self.sync)
 
-    def forward(self, input, residual=None, relu=False):
+    def forward(self, input, residual=None, relu=False, cat_with=None):
+        """cat_with: a SparseTensor / tensor on the same coordinates; the result then carries cat([bn(x), cat_with], 1)
+        (torchsparse.cat of the reference's decoder, fused into the apply pass)."""
         x = input.feats
         r = residual.feats if isinstance(residual, SparseTensor) else residual
+        tail = cat_with.feats if isinstance(cat_with, SparseTensor) else cat_with
         if self.training:
             self.num_batches_tracked += 1
             y = _FusedBN.apply(x, r, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                               self.momentum, relu, self.sync, input.cmaps, input.stride, getattr(input, "bn_sums", None))
+                               self.momentum, relu, self.sync, input.cmaps, input.stride, getattr(input, "bn_sums", None),
+                               tail)
         else:
             inv = torch.rsqrt(self.running_var.double() + self.eps)
             stat = torch.cat([self.running_mean.double(), inv]).contiguous()
             y = native.backend().bn_apply(x.contiguous(), r.contiguous() if r is not None else None, stat,
-                                          self.weight, self.bias, relu)
+                                          self.weight, self.bias, relu, tail=tail.contiguous() if tail is not None else None)
         return input._like(y)
 
 

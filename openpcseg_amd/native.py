@@ -61,14 +61,15 @@ SIGNATURES = {
     "pcs_bn_num_partials": (c_int32, []),
     "pcs_bn_stats_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P]),
     "pcs_bn_finalize_f32": (c_int32, [_P, c_double, _P, c_int32, c_double, c_double, _P, _P, _P, _P]),
-    "pcs_bn_apply_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
-    "pcs_bn_bwd_stats_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
-    "pcs_bn_bwd_apply_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_double, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
+    "pcs_bn_apply_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, c_int32, _P]),
+    "pcs_bn_bwd_stats_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P]),
+    "pcs_bn_bwd_apply_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_double, _P, _P, c_int64, c_int32, c_int32, _P, _P,
+                                       c_int64, _P]),
     "pcs_bn_stats_h": (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
-    "pcs_bn_apply_h": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P]),
-    "pcs_bn_bwd_stats_h": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "pcs_bn_apply_h": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, c_int64, _P, c_int32, _P]),
+    "pcs_bn_bwd_stats_h": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, c_int64, _P]),
     "pcs_bn_bwd_apply_h": (c_int32, [_P, _P, _P, _P, _P, _P, c_double, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P,
-                                     _P]),
+                                     c_int64, _P]),
     "pcs_quantize_floor": (c_int32, [_P, c_int32, c_int64, c_int32, _P, _P, _P, _P]),
     "pcs_quantize_keys": (c_int32, [_P, c_int64, _P, _P, _P]),
     "pcs_quantize_flags": (c_int32, [_P, c_int64, _P, _P]),
@@ -742,24 +743,30 @@ class HipBackend:
                                             _stream()), "pcs_bn_finalize_f32")
         return stat
 
-    def bn_apply(self, x, res, stat, w, b, relu, want_mask=False):
+    def bn_apply(self, x, res, stat, w, b, relu, want_mask=False, tail=None):
         """y = act((x - mean) * invstd * w + b [+ res]) in x's dtype (fp32 / bf16 / fp16). want_mask (c % 32 == 0): also
         the ReLU gate as n x c/32 int32 words (bit ch % 32 of word ch / 32 = [y > 0]) -- what the backward passes read
-        instead of y."""
+        instead of y. tail (n, ct): concat fusion -- the result is the (n, c + ct) tensor cat([y, tail], 1), y written
+        straight into its left columns and `tail` copied to the right ones by the same launch."""
         x = self._feat(x, "input")
         res = self._feat(res, "residual", x) if res is not None else None
+        tail = self._feat(tail, "tail", x) if tail is not None else None
         n, c = x.shape
+        ct = tail.shape[1] if tail is not None else 0
         if want_mask and c % 32:
             raise RuntimeError("openpcseg_amd: the ReLU bit mask needs a channel count that is a multiple of 32")
-        y = torch.empty_like(x)
+        if tail is not None and (tail.shape[0] != n or c % 4 or ct % 4):
+            raise RuntimeError("openpcseg_amd: concat fusion needs equal row counts and channel counts that are multiples of 4")
+        y = torch.empty((n, c + ct), dtype=x.dtype, device=x.device)
         mask = torch.empty((n, c // 32), dtype=torch.int32, device=x.device) if want_mask else None
         args = [_ptr(x), _ptr(res) if res is not None else None, _ptr(stat), _ptr(w) if w is not None else None,
                 _ptr(b) if b is not None else None, n, c, int(relu)]
+        cat = [c + ct, _ptr(tail) if tail is not None else None, ct]
         if x.dtype == torch.float32:
-            _check(self.lib.pcs_bn_apply_f32(*args, _ptr(y), _ptr(mask) if want_mask else None, _stream()),
+            _check(self.lib.pcs_bn_apply_f32(*args, _ptr(y), _ptr(mask) if want_mask else None, *cat, _stream()),
                    "pcs_bn_apply_f32")
         else:
-            _check(self.lib.pcs_bn_apply_h(*args, self._HALF[x.dtype], _ptr(y), _ptr(mask) if want_mask else None,
+            _check(self.lib.pcs_bn_apply_h(*args, self._HALF[x.dtype], _ptr(y), _ptr(mask) if want_mask else None, *cat,
                                            _stream()), "pcs_bn_apply_h")
         return (y, mask) if want_mask else y
 
@@ -770,31 +777,46 @@ class HipBackend:
             return None, None
         return (None, _ptr(gate)) if gate.dtype == torch.int32 else (_ptr(gate), None)
 
+    @staticmethod
+    def _rows(t, name, like, c):
+        """dy of the BN backward passes: (n, c) in like's dtype, unit column stride, any row stride that keeps the rows
+        vector-aligned (a column slice of the gradient of a concat buffer); anything else is made contiguous."""
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise RuntimeError("openpcseg_amd: `%s` must be a HIP device tensor" % name)
+        if t.dtype != like.dtype:
+            t = t.to(like.dtype)
+        unit = 16 // t.element_size() if t.dtype == torch.float32 else 4
+        ok = t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= c and t.stride(0) % 4 == 0 and \
+            t.data_ptr() % (unit * t.element_size()) == 0
+        if not ok:
+            t = t.contiguous()
+        return t, t.stride(0)
+
     def bn_bwd_stats(self, dy, x, gate, stat, relu):
         x = self._feat(x, "input")
-        dy = self._feat(dy, "grad_output", x)
         n, c = x.shape
+        dy, lddy = self._rows(dy, "grad_output", x, c)
         ws = torch.empty(self.lib.pcs_bn_num_partials() * 2 * c, dtype=torch.float32, device=x.device)
         sums2 = torch.empty(2 * c, dtype=torch.float64, device=x.device)
         yp, mp = self._gate(gate, relu)
         if x.dtype == torch.float32:
             _check(self.lib.pcs_bn_bwd_stats_f32(_ptr(dy), _ptr(x), yp, mp, _ptr(stat), n, c, int(relu),
-                                                 _ptr(ws), _ptr(sums2), _stream()), "pcs_bn_bwd_stats_f32")
+                                                 _ptr(ws), _ptr(sums2), lddy, _stream()), "pcs_bn_bwd_stats_f32")
         else:
             _check(self.lib.pcs_bn_bwd_stats_h(_ptr(dy), _ptr(x), yp, mp, _ptr(stat), n, c, int(relu), self._HALF[x.dtype],
-                                               _ptr(ws), _ptr(sums2), _stream()), "pcs_bn_bwd_stats_h")
+                                               _ptr(ws), _ptr(sums2), lddy, _stream()), "pcs_bn_bwd_stats_h")
         return sums2
 
     def bn_bwd_apply(self, dy, x, gate, stat, sums2, count, w, relu, want_res, count_dev=None):
         x = self._feat(x, "input")
-        dy = self._feat(dy, "grad_output", x)
         n, c = x.shape
+        dy, lddy = self._rows(dy, "grad_output", x, c)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if want_res else None
         yp, mp = self._gate(gate, relu)
         head = [_ptr(dy), _ptr(x), yp, mp, _ptr(stat), _ptr(sums2), float(count),
                 _ptr(count_dev) if count_dev is not None else None, _ptr(w) if w is not None else None, n, c, int(relu)]
-        tail = [_ptr(dx), _ptr(dres) if want_res else None, _stream()]
+        tail = [_ptr(dx), _ptr(dres) if want_res else None, lddy, _stream()]
         if x.dtype == torch.float32:
             _check(self.lib.pcs_bn_bwd_apply_f32(*head, *tail), "pcs_bn_bwd_apply_f32")
         else:

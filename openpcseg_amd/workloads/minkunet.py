@@ -48,14 +48,20 @@ def _link(conv, bn):
         conv.emit_bn_stats = os.environ.get("PCS_CONV_BN_STATS", "1") != "0"
 
 
-def _bn_act(bn, x, residual=None, relu=True, act=None):
-    """BN (+residual) (+ReLU): one fused pass, or the reference's separate torch modules."""
+CAT_FUSED = os.environ.get("PCS_CAT_FUSED", "1") != "0"  # decoder concat written by the BN apply pass
+
+
+def _bn_act(bn, x, residual=None, relu=True, act=None, cat_with=None):
+    """BN (+residual) (+ReLU) (+concat with the skip tensor): one fused pass, or the reference's separate torch modules."""
     if isinstance(bn, FusedBatchNorm):
-        return bn(x, residual=residual, relu=relu)
+        if cat_with is not None and not CAT_FUSED:
+            return cat([bn(x, residual=residual, relu=relu), cat_with])
+        return bn(x, residual=residual, relu=relu, cat_with=cat_with)
     y = bn(x)
     if residual is not None:
         y = y + residual
-    return act(y) if relu else y
+    y = act(y) if relu else y
+    return y if cat_with is None else cat([y, cat_with])
 
 
 class ConvBlock(nn.Module):
@@ -67,8 +73,8 @@ class ConvBlock(nn.Module):
                                  _norm(cout, dist), spnn.ReLU(True))
         _link(self.net[0], self.net[1])
 
-    def forward(self, x):
-        return _bn_act(self.net[1], self.net[0](x), act=self.net[2])
+    def forward(self, x, cat_with=None):
+        return _bn_act(self.net[1], self.net[0](x), act=self.net[2], cat_with=cat_with)
 
 
 class ResBlock(nn.Module):
@@ -139,12 +145,12 @@ class MinkUNet(nn.Module):
         x4 = self.stage4(x3)
         z1 = voxel_to_point(x4, z0)
         x4.F = self.dropout(x4.F)
-        y1 = self.up1[1](cat([self.up1[0](x4), x3]))
-        y2 = self.up2[1](cat([self.up2[0](y1), x2]))
+        y1 = self.up1[1](self.up1[0](x4, cat_with=x3))  # torchsparse.cat([up(x4), x3]) fused into the BN apply pass
+        y2 = self.up2[1](self.up2[0](y1, cat_with=x2))
         z2 = voxel_to_point(y2, z1)
         y2.F = self.dropout(y2.F)
-        y3 = self.up3[1](cat([self.up3[0](y2), x1]))
-        y4 = self.up4[1](cat([self.up4[0](y3), x0]))
+        y3 = self.up3[1](self.up3[0](y2, cat_with=x1))
+        y4 = self.up4[1](self.up4[0](y3, cat_with=x0))
         z3 = voxel_to_point(y4, z2)
         return self.classifier(torch.cat([z1.F, z2.F, z3.F], dim=1))
 

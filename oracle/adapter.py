@@ -154,7 +154,12 @@ class OracleBackend:
             running_var.mul_(1 - momentum).add_((momentum * unb).float())
         return torch.cat([mean, 1.0 / torch.sqrt(var + eps)])
 
-    def bn_apply(self, x, res, stat, w, b, relu, want_mask=False):
+    def bn_apply(self, x, res, stat, w, b, relu, want_mask=False, tail=None):
+        if tail is not None:
+            got = self.bn_apply(x, res, stat, w, b, relu, want_mask)
+            y = got[0] if want_mask else got
+            y = torch.cat([y, tail], dim=1)
+            return (y, got[1]) if want_mask else y
         c = x.shape[1]
         y = (x - stat[:c].float()) * stat[c:].float()
         if w is not None:

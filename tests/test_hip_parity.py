@@ -709,3 +709,34 @@ def test_unique_inverse_csr(hip):
     close(out, orc.voxelize_fwd(feats.cpu().numpy(), inv.cpu().numpy().astype(np.int32), counts.cpu().numpy()), 1e-5)
     e = hip.unique_inverse_csr(torch.zeros(0, dtype=torch.int64, device=DEV))
     assert e[0].numel() == 0 and e[1].numel() == 0 and e[2].numel() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c,ct", [(96, 32), (128, 64), (256, 128), (20, 12)])
+def test_fused_batchnorm_concat(hip, dtype, c, ct):
+    """torchsparse.cat([relu(bn(x)), skip]) of the decoder (R:.../minkunet/minkunet.py:404-416) as ONE apply launch: the
+    BN result lands in the left columns of the concat buffer, the skip tensor is copied to the right ones, and backward
+    reads its dy through the row stride -- bit-identical to BN followed by torch.cat, forward and backward."""
+    from openpcseg_amd.fused import FusedBatchNorm
+    from openpcseg_amd.sparse import SparseTensor
+    g = torch.Generator(device=DEV).manual_seed(c + ct)
+    n = 20000
+    x0 = (torch.randn(n, c, device=DEV, generator=g) * 1.5 + 0.3).to(dtype)
+    s0 = torch.randn(n, ct, device=DEV, generator=g).to(dtype)
+    gy = torch.randn(n, c + ct, device=DEV, generator=g).to(dtype)
+    coords = torch.zeros(n, 4, dtype=torch.int32, device=DEV)
+    bn = FusedBatchNorm(c).to(DEV).train()
+    outs = []
+    for fused in (True, False):
+        bn.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        s = s0.clone().requires_grad_(True)
+        if fused:
+            y = bn(SparseTensor(x, coords), relu=True, cat_with=SparseTensor(s, coords)).F
+        else:
+            y = torch.cat([bn(SparseTensor(x, coords), relu=True).F, s], dim=1)
+        assert y.shape == (n, c + ct) and y.dtype == dtype
+        (y * gy).sum().backward()
+        outs.append((y.detach(), x.grad, s.grad, bn.weight.grad.clone(), bn.bias.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
