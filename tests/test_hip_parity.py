@@ -740,3 +740,49 @@ def test_fused_batchnorm_concat(hip, dtype, c, ct):
         outs.append((y.detach(), x.grad, s.grad, bn.weight.grad.clone(), bn.bias.grad.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_half_paths_empty_and_ragged(hip, dtype):
+    """Edge cases of the round-2 kernels: isolated voxels (only the centre offset has pairs), 1 voxel, tile boundary + 1,
+    empty tensors -- half conv, wgrad from half operands (wgrad3 and wgrad2<half>), the fp32 split path, conv write-back
+    statistics, half BatchNorm, the cylinder front-end and the one-sort voxel set."""
+    from openpcseg_amd import cylinder
+    from openpcseg_amd import functional as F
+    for n in (1, 129, 130):
+        c = np.zeros((n, 4), np.int32)
+        c[:, 0] = np.arange(n) * 5
+        entry = F.build_kernel_map(t(c), t(c), (3, 3, 3), (1, 1, 1), (1, 1, 1))
+        rng = np.random.default_rng(n)
+        x = torch.from_numpy(rng.normal(size=(n, 128)).astype(np.float32)).to(dtype)
+        w = torch.from_numpy((rng.normal(size=(27, 128, 128)) * 0.1).astype(np.float32)).to(dtype)
+        xd, wd = x.to(DEV), w.float().to(DEV)
+        wp = hip.prepare_weights_h(wd, dtype, transpose=False)
+        got = []
+        y = hip.conv_gather_gemm_h(xd, wp, 27, 128, entry.fwd, bn_sums=got)
+        ref = x.float().numpy() @ w.float().numpy()[13]
+        tol = (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11)
+        assert np.abs(y.float().cpu().numpy() - ref).max() <= tol * np.abs(ref).max() + 1e-5
+        if got:  # small tiles may not hold the statistics scratch: then the list stays empty
+            assert float(got[0][-1]) == n
+        gw = hip.conv_wgrad_h(xd, xd, entry.fwd, 0)  # 128 x 128: wgrad3
+        close(gw[13], x.float().numpy().T @ x.float().numpy(), 2e-5)
+        assert float(gw[0].abs().max()) == 0.0 and float(gw[26].abs().max()) == 0.0
+        gw2 = hip.conv_wgrad_h(xd[:, :32].contiguous(), xd[:, :32].contiguous(), entry.fwd, 0)  # 32 x 32: wgrad2<half>
+        close(gw2[13], x.float().numpy()[:, :32].T @ x.float().numpy()[:, :32], 2e-5)
+        xf = xd.float()
+        close(hip.conv_wgrad(xf, xf, entry.fwd, 0, split=True)[13], x.float().numpy().T @ x.float().numpy(), 2e-5)
+    # empty tensors
+    e4 = torch.zeros(0, 4, dtype=torch.int32, device=DEV)
+    entry = F.build_kernel_map(e4, e4, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    wp = hip.prepare_weights_h(torch.zeros(27, 64, 64, device=DEV), dtype, transpose=False)
+    assert hip.conv_gather_gemm_h(torch.zeros(0, 64, dtype=dtype, device=DEV), wp, 27, 64, entry.fwd).shape == (0, 64)
+    assert float(hip.conv_wgrad_h(torch.zeros(0, 64, dtype=dtype, device=DEV), torch.zeros(0, 64, dtype=dtype, device=DEV),
+                                  entry.fwd, 0).abs().max()) == 0.0
+    pol, coord, feat = hip.cylinder_partition(torch.zeros(0, 4, device=DEV), [0, -180, -4], [50, 180, 2], [480, 360, 32])
+    assert coord.shape == (0, 3) and feat.shape == (0, 9)
+    assert cylinder.map_voxel_predictions(torch.randn(5, 20, device=DEV), torch.zeros(0, dtype=torch.int64, device=DEV)).numel() == 0
+    with pytest.raises(RuntimeError):
+        hip.cylinder_partition(torch.zeros(4, 4, device=DEV), [0, -180, -4], [50, 180, 2], [1, 360, 32])   # grid < 2
+    with pytest.raises(RuntimeError):
+        hip.prepare_weights_h(torch.zeros(27, 5, 33, device=DEV), dtype, transpose=False)                # shape not served
