@@ -140,14 +140,24 @@ class _SkinnyLinear(Function):
     as a K = 1 convolution over the identity map: forward + dgrad on the gather-GEMM, dW on the split-reduction wgrad."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cache):
+    def forward(ctx, x, weight, bias, cache, hd=None):
+        """hd: the half dtype under autocast (the 16-bit MFMA kernel serves the forward when its shape rules allow)."""
         from .functional import _identity_map
         be = native.backend()
-        x = x.contiguous()
         km = _identity_map(x.shape[0], x.device, cache)
-        y = be.conv_gather_gemm(x, weight.t().contiguous().unsqueeze(0), km, bias)
+        w1 = weight.detach().float().t().contiguous().unsqueeze(0)  # (1, in, out)
+        cin, cout = w1.shape[1], w1.shape[2]
+        if hd is not None and be.conv_h_applies(cin, cout, 1):
+            x = x.contiguous().to(hd)
+            y = be.conv_gather_gemm_h(x, be.prepare_weights_h(w1, hd, transpose=False), 1, cout, km,
+                                      bias.float() if bias is not None else None)
+        else:
+            x = x.contiguous().float()
+            y = be.conv_gather_gemm(x, w1, km, bias.float() if bias is not None else None)
+            if hd is not None:
+                y = y.to(hd)
         ctx.save_for_backward(x, weight)
-        ctx.km = km
+        ctx.km, ctx.hd, ctx.in_dtype = km, hd, x.dtype
         return y
 
     @staticmethod
@@ -155,10 +165,18 @@ class _SkinnyLinear(Function):
         be = native.backend()
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = be.conv_gather_gemm(dy, weight.contiguous().unsqueeze(0), ctx.km) if ctx.needs_input_grad[0] else None
-        dw = be.conv_wgrad(x, dy, ctx.km, 0)[0].t() if ctx.needs_input_grad[1] else None
-        db = dy.sum(0) if ctx.needs_input_grad[2] else None
-        return dx, dw, db, None
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = be.conv_gather_gemm(dy.float(), weight.detach().float().contiguous().unsqueeze(0), ctx.km)
+        if ctx.needs_input_grad[1]:
+            if x.dtype != torch.float32 and x.shape[1] % 4 == 0 and dy.shape[1] % 4 == 0:
+                dw = be.conv_wgrad_h(x, dy.to(x.dtype), ctx.km, 0)[0].t()
+            else:
+                dw = be.conv_wgrad(x.float(), dy.float(), ctx.km, 0)[0].t()
+            dw = dw.to(weight.dtype)
+        if ctx.needs_input_grad[2]:
+            db = dy.float().sum(0)
+        return dx, dw, db, None, None
 
 
 class FusedLinear(nn.Linear):
@@ -170,10 +188,15 @@ class FusedLinear(nn.Linear):
         self._maps = {}  # identity maps by row count (a handful of distinct batch sizes per run)
 
     def forward(self, x):
-        ok = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 4096 and
-              self.in_features % 4 == 0 and self.out_features % 4 == 0 and not torch.is_autocast_enabled())
+        ok = (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and x.dim() == 2 and
+              x.shape[0] >= 4096 and self.in_features % 4 == 0 and self.out_features % 4 == 0)
         if not ok:
             return super().forward(x)
         if len(self._maps) > 8:
             self._maps.clear()
-        return _SkinnyLinear.apply(x, self.weight, self.bias, self._maps)
+        hd = None
+        if x.dtype != torch.float32:
+            hd = x.dtype
+        elif torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16):
+            hd = torch.get_autocast_dtype("cuda")
+        return _SkinnyLinear.apply(x, self.weight, self.bias, self._maps, hd)
