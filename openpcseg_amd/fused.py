@@ -38,9 +38,15 @@ def _stats_group():
                 kw["pg_options"] = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
             except Exception:
                 pass
-        g = dist.new_group(backend=dist.get_backend(), **kw)  # collective: every rank reaches its first BN layer
+        try:
+            g = dist.new_group(backend=dist.get_backend(), **kw)  # collective: every rank reaches its first BN layer
+        except Exception:  # an older / stricter torch.distributed: the statistics stay on the default group
+            try:
+                g = dist.new_group(backend=dist.get_backend())
+            except Exception:
+                g = False
         _STATS_GROUP[key] = g
-    return g
+    return g or None
 
 
 class _FusedBN(Function):
