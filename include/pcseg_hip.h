@@ -34,7 +34,7 @@ extern "C" {
 #define PCS_ELAUNCH (-3)  /* hipLaunch / hipMemsetAsync failed (pcs_last_error has text) */
 #define PCS_EUNSUPPORTED (-4)
 
-#define PCS_ABI_VERSION 3
+#define PCS_ABI_VERSION 4
 
 int pcs_abi_version(void);
 const char *pcs_last_error(void);
@@ -178,6 +178,11 @@ int pcs_rulebook_fill(const int32_t *results, int64_t nq, int32_t K, const void 
 int pcs_rulebook_tile_segments(const int32_t *pairs, const int32_t *koff, int32_t K,
                                int64_t n_dst, int32_t tile_rows, int32_t dst_col,
                                int32_t *seg, void *stream);
+/* Heaviest-first order of the row tiles of a segment table (work of a tile = its 16-row MFMA blocks over all
+ * offsets): order[i] = the tile the i-th workgroup slot of the fused convolution runs. Workgroups are dispatched in
+ * index order, so the light tiles run last and the launch drains evenly (+2..5 % on the deep levels). The order among
+ * equally heavy tiles is unspecified; results never depend on it. */
+int pcs_rulebook_tile_order(const int32_t *seg, int32_t K, int64_t ntiles, int32_t *order, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * F1  convolution_forward_cuda   TS:torchsparse/backend/convolution/convolution_cuda.cu:53-165
@@ -203,17 +208,24 @@ int pcs_rulebook_tile_segments(const int32_t *pairs, const int32_t *koff, int32_
 const char *pcs_conv_kernel_revision(void); /* identifies the fused-conv kernels a measurement file was taken on */
 int32_t pcs_conv_tile_rows(int32_t cin, int32_t cout);
 int32_t pcs_conv_pick_tile_rows(int64_t n_dst, int64_t n_pairs, int32_t K, int32_t cin, int32_t cout);
+int32_t pcs_conv_pick_tile_rows_dt(int64_t n_dst, int64_t n_pairs, int32_t K, int32_t cin, int32_t cout,
+                                   int32_t dtype); /* dtype 0: fp32 kernels (= the call above), 1 / 2: half kernels */
 /* *   bn_partial (may be NULL): [ceil(n_dst / tile_rows)][2][cout] doubles. When given, the write-back also leaves, per
  *   tile and column, sum(x) and sum(x^2) of the rows it stored: the statistics pass of the BatchNorm that follows
  *   the convolution (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:31-129) costs no extra read of the tensor;
  *   pcs_bn_reduce_partials turns them into the `sums` vector of pcs_bn_finalize_f32. Only for shapes / tile heights
  *   with pcs_conv_emits_bn_partials(...) != 0 (PCS_EUNSUPPORTED otherwise).
+ *   tile_order (may be NULL): ceil(n_dst / tile_rows) int32 from pcs_rulebook_tile_order for the same seg; NULL =
+ *   tiles in row order (XCD-contiguous ranges). Only the wave kernels (16-byte-granular shapes, cin >= 64; every
+ *   shape of the half kernels) use it.
  */
 int32_t pcs_conv_emits_bn_partials(int32_t cin, int32_t cout, int32_t K, int32_t tile_rows, int32_t dtype);
+int32_t pcs_conv_uses_tile_order(int32_t cin, int32_t cout, int32_t K, int32_t dtype); /* 1: the shape's kernel reads tile_order */
 int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t cin, const float *W,
                              int32_t K, int32_t cout, const int32_t *pairs, int32_t src_col,
                              const int32_t *seg, int32_t tile_rows, int64_t n_dst,
-                             const float *bias, float *dst, double *bn_partial, void *stream);
+                             const float *bias, float *dst, double *bn_partial, const int32_t *tile_order,
+                             void *stream);
 
 /* dst[k][b][a] = src[k][a][b]: the per-offset transposed weights dgrad contracts with (the reference transposes
  * inside torch::mm_out per offset, convolution_cuda.cu:259-263). */
@@ -373,7 +385,8 @@ int pcs_conv_prepare_weights_h(const float *W, int32_t K, int32_t A, int32_t B, 
                                void *Wp, void *stream);
 int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t cin, const void *Wp, int32_t K, int32_t cout,
                            const int32_t *pairs, int32_t src_col, const int32_t *seg, int32_t tile_rows,
-                           int64_t n_dst, const float *bias, void *dst, int32_t dtype, double *bn_partial, void *stream);
+                           int64_t n_dst, const float *bias, void *dst, int32_t dtype, double *bn_partial,
+                           const int32_t *tile_order, void *stream);
 /* fp32 operands through the bf16 MFMAs (three-plane split, six products, fp32-grade result); same arguments as _f32 */
 int pcs_conv_wgrad_f32_bf16x3(const float *fa, int32_t ca, const float *fb, int32_t cb, const int32_t *pairs,
                               int32_t a_col, const int32_t *koff_dev, const int32_t *koff_host, int32_t K, float *gW,

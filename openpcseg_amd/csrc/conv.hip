@@ -2,6 +2,8 @@
 // convolutions, fp32 storage + fp32 MFMA (v_mfma_f32_16x16x4_f32). This file: the per-layer launch shape and the C
 // entry point; the kernels live in conv_wave5.hip (>= 64 channels), conv_wave4.hip (other 16-byte-granular shapes)
 // and conv_block.hip (everything else); the weight gradient in conv_wgrad.hip.
+#include <math.h>
+
 #include "conv_common.h"
 
 using namespace pcs;
@@ -48,7 +50,7 @@ extern "C" int pcs_transpose_kab_f32(const float *src, int32_t K, int32_t A, int
 
 // Bumped whenever a fused-conv kernel, its launch shape picker or its epilogue changes: measurements keyed to kernels
 // (profiles/*_conv_traffic.json) carry the revision they were taken on and bench.py refuses a stale one.
-extern "C" const char *pcs_conv_kernel_revision(void) { return "r2.3-wave5+epilogue-stats"; }
+extern "C" const char *pcs_conv_kernel_revision(void) { return "r2.4-wave5+commit-prio+tile-order"; }
 
 extern "C" int32_t pcs_conv_tile_rows(int32_t cin, int32_t cout) {
   (void)cin;
@@ -56,52 +58,82 @@ extern "C" int32_t pcs_conv_tile_rows(int32_t cin, int32_t cout) {
   return 128;
 }
 
-// Output tile height for one layer. The workgroups of a launch run in waves of (CUs x 2) -- two 4-wave
-// workgroups fit a CU -- so a launch of 1.1 waves takes as long as one of 2.0: with few output rows (strides
-// 8/16) a height is chosen that fills the last wave (s16 256->256: 66.9 -> 82.7 TFLOP/s). Model: waves(T) x (pairs per tile + padding of half a
-// 16-row block per offset); 128 unless another height is predicted >= 5 % faster.
-extern "C" int32_t pcs_conv_pick_tile_rows(int64_t n_dst, int64_t n_pairs, int32_t K, int32_t cin, int32_t cout) {
+// Output tile height for one layer call (profiles/round2_tile_sweep_{f32,bf16}.md: every k3 shape of MinkUNet-34 on the
+// 12-frame maps x 13 heights). Model of one launch: the workgroups of a CU share its MFMA pipe, so the launch takes
+// (workgroups per CU) x (work of one workgroup), work = pairs per tile + the padding of half a 16-row block per offset;
+// the last, partly filled round of workgroups counts half (heaviest-first tile order: the light tiles fill it).
+// Tall tiles pad less but fit fewer workgroups per CU (LDS holds the fp32 accumulator tile).
+namespace {
+double launch_cost(int64_t n_dst, int T, int64_t ncol, double ppr, int K) {
+  const double per_cu = (double)(ceil_div(n_dst, T) * ncol) / (double)device_cus();
+  const double rounds = 0.5 * (ceil(per_cu) + per_cu);
+  return rounds * (T * ppr + 8.0 * K);
+}
+}  // namespace
+
+extern "C" int32_t pcs_conv_pick_tile_rows_dt(int64_t n_dst, int64_t n_pairs, int32_t K, int32_t cin, int32_t cout,
+                                              int32_t dtype) {
   static const int fixed = getenv("PCS_CONV_TILE") ? atoi(getenv("PCS_CONV_TILE")) : 0;
-  if (n_dst <= 0 || K <= 0 || !conv5_applies(cin, cout, K)) return 128;
+  if (n_dst <= 0 || K <= 0 || cin <= 0 || cout <= 0) return 128;
+  if (!(dtype == 0 ? conv5_applies(cin, cout, K) : convh_applies(cin, cout, K))) return 128;
   if (fixed > 0) return fixed;
-  const int64_t slots = (int64_t)device_cus() * 2;
   const double ppr = (double)n_pairs / (double)n_dst;
-  if (cout >= 192) {
-    // wide outputs: 64-column tiles on 192..288-row tiles (two 4-wave workgroups per CU), see launch_conv_wave5
-    const int64_t ncol64 = ceil_div(cout, 64);
-    int best = 256;
+  const int nctt = conv_nctt(cout);
+  if (dtype != 0) {
+    // 16-bit MFMA kernels: bound by the operand stream and, on the sparse levels, by the serial commit chain of a
+    // workgroup -- two (or more) 4-wave workgroups per CU beat one tall 8-wave workgroup except on the >= 256-channel
+    // deep levels, where the tall tile's lower padding and W reuse win (224 / 288 rows)
+    if (cin >= 256 && cout >= 256) {
+      const int64_t ncol = ceil_div(cout, 16 * nctt);
+      return launch_cost(n_dst, 288, ncol, ppr, K) <= launch_cost(n_dst, 224, ncol, ppr, K) ? 288 : 224;
+    }
+    // up to the tallest tile that fits twice per CU (192 rows at 96 columns, 144 at 128); below a few rounds of
+    // workgroups the height that fills the last round
+    const int64_t ncol = ceil_div(cout, 16 * nctt);
+    const int tmax = nctt == 6 ? 192 : 144;
+    int best = tmax;
+    double best_cost = launch_cost(n_dst, tmax, ncol, ppr, K);
+    for (int T = tmax - 16; T >= tmax - 48; T -= 16) {
+      const double c = launch_cost(n_dst, T, ncol, ppr, K);
+      if (c < best_cost * 0.97) { best = T; best_cost = c; }
+    }
+    return best;
+  }
+  if (conv5_nctt(cout, 192) <= 4) {
+    // <= 64-column tiles (32 / 64 outputs, or >= 128 outputs as 64-column tiles): 192..288 rows, 2-3 workgroups per CU
+    const int64_t ncol = ceil_div(cout, 16 * conv5_nctt(cout, 192));
+    int best = 224;
     double best_cost = 0;
     for (int T = 192; T <= 288; T += 32) {
-      const double c = (double)ceil_div(ceil_div(n_dst, T) * ncol64, slots) * (T * ppr + 8.0 * K);
+      const double c = launch_cost(n_dst, T, ncol, ppr, K);
       if (best_cost == 0 || c < best_cost) { best = T; best_cost = c; }
     }
     return best;
   }
-  const int nctt = conv_nctt(cout);
+  // 96-column tiles (and other shapes of six / eight 16-column tiles that are not multiples of 64)
   const int64_t ncol = ceil_div(cout, 16 * nctt);
-  auto cost = [&](int T) {
-    const int64_t wgs = ceil_div(n_dst, T) * ncol;
-    return (double)ceil_div(wgs, slots) * (T * ppr + 8.0 * K);
-  };
-  // many waves of workgroups and few pairs per row (strides 1/2: 4-5.5 pairs per row, 1.28-1.36x MFMA padding at
-  // 128 rows): one 8-wave workgroup per CU on 256..384-row tiles pads 1.12-1.17x (measured +3..8 %)
+  const int64_t slots = (int64_t)device_cus() * 2;
+  // many rounds of workgroups and few pairs per row (strides 1/2: 4-5.5 pairs per row, 1.28-1.36x MFMA padding at
+  // 128 rows): one 8-wave workgroup per CU on the tallest tile the LDS holds pads 1.12-1.17x
   if (ceil_div(n_dst, 128) * ncol >= 8 * slots && ppr < 6.5) {
-    int T = 384;  // the tallest tile the LDS holds, up to 384 rows (256 -> 384 rows at 96 columns: another +4 %)
+    int T = 384;
     while (T > 128 && (size_t)((T + 1) * (16 * nctt + 4)) * 4 + 1024 > kMaxDynLds) T -= 32;
     if (T >= 192) return T;
   }
-  // measured: beyond ~4 waves the choice among 96..160 is within +-3 % either way -> keep the default there
-  if (ceil_div(n_dst, 128) * ncol >= 4 * slots) return 128;
   int best = 128;
-  double best_cost = cost(128) * 0.95;
-  for (int T = 80; T <= 160; T += 16) {
+  double best_cost = launch_cost(n_dst, 128, ncol, ppr, K) * 0.97;
+  for (int T = 80; T <= 192; T += 16) {
     if (T == 128) continue;
     const size_t lds = (size_t)((T + 1) * (16 * nctt + 4)) * 4 + 5 * 33 * 4 + 16;
     if (2 * (lds + 1024) > 160 * 1024) continue;  // keep two workgroups per CU
-    const double c = cost(T);
+    const double c = launch_cost(n_dst, T, ncol, ppr, K);
     if (c < best_cost) { best = T; best_cost = c; }
   }
   return best;
+}
+
+extern "C" int32_t pcs_conv_pick_tile_rows(int64_t n_dst, int64_t n_pairs, int32_t K, int32_t cin, int32_t cout) {
+  return pcs_conv_pick_tile_rows_dt(n_dst, n_pairs, K, cin, cout, 0);
 }
 
 // 1 when the fused convolution of this shape can leave per-tile BatchNorm partial sums in its write-back (the wave
@@ -111,7 +143,7 @@ extern "C" int32_t pcs_conv_emits_bn_partials(int32_t cin, int32_t cout, int32_t
   int nctt = conv_nctt(cout), nt = 256;
   if (dtype == 0) {
     if (conv5_applies(cin, cout, K)) {
-      if (cout >= 192 && tile_rows >= 192) nctt = 4;
+      nctt = conv5_nctt(cout, tile_rows);
       const size_t lds = (size_t)((tile_rows + 1) * (16 * nctt + 4)) * 4 + 1024;
       nt = 2 * lds > 160 * 1024 ? 512 : 256;
     } else if (tile_rows != 64 && tile_rows != 128) {
@@ -125,11 +157,18 @@ extern "C" int32_t pcs_conv_emits_bn_partials(int32_t cin, int32_t cout, int32_t
   return conv_stats_fit(tile_rows, 16 * nctt, nt) ? 1 : 0;
 }
 
+// 1 when the fused convolution of this shape reads `tile_order` (the wave-autonomous kernels). dtype as above.
+extern "C" int32_t pcs_conv_uses_tile_order(int32_t cin, int32_t cout, int32_t K, int32_t dtype) {
+  if (cin <= 0 || cout <= 0 || K <= 0) return 0;
+  return (dtype == 0 ? conv5_applies(cin, cout, K) : convh_applies(cin, cout, K)) ? 1 : 0;
+}
+
 extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t cin,
                                         const float *W, int32_t K, int32_t cout,
                                         const int32_t *pairs, int32_t src_col,
                                         const int32_t *seg, int32_t tile_rows, int64_t n_dst,
-                                        const float *bias, float *dst, double *bn_partial, void *stream) {
+                                        const float *bias, float *dst, double *bn_partial,
+                                        const int32_t *tile_order, void *stream) {
   if (cin <= 0 || cout <= 0 || K <= 0 || n_dst < 0 || n_src < 0 || (src_col != 0 && src_col != 1)) {
     set_error("pcs_conv_gather_gemm_f32: bad sizes");
     return PCS_EINVAL;
@@ -141,6 +180,7 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
   a.src = src; a.W = W; a.bias = bias; a.dst = dst; a.pairs = pairs; a.seg = seg;
   a.n_dst = n_dst; a.ntiles = ceil_div(n_dst, tile_rows); a.tile_rows = tile_rows;
   a.cin = cin; a.cout = cout; a.K = K; a.src_col = src_col; a.ncoltiles = 1; a.stats = bn_partial;
+  a.order = tile_order;
   if (bn_partial && !pcs_conv_emits_bn_partials(cin, cout, K, tile_rows, 0)) {
     set_error("pcs_conv_gather_gemm_f32: this shape / tile height does not produce BatchNorm partials (ask pcs_conv_emits_bn_partials)");
     return PCS_EUNSUPPORTED;

@@ -38,6 +38,7 @@ struct ConvArgs {
   int64_t ntiles;
   int cin, cout, K, src_col, ncoltiles, xcd_remap, tile_rows;
   double *stats;  // optional [ntiles][2][cout]: per-tile column sums / sums of squares of the rows written (BatchNorm)
+  const int32_t *order;  // optional [ntiles]: workgroup slot -> row tile (heaviest first), nullptr = row order
 };
 
 // storage-format tags of the half-precision kernels (features / prepared weights / outputs)
@@ -66,6 +67,14 @@ inline int conv_nctt(int cout) {
   if (nctt == 5) nctt = 6;
   if (nctt == 7) nctt = 8;
   return nctt;
+}
+// fp32 wave5: 16-column MFMA tiles per column tile for (cout, tile height). >= 128 output columns on tiles of 176 rows
+// or more run as 64-column tiles (144 VGPRs: three waves per SIMD, two to three workgroups per CU; the taller tile pads
+// fewer MFMA rows and the A rows read once per column tile cost nothing, profiles/round1_conv_pmc.md).
+inline int conv5_nctt(int cout, int tile_rows) {
+  if (cout >= 128 && cout % 64 == 0 && tile_rows >= 176) return 4;
+  if (cout >= 192 && tile_rows >= 192) return 4;
+  return conv_nctt(cout);
 }
 // wave5 serves 16-byte-granular shapes with a contraction of at least two 32-channel steps and an even column tile
 inline bool conv5_applies(int cin, int cout, int K) {

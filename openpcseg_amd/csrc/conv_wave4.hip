@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os4_kernel(ConvArgs a) {
   int *commit = kl_r + 33;                                   // ticket: number of row blocks committed
   __shared__ int nk_s;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // a scalar: wave-level loops and branches stay uniform
   const int g = lane >> 4, l15 = lane & 15;
   // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (observed dispatch order, speed only).
   // Give every XCD one CONTIGUOUS range of tiles so that neighbouring tiles -- which gather

@@ -47,14 +47,15 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
   int *commit = kl_h + 33;
   __shared__ int nk_s;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // a scalar: wave-level loops and branches stay uniform
   const int g = lane >> 4, l15 = lane & 15;
   unsigned bid = blockIdx.x;
-  if (a.xcd_remap) {
+  if (a.xcd_remap && !a.order) {  // row order: one contiguous tile range per XCD; heaviest-first order: dealt round-robin
     const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int64_t tile = bid / a.ncoltiles;
+  const int64_t slot = bid / a.ncoltiles;
+  const int64_t tile = a.order ? (int64_t)a.order[slot] : slot;
   const int ctile = bid % a.ncoltiles;
   const int n0 = ctile * C::CT;
   const int64_t row0 = tile * T;
@@ -86,15 +87,19 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
       nk_s = nkk; kl_g[nkk] = total & 0xFFFF; kl_h[nkk] = total >> 16; *commit = 0;
     }
   }
-  for (int i = tid; i < (T + 1) * C::ACS; i += C::NT) acc_l[i] = 0.f;
+  {  // zero the tile: (T + 1) * ACS floats, a multiple of four
+    float4 *z = reinterpret_cast<float4 *>(acc_l);
+    const int n4 = (T + 1) * (C::ACS / 4);
+    for (int i = tid; i < n4; i += C::NT) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __syncthreads();
-  const int nk = nk_s;
+  const int nk = __builtin_amdgcn_readfirstlane(nk_s);  // scalars: the group loop and its branches are wave-uniform
   // group order = commit order: all full groups (R row blocks, equal duration) in ascending offset order, then the
   // partial groups. Waves take groups round-robin and commit in order, so neighbours of equal length never wait
   // for each other (with offset-major numbering a short group queued behind a long one idled its wave: 9-12 % of
   // the wave time in the ticket wait, tools/conv_trace.py). The order depends on the map only: deterministic.
-  const int total_full = nk > 0 ? kl_g[nk] : 0;
-  const int total_grp = nk > 0 ? total_full + kl_h[nk] : 0;
+  const int total_full = nk > 0 ? __builtin_amdgcn_readfirstlane(kl_g[nk]) : 0;
+  const int total_grp = nk > 0 ? total_full + __builtin_amdgcn_readfirstlane(kl_h[nk]) : 0;
 
   const int cin4 = a.cin - 4;
   int col4[C::N4 > 0 ? C::N4 : 1];
@@ -222,7 +227,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
 #pragma unroll
       for (int t = 0; t < NCTT; ++t) acc[r][t] = (f32x4){0, 0, 0, 0};
     const unsigned vmask = cur.vmask;
-    const int nr = cur.nr;  // wave-uniform
+    const int nr = __builtin_amdgcn_readfirstlane(cur.nr);  // wave-uniform: a scalar, so the bodies below are real branches
     // MFMAs of one 16-channel block for the first NR row blocks of the group (NR is wave-uniform)
     auto mfma_frag = [&](const Frag &f, auto nr_tag) {
       constexpr int NR = decltype(nr_tag)::value;
@@ -287,12 +292,23 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
 #undef PCS_BODY5
 #undef PCS_PIPE5
     // ---- in-order commit of the group's row blocks -------------------------------------------------------
+    // The commits of a workgroup form ONE serial chain (ticket order = group order: bit-reproducible sums); on the
+    // sparse full-resolution levels (384-row tiles, 8 waves, ~62 groups per tile) that chain, not the MFMA pipe,
+    // bounds the tile. So the row addresses are formed BEFORE the ticket wait, and the wave raises its priority while
+    // it holds the ticket (its VALU / LDS instructions otherwise queue behind the MFMA streams of the waves sharing
+    // its SIMD): +8 % and +3 % at stride 1. A second ticket for half of the columns bought nothing on top.
     PCS_T(const long long tr_b = wall_clock64();)
+    int doff[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) doff[r][j] = __shfl(cur.dloc[r], 4 * g + j, 64) * C::ACS;
     if (lane == 0) {
       while (__hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != grp)
         __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    __builtin_amdgcn_s_setprio(3);
     PCS_T(const long long tr_c = wall_clock64();)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -300,7 +316,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
         // all LDS reads of the block first (one latency), then the adds, then the writes
         float *d[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d[j] = acc_l + __shfl(cur.dloc[r], 4 * g + j, 64) * C::ACS;
+        for (int j = 0; j < 4; ++j) d[j] = acc_l + doff[r][j];
         float4 v4[4][C::N4 > 0 ? C::N4 : 1];
         float2 v2[4];
         float v1[4];
@@ -329,6 +345,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) __hip_atomic_store(commit, grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_s_setprio(0);
     PCS_T(const long long tr_d = wall_clock64(); tr_loop += tr_b - tr_a; tr_ticket += tr_c - tr_b; tr_commit += tr_d - tr_c; ++tr_groups;)
     cur = nxt;
     i = in;
@@ -379,6 +396,16 @@ int launch_conv5(const ConvArgs &a, hipStream_t st) {
     attr_set = true;
   }
   PCS_T(trace_prepare(st);)
+  static const int dbg = getenv("PCS_CONV_DEBUG") ? atoi(getenv("PCS_CONV_DEBUG")) : 0;  // debug: launch shape + residency
+  static long long dbg_last = -1;
+  const long long dbg_key = ((long long)a.tile_rows << 32) ^ ((long long)a.cin << 16) ^ a.cout;
+  if (dbg && dbg_key != dbg_last) {
+    dbg_last = dbg_key;
+    int nb = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), C::NT, lds);
+    fprintf(stderr, "[pcs_conv] wave5<%d,%d,%d,%d> T=%d cin=%d cout=%d grid=%lld lds=%zu resident WG/CU=%d (waves/SIMD=%d)\n", NCTT, NW,
+            MINW, R, a.tile_rows, a.cin, a.cout, (long long)nblocks, lds, nb, nb * NW / 4);
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(C::NT), lds, st, a);
   return check_launch("pcs_conv_gather_gemm_f32(wave5)");
 }
@@ -395,10 +422,7 @@ extern "C" int pcs_debug_conv_trace(long long *host_out) {
 #endif
 
 int pcs::launch_conv_wave5(ConvArgs a, hipStream_t st) {
-  int nctt = conv_nctt(a.cout);
-  // wide outputs on tall tiles: 64-column tiles (4 workgroups per 256 columns instead of 2) -- the taller tile pads
-  // fewer MFMA rows and the A rows read twice as often cost nothing (profiles/round1_conv_pmc.md): +5..7 % at 256 ch
-  if (a.cout >= 192 && a.tile_rows >= 192) nctt = 4;
+  int nctt = conv5_nctt(a.cout, a.tile_rows);  // wide outputs on tall tiles: 64-column tiles
   static const int force_nctt = getenv("PCS_CONV_NCTT") ? atoi(getenv("PCS_CONV_NCTT")) : 0;  // debug
   static const int force_nw = getenv("PCS_CONV_NW") ? atoi(getenv("PCS_CONV_NW")) : 0;        // debug: 4 / 8
   if (force_nctt && nctt > force_nctt) nctt = force_nctt;

@@ -84,6 +84,7 @@ struct ConvArgsH {
   int64_t ntiles;
   int cin, cout, K, src_col, ncoltiles, xcd_remap, tile_rows, nt16, ns;
   double *stats;  // optional [ntiles][2][cout], as ConvArgs::stats (over the ROUNDED values stored)
+  const int32_t *order;  // optional [ntiles]: workgroup slot -> row tile (heaviest first), as ConvArgs::order
 };
 
 template <int NCTT, int NW_, int R_>
@@ -113,14 +114,15 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
   int *commit = kl_h + 33;
   __shared__ int nk_s;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // a scalar: wave-level loops and branches stay uniform
   const int g = lane >> 4, l15 = lane & 15;
   unsigned bid = blockIdx.x;
-  if (a.xcd_remap) {
+  if (a.xcd_remap && !a.order) {
     const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int64_t tile = bid / a.ncoltiles;
+  const int64_t slot = bid / a.ncoltiles;
+  const int64_t tile = a.order ? (int64_t)a.order[slot] : slot;
   const int ctile = bid % a.ncoltiles;
   const int n0 = ctile * C::CT;
   const int64_t row0 = tile * T;
@@ -152,11 +154,15 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
       nk_s = nkk; kl_g[nkk] = total & 0xFFFF; kl_h[nkk] = total >> 16; *commit = 0;
     }
   }
-  for (int i = tid; i < (T + 1) * C::ACS; i += C::NT) acc_l[i] = 0.f;
+  {  // zero the tile: (T + 1) * ACS floats, a multiple of four
+    float4 *z = reinterpret_cast<float4 *>(acc_l);
+    const int n4 = (T + 1) * (C::ACS / 4);
+    for (int i = tid; i < n4; i += C::NT) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __syncthreads();
-  const int nk = nk_s;
-  const int total_full = nk > 0 ? kl_g[nk] : 0;
-  const int total_grp = nk > 0 ? total_full + kl_h[nk] : 0;
+  const int nk = __builtin_amdgcn_readfirstlane(nk_s);  // scalars: the group loop and its branches are wave-uniform
+  const int total_full = nk > 0 ? __builtin_amdgcn_readfirstlane(kl_g[nk]) : 0;
+  const int total_grp = nk > 0 ? total_full + __builtin_amdgcn_readfirstlane(kl_h[nk]) : 0;
 
   // B fragments of this column tile: 16-column tiles that do not exist (beyond cout) read tile 0, results dropped
   const int gt0 = ctile * NCTT;
@@ -247,7 +253,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
 #pragma unroll
       for (int t = 0; t < NCTT; ++t) acc[r][t] = (f32x4){0, 0, 0, 0};
     const unsigned vmask = cur.vmask;
-    const int nr = cur.nr;  // wave-uniform
+    const int nr = __builtin_amdgcn_readfirstlane(cur.nr);  // wave-uniform: a scalar, so the bodies below are real branches
     auto mfma_frag = [&](const Frag &f) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -282,18 +288,25 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
       mfma_frag(f0);
       f0 = f1;
     }
-    // ---- in-order commit of the group's row blocks (identical to conv_wave5.hip) ------------------------------
+    // ---- in-order commit of the group's row blocks (as conv_wave5.hip: row addresses formed before the ticket wait,
+    // raised wave priority while the ticket is held -- the commits of a workgroup are one serial chain) -----------
+    int doff[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) doff[r][j] = __shfl(cur.dloc[r], 4 * g + j, 64) * C::ACS;
     if (lane == 0) {
       while (__hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != grp)
         __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (r < nr) {  // wave-uniform
         float *d[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d[j] = acc_l + __shfl(cur.dloc[r], 4 * g + j, 64) * C::ACS;
+        for (int j = 0; j < 4; ++j) d[j] = acc_l + doff[r][j];
         float4 v4[4][C::N4 > 0 ? C::N4 : 1];
         float2 v2[4];
         float v1[4];
@@ -322,6 +335,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) __hip_atomic_store(commit, grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_s_setprio(0);
     cur = nxt;
     i = in;
   }
@@ -361,7 +375,9 @@ int launch_conv5h(const ConvArgsH &a, hipStream_t st) {
 
 template <typename HT>
 int launch_h(ConvArgsH a, hipStream_t st) {
-  const int nctt = conv_nctt(a.cout);
+  int nctt = conv_nctt(a.cout);
+  static const int force_nctt = getenv("PCS_CONVH_NCTT") ? atoi(getenv("PCS_CONVH_NCTT")) : 0;  // debug: narrower column tiles
+  if (force_nctt && nctt > force_nctt && a.cout % (16 * force_nctt) == 0 && !a.stats) nctt = force_nctt;
   a.ncoltiles = (int)ceil_div(a.cout, 16 * nctt);
   const size_t lds = (size_t)((a.tile_rows + 1) * (16 * nctt + 4)) * 4 + 1024;
   const bool nw8 = 2 * lds > 160 * 1024;  // 4-wave workgroups while two of them fit a CU's LDS, else one 8-wave workgroup
@@ -414,7 +430,7 @@ extern "C" int pcs_conv_prepare_weights_h(const float *W, int32_t K, int32_t A, 
 extern "C" int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t cin, const void *Wp, int32_t K, int32_t cout,
                                       const int32_t *pairs, int32_t src_col, const int32_t *seg, int32_t tile_rows,
                                       int64_t n_dst, const float *bias, void *dst, int32_t dtype, double *bn_partial,
-                                      void *stream) {
+                                      const int32_t *tile_order, void *stream) {
   if (cin <= 0 || cout <= 0 || K <= 0 || n_dst < 0 || n_src < 0 || (src_col != 0 && src_col != 1) || (dtype != 1 && dtype != 2)) {
     set_error("pcs_conv_gather_gemm_h: bad sizes");
     return PCS_EINVAL;
@@ -428,7 +444,7 @@ extern "C" int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t ci
   a.src = reinterpret_cast<const char *>(src); a.Wp = reinterpret_cast<const char *>(Wp); a.bias = bias;
   a.dst = reinterpret_cast<uint16_t *>(dst); a.pairs = pairs; a.seg = seg;
   a.n_dst = n_dst; a.ntiles = ceil_div(n_dst, tile_rows); a.tile_rows = tile_rows;
-  a.cin = cin; a.cout = cout; a.K = K; a.src_col = src_col; a.ncoltiles = 1; a.xcd_remap = 1; a.stats = bn_partial;
+  a.cin = cin; a.cout = cout; a.K = K; a.src_col = src_col; a.ncoltiles = 1; a.xcd_remap = 1; a.stats = bn_partial; a.order = tile_order;
   if (bn_partial && !pcs_conv_emits_bn_partials(cin, cout, K, tile_rows, dtype)) {
     set_error("pcs_conv_gather_gemm_h: this shape / tile height does not produce BatchNorm partials");
     return PCS_EUNSUPPORTED;

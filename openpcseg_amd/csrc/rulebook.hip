@@ -204,6 +204,53 @@ __global__ void __launch_bounds__(256) rb_segments_kernel(const int32_t *__restr
   }
 }
 
+// Heaviest-first order of the row tiles of one segment table: work(t) = 16-row blocks of tile t over all offsets (what
+// the fused convolution issues MFMAs for). One workgroup: histogram of the work values, descending prefix, scatter.
+// The order among equally heavy tiles is arbitrary -- it only decides which workgroup slot runs which tile, never a sum.
+constexpr int kOrderBins = 2048;  // work <= K * (tile_rows / 16 + 1) <= 32 * 33
+__global__ void __launch_bounds__(1024) rb_tile_order_kernel(const int32_t *__restrict__ seg, int K, int64_t ntiles,
+                                                             int32_t *__restrict__ order) {
+  __shared__ int hist[kOrderBins];
+  __shared__ int base[kOrderBins];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  const int64_t nt1 = ntiles + 1;
+  auto work_of = [&](int64_t t) {
+    int w = 0;
+    for (int k = 0; k < K; ++k) {
+      const int64_t o = (int64_t)k * nt1 + t;
+      w += (seg[o + 1] - seg[o] + 15) >> 4;
+    }
+    return w < kOrderBins - 1 ? w : kOrderBins - 1;
+  };
+  for (int i = tid; i < kOrderBins; i += 1024) hist[i] = 0;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int64_t t = tid; t < ntiles; t += 1024) atomicAdd(&hist[work_of(t)], 1);
+  __syncthreads();
+  // base[w] = number of tiles heavier than w: two bins per thread, scanned from the heavy end
+  {
+    const int b0 = kOrderBins - 1 - 2 * tid, b1 = b0 - 1;  // this thread's bins, heavy first
+    const int h0 = hist[b0], h1 = hist[b1];
+    int incl = h0 + h1;
+    const int lane = tid & 63, wid = tid >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    __shared__ int wsum[16];
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wid; ++w) off += wsum[w];
+    const int excl = off + incl - (h0 + h1);
+    base[b0] = excl;
+    base[b1] = excl + h0;
+  }
+  __syncthreads();
+  for (int64_t t = tid; t < ntiles; t += 1024) order[atomicAdd(&base[work_of(t)], 1)] = (int32_t)t;
+}
+
 struct RbWs {
   int32_t *blockcnt;  // K*nblk
   int32_t *blockoff;  // K*nblk + 1
@@ -319,4 +366,12 @@ extern "C" int pcs_rulebook_tile_segments(const int32_t *pairs, const int32_t *k
   hipLaunchKernelGGL(rb_segments_kernel, dim3(stream_grid((int64_t)K * nt1, 256)), dim3(256), 0,
                      as_stream(stream), pairs, koff, (int)K, nt1, (int)tile_rows, (int)dst_col, seg);
   return check_launch("pcs_rulebook_tile_segments");
+}
+
+extern "C" int pcs_rulebook_tile_order(const int32_t *seg, int32_t K, int64_t ntiles, int32_t *order, void *stream) {
+  if (K <= 0 || K > 32 || ntiles < 0 || ntiles > 0x7FFFFFFF) { set_error("pcs_rulebook_tile_order: bad sizes"); return PCS_EINVAL; }
+  if (ntiles == 0) return PCS_OK;
+  if (!seg || !order) { set_error("pcs_rulebook_tile_order: null pointer"); return PCS_EINVAL; }
+  hipLaunchKernelGGL(rb_tile_order_kernel, dim3(1), dim3(1024), 0, as_stream(stream), seg, (int)K, ntiles, order);
+  return check_launch("pcs_rulebook_tile_order");
 }

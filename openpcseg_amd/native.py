@@ -40,12 +40,15 @@ SIGNATURES = {
     "pcs_rulebook_probe": (c_int32, [_P, c_int64, _P, c_int32, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "pcs_rulebook_fill": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P]),
     "pcs_rulebook_tile_segments": (c_int32, [_P, _P, c_int32, c_int64, c_int32, c_int32, _P, _P]),
+    "pcs_rulebook_tile_order": (c_int32, [_P, c_int32, c_int64, _P, _P]),
     "pcs_conv_kernel_revision": (c_char_p, []),
     "pcs_conv_tile_rows": (c_int32, [c_int32, c_int32]),
     "pcs_conv_pick_tile_rows": (c_int32, [c_int64, c_int64, c_int32, c_int32, c_int32]),
+    "pcs_conv_pick_tile_rows_dt": (c_int32, [c_int64, c_int64, c_int32, c_int32, c_int32, c_int32]),
     "pcs_conv_emits_bn_partials": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "pcs_conv_uses_tile_order": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     "pcs_conv_gather_gemm_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32,
-                                           _P, c_int32, c_int64, _P, _P, _P, _P]),
+                                           _P, c_int32, c_int64, _P, _P, _P, _P, _P]),
     "pcs_bn_reduce_partials": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P]),
     "pcs_transpose_kab_f32": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_conv_wgrad_ws_bytes": (c_size_t, [_P, c_int32, c_int32, c_int32]),
@@ -78,7 +81,7 @@ SIGNATURES = {
     "pcs_conv_prepared_weights_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "pcs_conv_prepare_weights_h": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_conv_gather_gemm_h": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32, _P, c_int32, c_int64,
-                                         _P, _P, c_int32, _P, _P]),
+                                         _P, _P, c_int32, _P, _P, _P]),
     "pcs_conv_wgrad_f32_bf16x3": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P,
                                             _P, c_size_t, _P]),
     "pcs_conv_wgrad_h": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P, _P, c_size_t, c_int32, _P]),
@@ -88,7 +91,7 @@ SIGNATURES = {
     "pcs_rows_argmax_gather_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
 }
 
-ABI_VERSION = 3  # include/pcseg_hip.h PCS_ABI_VERSION (3: cylinder front-end entries, float64 quantize input)
+ABI_VERSION = 4  # include/pcseg_hip.h PCS_ABI_VERSION (4: tile order of the fused convolution)
 _lib = None
 
 
@@ -479,11 +482,12 @@ class HipBackend:
                                           _stream()), "pcs_rulebook_fill")
         return KernelMap(pairs, koff, None, nbsizes, ref_coords.shape[0], nq, pending=(sizes, event), hint_key=hint_key)
 
-    def tile_rows(self, cin, cout, kmap=None):
-        """Output tile height of one conv launch: the library default, or with a kernel map the per-layer pick."""
+    def tile_rows(self, cin, cout, kmap=None, dtype=0):
+        """Output tile height of one conv launch: the library default, or with a kernel map the per-layer pick
+        (dtype 0: fp32 kernels, 1 / 2: bf16 / fp16 kernels)."""
         if kmap is None:
             return self.lib.pcs_conv_tile_rows(cin, cout)
-        return self.lib.pcs_conv_pick_tile_rows(kmap.n_dst, kmap.num_pairs_estimate(), kmap.K, cin, cout)
+        return self.lib.pcs_conv_pick_tile_rows_dt(kmap.n_dst, kmap.num_pairs_estimate(), kmap.K, cin, cout, dtype)
 
     def _segments(self, kmap, tile_rows):
         seg = kmap._seg.get(tile_rows)
@@ -495,6 +499,20 @@ class HipBackend:
                    "pcs_rulebook_tile_segments")
             kmap._seg[tile_rows] = seg
         return seg
+
+    def _tile_order(self, kmap, tile_rows):
+        """Heaviest-first order of the row tiles of (kmap, tile_rows), cached beside the segment table it is made from
+        (one small kernel per map and tile height, shared by every layer, forward and backward, that uses the map)."""
+        key = ("order", tile_rows)
+        order = kmap._seg.get(key)
+        if order is None:
+            seg = self._segments(kmap, tile_rows)
+            ntiles = (kmap.n_dst + tile_rows - 1) // tile_rows
+            order = torch.empty(max(ntiles, 1), dtype=torch.int32, device=seg.device)
+            _check(self.lib.pcs_rulebook_tile_order(_ptr(seg), kmap.K, ntiles, _ptr(order), _stream()),
+                   "pcs_rulebook_tile_order")
+            kmap._seg[key] = order
+        return order
 
     # -- convolution ----------------------------------------------------------------------------
     def _bn_partial(self, kmap, t, cin, cout, k, dtype_code, bn_sums, device):
@@ -513,7 +531,7 @@ class HipBackend:
                "pcs_bn_reduce_partials")
         bn_sums.append(sums)
 
-    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None, bn_sums=None):
+    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True):
         """dst[d] = sum_{(s,d) in offset k} src[s] @ weight[k] (+bias); kmap dst-sorted. bn_sums: a list; when the
         kernel can, the [sum x | sum x^2 | n] vector of dst (what bn_stats(dst) returns) is appended to it, computed in
         the convolution's write-back instead of by a pass over dst."""
@@ -530,10 +548,12 @@ class HipBackend:
         seg = self._segments(kmap, t)
         dst = torch.empty((kmap.n_dst, cout), dtype=torch.float32, device=src.device)
         part = self._bn_partial(kmap, t, cin, cout, k, 0, bn_sums, src.device)
+        order = self._tile_order(kmap, t) if ordered and kmap.n_dst > 0 and self.lib.pcs_conv_uses_tile_order(cin, cout, k, 0) else None
         _check(self.lib.pcs_conv_gather_gemm_f32(_ptr(src), src.shape[0], cin, _ptr(weight), k, cout,
                                                  _ptr(kmap._pairs_raw), 0, _ptr(seg), t, kmap.n_dst,
                                                  _ptr(bias) if bias is not None else None, _ptr(dst),
                                                  _ptr(part) if part is not None else None,
+                                                 _ptr(order) if order is not None else None,
                                                  _stream()), "pcs_conv_gather_gemm_f32")
         if part is not None:
             self._bn_reduce(part, t, kmap, cout, bn_sums)
@@ -559,7 +579,7 @@ class HipBackend:
                                                    _stream()), "pcs_conv_prepare_weights_h")
         return wp
 
-    def conv_gather_gemm_h(self, src, wp, k, cout, kmap, bias=None, tile_rows=None, bn_sums=None):
+    def conv_gather_gemm_h(self, src, wp, k, cout, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True):
         """Half-precision fused conv: src (n, cin) bf16 / fp16, wp = prepare_weights_h(...) of the same dtype."""
         if src.dtype not in self._HALF:
             raise TypeError("openpcseg_amd: conv_gather_gemm_h wants bfloat16 / float16 features, got %s" % src.dtype)
@@ -569,13 +589,15 @@ class HipBackend:
             raise ValueError("kernel volume %d does not match the kernel map (%d)" % (k, kmap.K))
         if bias is not None:
             bias = _dev(bias, "bias", torch.float32)
-        t = tile_rows or self.tile_rows(cin, cout, kmap)
+        t = tile_rows or self.tile_rows(cin, cout, kmap, self._HALF[src.dtype])
         seg = self._segments(kmap, t)
         dst = torch.empty((kmap.n_dst, cout), dtype=src.dtype, device=src.device)
         part = self._bn_partial(kmap, t, cin, cout, k, self._HALF[src.dtype], bn_sums, src.device)
+        order = self._tile_order(kmap, t) if ordered and kmap.n_dst > 0 else None
         _check(self.lib.pcs_conv_gather_gemm_h(_ptr(src), src.shape[0], cin, _ptr(wp), k, cout, _ptr(kmap._pairs_raw), 0,
                                                _ptr(seg), t, kmap.n_dst, _ptr(bias) if bias is not None else None,
                                                _ptr(dst), self._HALF[src.dtype], _ptr(part) if part is not None else None,
+                                               _ptr(order) if order is not None else None,
                                                _stream()), "pcs_conv_gather_gemm_h")
         if part is not None:
             self._bn_reduce(part, t, kmap, cout, bn_sums)

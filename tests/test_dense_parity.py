@@ -82,8 +82,8 @@ FWD_CASES = [
     (4, 192, 128, None), (4, 192, 128, 128), (4, 256, 128, 224),
     (8, 256, 256, None), (8, 256, 256, 128), (8, 256, 256, 224), (8, 256, 256, 288),
     (8, 384, 256, None), (8, 384, 256, 256),
-    (2, 64, 64, None), (2, 128, 64, 256),
-    (1, 96, 96, 384), (1, 128, 96, None), (1, 96, 96, 128),
+    (2, 64, 64, None), (2, 128, 64, 256), (2, 64, 64, 192), (4, 64, 32, 224), (4, 128, 128, 176), (8, 128, 256, 192),
+    (1, 96, 96, 384), (1, 128, 96, None), (1, 96, 96, 128), (1, 96, 128, None),
 ]
 
 
@@ -98,6 +98,38 @@ def test_conv_forward_dense_map(hip, levels, stride, cin, cout, tile):
     y = hip.conv_gather_gemm(dx, dw, entry.fwd, tile_rows=tile)
     close(y, orc.conv_fwd(x, w, nbmaps, nbsizes, (n, n)), 2e-5)
     assert torch.equal(y, hip.conv_gather_gemm(dx, dw, entry.fwd, tile_rows=tile))
+
+
+@pytest.mark.parametrize("stride,tile", [(1, 384), (2, 128), (4, 224), (8, 288), (8, 112)])
+def test_tile_order_heaviest_first(hip, levels, stride, tile):
+    """pcs_rulebook_tile_order: a permutation of the row tiles, work (16-row blocks over all offsets) non-increasing."""
+    entry = level_map(levels, stride)[0]
+    km = entry.fwd
+    seg = hip._segments(km, tile).view(27, -1).cpu().numpy().astype(np.int64)
+    order = hip._tile_order(km, tile).cpu().numpy()
+    ntiles = (km.n_dst + tile - 1) // tile
+    assert order.shape == (ntiles,) and np.array_equal(np.sort(order), np.arange(ntiles))
+    work = ((seg[:, 1:] - seg[:, :-1] + 15) // 16).sum(0)
+    w = work[order]
+    assert (w[:-1] >= w[1:]).all() and w[0] == work.max()
+
+
+@pytest.mark.parametrize("stride,cin,cout,tile", [(4, 128, 128, None), (8, 256, 256, None), (1, 96, 96, 384), (2, 64, 64, 128)])
+def test_conv_is_independent_of_the_tile_order(hip, levels, stride, cin, cout, tile):
+    """The tile order only decides which workgroup slot runs which tile: outputs and the BatchNorm partial sums are
+    bit-identical with the heaviest-first order and in row order, fp32 and half kernels."""
+    entry = level_map(levels, stride)[0]
+    n = entry.fwd.n_dst
+    x = torch.randn(n, cin, device=DEV)
+    w = torch.randn(27, cin, cout, device=DEV) * 0.05
+    a, b = [], []
+    ya = hip.conv_gather_gemm(x, w, entry.fwd, tile_rows=tile, bn_sums=a, ordered=True)
+    yb = hip.conv_gather_gemm(x, w, entry.fwd, tile_rows=tile, bn_sums=b, ordered=False)
+    assert torch.equal(ya, yb) and len(a) == len(b) and all(torch.equal(p, q) for p, q in zip(a, b))
+    for dtype in (torch.bfloat16, torch.float16):
+        xh, wp = x.to(dtype), hip.prepare_weights_h(w, dtype, transpose=False)
+        assert torch.equal(hip.conv_gather_gemm_h(xh, wp, 27, cout, entry.fwd, tile_rows=tile, ordered=True),
+                           hip.conv_gather_gemm_h(xh, wp, 27, cout, entry.fwd, tile_rows=tile, ordered=False))
 
 
 @pytest.mark.parametrize("stride,cin,cout", [(4, 128, 128), (4, 192, 128), (8, 256, 256), (8, 384, 256), (1, 128, 96)])

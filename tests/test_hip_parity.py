@@ -259,14 +259,21 @@ def test_rulebook_sizes_are_deferred(hip, golden):
 
 def test_conv_tile_pick_and_errors(hip, golden):
     lib = hip.lib
-    # many waves + few pairs per row (stride 1): 256-row tiles (one 8-wave workgroup per CU, less MFMA padding);
-    # many waves, dense: default height; wide outputs (>= 192 columns): 64-column tiles on 192..288 rows, the height
-    # that fills the last wave of workgroups (36k rows x 4 column tiles at 288 rows = 504 workgroups on 512 slots)
+    # the picks behind profiles/round2_tile_sweep_{f32,bf16}.md (12-frame bench maps): 96 columns on the sparse levels:
+    # the tallest tile (one 8-wave workgroup per CU); <= 64-column tiles (64 outputs, or >= 128 outputs split in
+    # 64-column tiles): 192..288 rows by the per-CU cost model (36k rows x 4 column tiles at 288 rows = 504 workgroups,
+    # two per CU); half kernels: up to the tallest tile that fits twice per CU
     assert lib.pcs_conv_pick_tile_rows(1158864, 5112372, 27, 96, 96) == 384
-    assert lib.pcs_conv_pick_tile_rows(329421, 2752033, 27, 128, 128) == 128
+    assert lib.pcs_conv_pick_tile_rows(329421, 2752033, 27, 128, 128) == 288
     assert lib.pcs_conv_pick_tile_rows(36068, 331722, 27, 256, 256) == 288
-    assert lib.pcs_conv_pick_tile_rows(113008, 1001308, 27, 128, 128) == 112
+    assert lib.pcs_conv_pick_tile_rows(113008, 1001308, 27, 128, 128) == 224
+    assert lib.pcs_conv_pick_tile_rows(113008, 1001308, 27, 256, 256) == 256
     assert lib.pcs_conv_pick_tile_rows(36068, 331722, 27, 32, 32) == 128  # not the cin >= 64 kernel
+    assert lib.pcs_conv_pick_tile_rows_dt(1158864, 5112372, 27, 96, 96, 0) == 384
+    assert lib.pcs_conv_pick_tile_rows_dt(1158864, 5112372, 27, 96, 96, 1) == 192
+    assert lib.pcs_conv_pick_tile_rows_dt(329421, 2752033, 27, 128, 128, 1) == 144
+    assert lib.pcs_conv_pick_tile_rows_dt(113008, 1001308, 27, 128, 128, 2) == 112
+    assert lib.pcs_conv_pick_tile_rows_dt(36068, 331722, 27, 256, 256, 1) == 288
     entry, _, n_in, _ = _scene_maps(hip, golden, "k3s1")
     x = torch.zeros((n_in, 32), device="cuda")
     w = torch.zeros((27, 32, 32), device="cuda")

@@ -45,6 +45,18 @@ def main():
     fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
     assert fn(buf.ctypes.data) == 0
     t = buf.reshape(8192, 8, 8)
+    # per workgroup: lifetime vs row-block groups processed (a proxy of its pairs): how much of the spread is work
+    wgs = [(w[w[:, 7] > 0]) for w in t if (w[:, 7] > 0).any()]
+    wlife = np.array([(w[:, 7].max() - w[:, 0].min()) * 0.01 for w in wgs])
+    wgrp = np.array([w[:, 6].sum() for w in wgs], dtype=np.float64)
+    if len(wgs) > 2 and wgrp.std() > 0:
+        A = np.stack([wgrp, np.ones_like(wgrp)], 1)
+        coef, *_ = np.linalg.lstsq(A, wlife, rcond=None)
+        resid = wlife - A @ coef
+        print("workgroups traced %d: lifetime mean %.0f us (p5 %.0f, p95 %.0f, max %.0f); groups/WG mean %.1f (p5 %.0f, p95 %.0f, max %.0f)" %
+              (len(wgs), wlife.mean(), *np.percentile(wlife, [5, 95, 100]), wgrp.mean(), *np.percentile(wgrp, [5, 95, 100])))
+        print("lifetime ~ %.2f us/group * groups + %.0f us; corr %.3f; residual std %.0f us" %
+              (coef[0], coef[1], np.corrcoef(wgrp, wlife)[0, 1], resid.std()))
     t = t[t[:, :, 7] > 0]                      # waves that ran
     tick = 0.01                                 # us
     life = (t[:, 7] - t[:, 0]) * tick
