@@ -186,7 +186,9 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
     return PCS_EUNSUPPORTED;
   }
   static const int xcd = getenv("PCS_CONV_XCD") ? atoi(getenv("PCS_CONV_XCD")) : 1;  // 0: no XCD-contiguous tile order (debug)
-  a.xcd_remap = xcd;
+  // 1: tiles in row order, one contiguous range per XCD; 2 (with a tile order): tiles dealt round-robin over the XCDs,
+  // the column tiles of a row tile back to back on one XCD (they gather the same A rows: +0.5..1 %)
+  a.xcd_remap = xcd ? (tile_order ? 2 : 1) : 0;
   const bool vec = (cin % 4 == 0) && (cout % 4 == 0) && (((uintptr_t)src | (uintptr_t)W | (uintptr_t)dst | (uintptr_t)bias) & 15) == 0;
   hipStream_t st = as_stream(stream);
   static const int generic = getenv("PCS_CONV_V1") ? atoi(getenv("PCS_CONV_V1")) : 0;  // 1: generic kernel only (debug)

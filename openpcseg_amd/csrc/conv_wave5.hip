@@ -54,9 +54,15 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
     const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int64_t slot = bid / a.ncoltiles;
+  int64_t slot = bid / a.ncoltiles;
+  int ctile = bid % a.ncoltiles;
+  if (a.xcd_remap == 2) {  // the column tiles of one row tile on ONE XCD, back to back (they gather the same A rows)
+    const unsigned xcd = bid & 7, idx = bid >> 3;
+    slot = (int64_t)(idx / a.ncoltiles) * 8 + xcd;
+    ctile = idx % a.ncoltiles;
+    if (slot >= a.ntiles) return;  // the grid is padded to 8 * ncoltiles
+  }
   const int64_t tile = a.order ? (int64_t)a.order[slot] : slot;
-  const int ctile = bid % a.ncoltiles;
   const int n0 = ctile * C::CT;
   const int64_t row0 = tile * T;
   const int64_t nt1 = a.ntiles + 1;
@@ -383,7 +389,7 @@ void trace_prepare(hipStream_t st) {
 template <int NCTT, int NW, int MINW, int R>
 int launch_conv5(const ConvArgs &a, hipStream_t st) {
   using C = Conv5Cfg<NCTT, NW, R>;
-  const int64_t nblocks = a.ntiles * a.ncoltiles;
+  const int64_t nblocks = a.xcd_remap == 2 ? ceil_div(a.ntiles, 8) * 8 * a.ncoltiles : a.ntiles * a.ncoltiles;
   if (nblocks <= 0) return PCS_OK;
   if (nblocks > 0x7FFFFFFF) { set_error("pcs_conv: grid too large"); return PCS_EUNSUPPORTED; }
   auto kern = conv_os5_kernel<NCTT, NW, MINW, R>;

@@ -121,9 +121,15 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
     const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int64_t slot = bid / a.ncoltiles;
+  int64_t slot = bid / a.ncoltiles;
+  int ctile = bid % a.ncoltiles;
+  if (a.order) {  // tiles dealt round-robin over the XCDs, the column tiles of one row tile back to back on one XCD
+    const unsigned xcd = bid & 7, idx = bid >> 3;
+    slot = (int64_t)(idx / a.ncoltiles) * 8 + xcd;
+    ctile = idx % a.ncoltiles;
+    if (slot >= a.ntiles) return;  // the grid is padded to 8 * ncoltiles
+  }
   const int64_t tile = a.order ? (int64_t)a.order[slot] : slot;
-  const int ctile = bid % a.ncoltiles;
   const int n0 = ctile * C::CT;
   const int64_t row0 = tile * T;
   const int64_t nt1 = a.ntiles + 1;
@@ -358,7 +364,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
 template <typename HT, int NCTT, int NW, int MINW, int R>
 int launch_conv5h(const ConvArgsH &a, hipStream_t st) {
   using C = Conv5hCfg<NCTT, NW, R>;
-  const int64_t nblocks = a.ntiles * a.ncoltiles;
+  const int64_t nblocks = a.order ? ceil_div(a.ntiles, 8) * 8 * a.ncoltiles : a.ntiles * a.ncoltiles;
   if (nblocks <= 0) return PCS_OK;
   if (nblocks > 0x7FFFFFFF) { set_error("pcs_conv_h: grid too large"); return PCS_EUNSUPPORTED; }
   auto kern = conv_os5h_kernel<HT, NCTT, NW, MINW, R>;
