@@ -271,6 +271,11 @@ __global__ void __launch_bounds__(256) wgrad_reduce4_kernel(const float *__restr
 // interleaved channels {a0+4i+f} x {b0+4n+h}. One 64x64 output block = 16 tiles = 16 MFMAs per
 // TWO 16-byte loads per lane. A workgroup = 4 waves = 4 output blocks of one (offset, pair chunk)
 // split; partial blocks go to the workspace and wgrad_reduce_kernel sums the splits in order.
+// Measured and dropped (round 2, tools/wgrad_sweep.py): the same MFMA sequence fed from a double-buffered LDS image of
+// 32-pair batches gathered once per workgroup ("wgrad4": half the global loads per MFMA, one barrier per 128 MFMAs,
+// two workgroups per CU) -- bit-identical results, 7-14 % SLOWER on the >= 96-channel layers and 2.5x slower on thin
+// ones. The PCS_ABLATEW debug builds show where wgrad2 stands: stride 8 256 x 256 1048 us with MFMAs only, 770 us
+// with loads only, 1185 us together; three waves per SIMD, each one batch ahead, already hide most of the rest.
 // ================================================================================================
 struct Wgrad2Args {
   const void *fa;  // rows of ET (float, or bf16 / fp16 halfs converted to fp32 on load)
@@ -373,18 +378,36 @@ __device__ __forceinline__ void wgrad_block(const Wgrad2Args &w, int a0, int b0,
   Batch b0s, b1s;
   load_rows(b0s, load_pairs(beg));
   int2 prn = load_pairs(beg + 16 < end ? beg + 16 : beg);  // pairs of the batch after the one in flight
+#ifndef PCS_ABLATEW
+#define PCS_ABLATEW 0  /* debug builds: 1 no row loads inside the loop, 2 no MFMAs */
+#endif
+#if PCS_ABLATEW == 1
+  load_rows(b1s, prn);
+#endif
   for (int p0 = beg; p0 < end; p0 += 32) {
     const int p2 = p0 + 32 < end ? p0 + 32 : p0;  // clamped: a redundant batch is masked out in mfma_batch
     const int p3 = p0 + 48 < end ? p0 + 48 : p0;
+#if PCS_ABLATEW != 1
     load_rows(b1s, prn);
+#endif
     prn = load_pairs(p2);
     __builtin_amdgcn_sched_barrier(0);
+#if PCS_ABLATEW != 2
     mfma_batch(b0s, p0);
+#else
+    acc[0][0][0] += wcomp(b0s.a[0], 0) + wcomp(b0s.a[1], 0) + wcomp(b0s.a[2], 0) + wcomp(b0s.a[3], 0) + wcomp(b0s.b[0], 0) + wcomp(b0s.b[1], 0) + wcomp(b0s.b[2], 0) + wcomp(b0s.b[3], 0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
+#if PCS_ABLATEW != 1
     load_rows(b0s, prn);
+#endif
     prn = load_pairs(p3);
     __builtin_amdgcn_sched_barrier(0);
+#if PCS_ABLATEW != 2
     if (p0 + 16 < end) mfma_batch(b1s, p0 + 16);  // wave-uniform
+#else
+    acc[0][0][1] += wcomp(b1s.a[0], 0) + wcomp(b1s.a[1], 0) + wcomp(b1s.a[2], 0) + wcomp(b1s.a[3], 0) + wcomp(b1s.b[0], 0) + wcomp(b1s.b[1], 0) + wcomp(b1s.b[2], 0) + wcomp(b1s.b[3], 0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
   }
   // tile (f,h), register r: row a0 + 4*(4g+r) + f, column b0 + 4*l15 + h  -> NB-wide stores
@@ -407,10 +430,14 @@ __global__ void __launch_bounds__(256, 3) wgrad2_kernel(Wgrad2Args w) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int beg, end;
   find_split_wave(w.koff, w.K, w.pch, blockIdx.x, lane, &beg, &end);  // per wave: no LDS, no barrier
-  const int blk = blockIdx.y * 4 + wid;  // output block of this wave
+  // the four waves of a workgroup own a 2 x 2 patch of output blocks: each A slice and each B slice they gather is
+  // shared by two of them through the vector L1 (a 1 x 4 row shared one A slice and read four B slices: 5 slice
+  // streams per workgroup instead of 4, +20 % L2 traffic at 256 columns)
   const int nag = wg_ngroups(w.ca);
-  if (beg >= end || blk >= nag * w.nbg) return;
-  const int ag = blk / w.nbg, bg = blk - ag * w.nbg;
+  const int nsb = (w.nbg + 1) >> 1;
+  const int sa = blockIdx.y / nsb, sb = blockIdx.y - sa * nsb;
+  const int ag = 2 * sa + (wid >> 1), bg = 2 * sb + (wid & 1);
+  if (beg >= end || ag >= nag || bg >= w.nbg) return;
   const int aw = wg_gwidth(w.ca), bw = wg_gwidth(w.cb);
   float *out = w.partial + (int64_t)blockIdx.x * w.ca * w.cb;
   const int a0 = aw * ag, b0 = bw * bg;
@@ -749,8 +776,7 @@ static int conv_wgrad_any(const void *fa_v, int32_t ca, const void *fb_v, int32_
     Wgrad2Args w2;
     w2.fa = fa; w2.fb = fb; w2.pairs = pairs; w2.koff = koff_dev; w2.partial = reinterpret_cast<float *>(ws);
     w2.ca = ca; w2.cb = cb; w2.K = K; w2.a_col = a_col; w2.pch = pch; w2.nbg = wg_ngroups(cb);
-    const int nblk = wg_ngroups(ca) * wg_ngroups(cb);
-    const dim3 grid2((unsigned)ns, (unsigned)ceil_div(nblk, 4));
+    const dim3 grid2((unsigned)ns, (unsigned)(((wg_ngroups(ca) + 1) / 2) * ((wg_ngroups(cb) + 1) / 2)));
     if (dtype == 0) hipLaunchKernelGGL(wgrad2_kernel<Fp32>, grid2, dim3(256), 0, st, w2);
     else if (dtype == 1) hipLaunchKernelGGL(wgrad2_kernel<Bf16>, grid2, dim3(256), 0, st, w2);
     else hipLaunchKernelGGL(wgrad2_kernel<Fp16>, grid2, dim3(256), 0, st, w2);
