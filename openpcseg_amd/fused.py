@@ -185,6 +185,60 @@ class _SkinnyLinear(Function):
         return dx, dw, db, None, None
 
 
+class _SkinnyLinearParts(Function):
+    """y = cat(parts, 1) @ W^T + b without the concatenation: one gather-GEMM per column block of W, summed -- the
+    classifier over [z1 | z2 | z3] (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:415-417) never materialises the
+    (N, 480) tensor (2.8 GB written and read back per step at 1.4 M points) nor, in backward, the contiguous copies of
+    its sliced gradient: every d(part) is written once, by its own launch."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, cache, hd, *parts):
+        from .functional import _identity_map
+        be = native.backend()
+        km = _identity_map(parts[0].shape[0], parts[0].device, cache)
+        wt = weight.detach().float().t().contiguous()  # (in, out)
+        saved, y, col = [], None, 0
+        for i, x in enumerate(parts):
+            cin = x.shape[1]
+            w1 = wt[col:col + cin].unsqueeze(0)  # (1, cin, out): a contiguous row block
+            b = bias.float() if (bias is not None and i == 0) else None
+            if hd is not None and be.conv_h_applies(cin, w1.shape[2], 1):
+                x = x.contiguous().to(hd)
+                t = be.conv_gather_gemm_h(x, be.prepare_weights_h(w1.contiguous(), hd, transpose=False), 1, w1.shape[2], km, b).float()
+            else:
+                x = x.contiguous().float()
+                t = be.conv_gather_gemm(x, w1.contiguous(), km, b)
+            y = t if y is None else y.add_(t)
+            saved.append(x)
+            col += cin
+        ctx.save_for_backward(weight, *saved)
+        ctx.km, ctx.hd, ctx.has_bias = km, hd, bias is not None
+        return y.to(hd) if hd is not None else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = native.backend()
+        weight, parts = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        dy32 = dy.contiguous().float()
+        w = weight.detach().float()  # (out, in)
+        grads, dws, col = [], [], 0
+        for i, x in enumerate(parts):
+            cin = x.shape[1]
+            dx = None
+            if ctx.needs_input_grad[4 + i]:
+                dx = be.conv_gather_gemm(dy32, w[:, col:col + cin].contiguous().unsqueeze(0), ctx.km)
+            grads.append(dx)
+            if ctx.needs_input_grad[0]:
+                if x.dtype != torch.float32 and cin % 4 == 0 and dy.shape[1] % 4 == 0:
+                    dws.append(be.conv_wgrad_h(x, dy32.to(x.dtype), ctx.km, 0)[0].t())
+                else:
+                    dws.append(be.conv_wgrad(x.float(), dy32, ctx.km, 0)[0].t())
+            col += cin
+        dw = torch.cat(dws, dim=1).to(weight.dtype) if ctx.needs_input_grad[0] else None
+        db = dy32.sum(0) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        return (dw, db, None, None) + tuple(grads)
+
+
 class FusedLinear(nn.Linear):
     """nn.Linear (same parameters / state_dict keys) whose fp32 device path runs on the fused conv kernels when the
     row count dwarfs the feature sizes and the shapes are 16-byte granular; anything else is nn.Linear."""
@@ -206,3 +260,20 @@ class FusedLinear(nn.Linear):
         elif torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16):
             hd = torch.get_autocast_dtype("cuda")
         return _SkinnyLinear.apply(x, self.weight, self.bias, self._maps, hd)
+
+    def forward_parts(self, parts):
+        """forward(torch.cat(parts, 1)) without building the concatenation (column blocks of the weight)."""
+        parts = list(parts)
+        ok = (all(x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and
+                  x.shape[1] % 4 == 0 for x in parts) and parts[0].shape[0] >= 4096 and self.out_features % 4 == 0 and
+              sum(x.shape[1] for x in parts) == self.in_features)
+        if not ok:
+            return self.forward(torch.cat(parts, dim=1))
+        if len(self._maps) > 8:
+            self._maps.clear()
+        hd = None
+        if any(x.dtype != torch.float32 for x in parts):
+            hd = next(x.dtype for x in parts if x.dtype != torch.float32)
+        elif torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16):
+            hd = torch.get_autocast_dtype("cuda")
+        return _SkinnyLinearParts.apply(self.weight, self.bias, self._maps, hd, *parts)

@@ -152,6 +152,9 @@ class MinkUNet(nn.Module):
         y3 = self.up3[1](self.up3[0](y2, cat_with=x1))
         y4 = self.up4[1](self.up4[0](y3, cat_with=x0))
         z3 = voxel_to_point(y4, z2)
+        lin = self.classifier[0]
+        if isinstance(lin, FusedLinear) and os.environ.get("PCS_CLASSIFIER_PARTS", "1") != "0":
+            return lin.forward_parts([z1.F, z2.F, z3.F])  # Linear over [z1 | z2 | z3] without the (N, 480) concat
         return self.classifier(torch.cat([z1.F, z2.F, z3.F], dim=1))
 
     def forward(self, batch):

@@ -505,6 +505,36 @@ def test_fused_linear_matches_torch(hip):
     assert torch.allclose(lin(small), ref(small), atol=1e-5)
 
 
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_fused_linear_over_column_blocks(hip, amp):
+    """forward_parts([z1, z2, z3]) == Linear(cat([z1, z2, z3], 1)): values, the three input gradients, dW, db -- the
+    classifier of the workload without the (N, 480) concatenation."""
+    from openpcseg_amd.fused import FusedLinear
+    torch.manual_seed(4)
+    n = 40013
+    lin = FusedLinear(480, 20).to(DEV)
+    ref = torch.nn.Linear(480, 20).to(DEV)
+    ref.load_state_dict(lin.state_dict())
+    parts = [torch.randn(n, c, device=DEV, requires_grad=True) for c in (256, 128, 96)]
+    parts2 = [p.detach().clone().requires_grad_(True) for p in parts]
+    g = torch.randn(n, 20, device=DEV)
+    if amp is None:
+        y, t, tol = lin.forward_parts(parts), ref(torch.cat(parts2, 1)), 2e-5
+    else:
+        with torch.autocast("cuda", dtype=amp):
+            y = lin.forward_parts(parts)
+        t, tol = ref(torch.cat(parts2, 1)), 2e-2
+    assert y.shape == t.shape and (y.float() - t).abs().max() <= tol * t.abs().max()
+    y.backward(g.to(y.dtype))
+    t.backward(g)
+    for a, b in zip(parts, parts2):
+        assert a.grad.is_contiguous() and (a.grad.float() - b.grad).abs().max() <= tol * b.grad.abs().max()
+    assert (lin.weight.grad - ref.weight.grad).abs().max() <= tol * ref.weight.grad.abs().max()
+    assert (lin.bias.grad - ref.bias.grad).abs().max() <= tol * ref.bias.grad.abs().max()
+    few = [torch.randn(64, c, device=DEV) for c in (256, 128, 96)]  # few rows: the plain path over the concatenation
+    assert torch.allclose(lin.forward_parts(few), ref(torch.cat(few, 1)), atol=1e-5)
+
+
 # ---- device-side sparse_quantize (SURVEY 8 f1) ---------------------------------------------------------
 @pytest.mark.parametrize("case", ["scan", "aniso", "ints"])
 def test_device_sparse_quantize_matches_reference_golden(hip, case):
