@@ -197,3 +197,24 @@ def test_minkunet_e2e_matches_reference_logits(golden_e2e, oracle_backend):
 
 
 # the reference's own MinkUNet source on this API: tests/test_reference_models.py (CPU oracle and, under -m gpu, HIP)
+
+
+def test_batched_lovasz_equals_the_per_class_loop():
+    """workloads/losses.py: the (C', n)-batched Lovasz-softmax == the reference's per-class loop
+    (R:tools/utils/common/lovasz_losses.py:176-204, classes='present'), value and gradient, with an ignored label
+    and an absent class."""
+    import torch
+    from openpcseg_amd.workloads.losses import lovasz_softmax, lovasz_softmax_per_class
+    torch.manual_seed(0)
+    for n in (1, 7, 5000):
+        logits = torch.randn(n, 20, requires_grad=True)
+        lab = torch.randint(0, 20, (n,))
+        if n > 7:
+            lab[lab == 7] = 3
+        p = logits.softmax(1)
+        a, b = lovasz_softmax(p, lab, ignore=0), lovasz_softmax_per_class(p, lab, ignore=0)
+        ga, = torch.autograd.grad(a, logits, retain_graph=True)
+        gb, = torch.autograd.grad(b, logits)
+        assert abs(float(a.detach()) - float(b.detach())) <= 1e-6 and (ga - gb).abs().max() <= 1e-7
+    empty = torch.zeros(4, 20).softmax(1)
+    assert float(lovasz_softmax(empty, torch.zeros(4, dtype=torch.long), ignore=0)) == 0.0
