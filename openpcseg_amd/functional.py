@@ -212,6 +212,7 @@ class _SparseConv(Function):
                 out = out.to(hd)
                 got = [] if want_stats else None  # statistics of the fp32 values, not of the rounded ones: not used
         ctx.for_backwards = (x, weight, entry, transposed, hd)
+        ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the statistics vector on every backward
         if not want_stats:
             return out
         sums = got[0] if got else torch.empty(0, dtype=torch.float64, device=out.device)
@@ -220,6 +221,8 @@ class _SparseConv(Function):
 
     @staticmethod
     def backward(ctx, grad_output, *_unused):
+        if grad_output is None:
+            return None, None, None, None, None
         be = _be()
         x, weight, entry, transposed, hd = ctx.for_backwards
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)

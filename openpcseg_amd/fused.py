@@ -64,9 +64,13 @@ class _FusedBN(Function):
         res = res.contiguous() if res is not None else None
         n, c = x.shape
         # [sum x | sum x^2 | n]: handed over by the producing convolution (its write-back computed them), else one pass
-        sums = pre.clone() if pre is not None and pre.numel() == 2 * c + 1 else be.bn_stats(x)
+        syncing = sync and _world() > 1
+        if pre is not None and pre.numel() == 2 * c + 1:
+            sums = pre.clone() if syncing else pre  # the all-reduce below works in place
+        else:
+            sums = be.bn_stats(x)
         count, count_dev = float(n), None
-        if sync and _world() > 1:
+        if syncing:
             # ONE collective per layer and direction: the row count rides in the statistics vector and the global
             # count stays on the device (finalize / bwd_apply read it there) -- no count all-reduce, no host sync
             dist.all_reduce(sums, group=_stats_group())
@@ -100,8 +104,10 @@ class _FusedBN(Function):
             sums2 = local.clone()
             dist.all_reduce(sums2, group=_stats_group())
         dx, dres = be.bn_bwd_apply(dy, x, gate, stat, sums2, count, weight, relu, has_res, count_dev=count_dev)
-        dw = local[c:].to(weight.dtype) if weight is not None else None   # local sums: DDP averages parameter grads
-        db = local[:c].to(weight.dtype) if weight is not None else None
+        dw = db = None
+        if weight is not None:  # local sums: DDP averages parameter grads; one cast for both halves
+            lw = local.to(weight.dtype)
+            dw, db = lw[c:], lw[:c]
         return dx, dres, dw, db, None, None, None, None, None, None, None, None, None, dtail
 
 
@@ -117,6 +123,7 @@ class FusedBatchNorm(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.counted_by_parent = False
 
     def extra_repr(self):
         return "%d, eps=%g, momentum=%g, sync=%s" % (self.num_features, self.eps, self.momentum, self.sync)
@@ -128,7 +135,8 @@ class FusedBatchNorm(nn.Module):
         r = residual.feats if isinstance(residual, SparseTensor) else residual
         tail = cat_with.feats if isinstance(cat_with, SparseTensor) else cat_with
         if self.training:
-            self.num_batches_tracked += 1
+            if not self.counted_by_parent:  # a model may bump all its counters with one _foreach_add_ per step
+                self.num_batches_tracked += 1
             y = _FusedBN.apply(x, r, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                self.momentum, relu, self.sync, input.cmaps, input.stride, getattr(input, "bn_sums", None),
                                tail)
@@ -202,9 +210,11 @@ class _SkinnyLinearParts(Function):
             cin = x.shape[1]
             w1 = wt[col:col + cin].unsqueeze(0)  # (1, cin, out): a contiguous row block
             b = bias.float() if (bias is not None and i == 0) else None
-            if hd is not None and be.conv_h_applies(cin, w1.shape[2], 1):
-                x = x.contiguous().to(hd)
-                t = be.conv_gather_gemm_h(x, be.prepare_weights_h(w1.contiguous(), hd, transpose=False), 1, w1.shape[2], km, b).float()
+            # a part that ARRIVES in half runs on the 16-bit kernel; an fp32 part stays fp32 even under autocast: the
+            # pass is HBM-bound, and casting first (read 4 + write 2 + read 2 bytes per element) costs twice the fp32 read
+            if x.dtype != torch.float32 and be.conv_h_applies(cin, w1.shape[2], 1):
+                x = x.contiguous()
+                t = be.conv_gather_gemm_h(x, be.prepare_weights_h(w1.contiguous(), x.dtype, transpose=False), 1, w1.shape[2], km, b).float()
             else:
                 x = x.contiguous().float()
                 t = be.conv_gather_gemm(x, w1.contiguous(), km, b)

@@ -128,6 +128,10 @@ class MinkUNet(nn.Module):
         self.classifier = nn.Sequential((FusedLinear if FUSED else nn.Linear)(cs[4] + cs[6] + cs[8], num_class))
         self.dropout = nn.Dropout(dropout, True)
         self.criterion = SegLoss(ignore_index=ignore_label, label_smoothing=label_smoothing)
+        # num_batches_tracked of the 63 BatchNorm layers: one _foreach_add_ per training step instead of 63 scalar kernels
+        self._bn_layers = [m for m in self.modules() if isinstance(m, FusedBatchNorm)]
+        for m in self._bn_layers:
+            m.counted_by_parent = True
 
     def _stem(self, x):
         h = _bn_act(self.stem[1], self.stem[0](x), act=self.stem[2])
@@ -135,6 +139,8 @@ class MinkUNet(nn.Module):
 
     def point_logits(self, x):
         """x: SparseTensor (feats (N,>=in_dim), coords (N,4) int) -> per-point logits (N, num_class)."""
+        if self.training and self._bn_layers:
+            torch._foreach_add_([m.num_batches_tracked for m in self._bn_layers], 1)
         x.F = x.F[:, :self.in_dim]
         z = PointTensor(x.F, x.C.float())
         x0 = self._stem(initial_voxelize(z, self.pres, self.vres))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Which Python call sites launch the torch (non-library) kernels of one training step: torch.profiler with stacks,
-device time per (kernel, innermost openpcseg_amd / bench frame). Usage: python tools/step_op_profile.py [bf16|fp16]"""
+"""Which torch ops (outside the C-ABI library) cost device time in one training step: torch.profiler, self device time
+per (aten op, input shapes). Usage: python tools/step_op_profile.py [bf16|fp16]"""
 import collections
 import os
 import sys
@@ -36,29 +36,24 @@ def main():
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
         step()
         torch.cuda.synchronize()
     agg = collections.defaultdict(lambda: [0.0, 0])
-    for ev in prof.key_averages(group_by_stack_n=12):
+    for ev in prof.key_averages(group_by_input_shape=True):
         dt = getattr(ev, "self_device_time_total", None)
         if dt is None:
             dt = getattr(ev, "self_cuda_time_total", 0)
         if not dt or not ev.key.startswith("aten::"):
             continue
-        site = "?"
-        for fr in ev.stack or []:
-            if ("openpcseg_amd" in fr or "bench.py" in fr or "step_op_profile" in fr) and "torch/" not in fr:
-                site = fr.strip().split("/")[-1]
-                break
-        a = agg[(ev.key, site)]
+        a = agg[(ev.key, str(ev.input_shapes)[:110])]
         a[0] += dt
         a[1] += ev.count
     rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
     tot = sum(v[0] for _, v in rows)
     print("aten ops, self device time: %.2f ms in one step" % (tot / 1e3))
-    for (name, site), (us, n) in rows[:50]:
-        print("%8.3f ms %5d  %-28s %s" % (us / 1e3, n, name, site))
+    for (name, shp), (us, n) in rows[:70]:
+        print("%8.3f ms %5d  %-24s %s" % (us / 1e3, n, name, shp))
 
 
 if __name__ == "__main__":
