@@ -199,7 +199,7 @@ int pcs_rulebook_tile_order(const int32_t *seg, int32_t K, int64_t ntiles, int32
  *   src (n_src, cin), W (K, cin, cout), dst (n_dst, cout); pairs (P,2) with the src row in
  *   column src_col and the dst row in column 1-src_col, sorted k-major / dst ascending;
  *   seg from pcs_rulebook_tile_segments with the same tile_rows; bias (cout) or NULL.
- *   tile_rows: a multiple of 16 in [16, 512]; shapes outside the 16-byte-granular, cin >= 64 kernel
+ *   tile_rows: a multiple of 16 in [16, 512]; shapes outside the 16-byte-granular, cin % 32 == 0 kernel
  *   take 64 or 128 only (PCS_EUNSUPPORTED otherwise).
  * pcs_conv_tile_rows returns the default tile height for (cin, cout); pcs_conv_pick_tile_rows the
  * height for one layer call: with few dst rows (deep strides) the launch is only a few waves of
@@ -216,7 +216,7 @@ int32_t pcs_conv_pick_tile_rows_dt(int64_t n_dst, int64_t n_pairs, int32_t K, in
  *   pcs_bn_reduce_partials turns them into the `sums` vector of pcs_bn_finalize_f32. Only for shapes / tile heights
  *   with pcs_conv_emits_bn_partials(...) != 0 (PCS_EUNSUPPORTED otherwise).
  *   tile_order (may be NULL): ceil(n_dst / tile_rows) int32 from pcs_rulebook_tile_order for the same seg; NULL =
- *   tiles in row order (XCD-contiguous ranges). Only the wave kernels (16-byte-granular shapes, cin >= 64; every
+ *   tiles in row order (XCD-contiguous ranges). Only the wave kernels (16-byte-granular shapes, cin % 32 == 0; every
  *   shape of the half kernels) use it.
  */
 int32_t pcs_conv_emits_bn_partials(int32_t cin, int32_t cout, int32_t K, int32_t tile_rows, int32_t dtype);

@@ -76,9 +76,10 @@ inline int conv5_nctt(int cout, int tile_rows) {
   if (cout >= 192 && tile_rows >= 192) return 4;
   return conv_nctt(cout);
 }
-// wave5 serves 16-byte-granular shapes with a contraction of at least two 32-channel steps and an even column tile
+// wave5 serves 16-byte-granular shapes with a 32-channel contraction granule and an even column tile (32-channel
+// layers too since round 2: 32->32 at stride 2 155 -> 131 us against the one-row-block-per-step wave4 kernel)
 inline bool conv5_applies(int cin, int cout, int K) {
-  return cin % 32 == 0 && cin >= 64 && cout % 4 == 0 && K <= 32 && conv_nctt(cout) % 2 == 0;
+  return cin % 32 == 0 && cin >= 32 && cout % 4 == 0 && K <= 32 && conv_nctt(cout) % 2 == 0;
 }
 
 // the half-precision wave kernel (conv_wave5h.hip) steps 32 channels per MFMA and needs no second pipeline stage:

@@ -268,16 +268,17 @@ def test_conv_tile_pick_and_errors(hip, golden):
     assert lib.pcs_conv_pick_tile_rows(36068, 331722, 27, 256, 256) == 288
     assert lib.pcs_conv_pick_tile_rows(113008, 1001308, 27, 128, 128) == 224
     assert lib.pcs_conv_pick_tile_rows(113008, 1001308, 27, 256, 256) == 256
-    assert lib.pcs_conv_pick_tile_rows(36068, 331722, 27, 32, 32) == 128  # not the cin >= 64 kernel
+    assert lib.pcs_conv_pick_tile_rows(688382, 3790760, 27, 32, 32) in (224, 256, 288)  # 32-channel layers: the same kernel
+    assert lib.pcs_conv_pick_tile_rows(36068, 331722, 27, 16, 32) == 128  # cin % 32 != 0: not the row-block-group kernel
     assert lib.pcs_conv_pick_tile_rows_dt(1158864, 5112372, 27, 96, 96, 0) == 384
     assert lib.pcs_conv_pick_tile_rows_dt(1158864, 5112372, 27, 96, 96, 1) == 192
     assert lib.pcs_conv_pick_tile_rows_dt(329421, 2752033, 27, 128, 128, 1) == 144
     assert lib.pcs_conv_pick_tile_rows_dt(113008, 1001308, 27, 128, 128, 2) == 112
     assert lib.pcs_conv_pick_tile_rows_dt(36068, 331722, 27, 256, 256, 1) == 288
     entry, _, n_in, _ = _scene_maps(hip, golden, "k3s1")
-    x = torch.zeros((n_in, 32), device="cuda")
-    w = torch.zeros((27, 32, 32), device="cuda")
-    for bad in (8, 24, 1024, 144):  # 144 is legal only for the cin >= 64 kernel
+    x = torch.zeros((n_in, 16), device="cuda")
+    w = torch.zeros((27, 16, 32), device="cuda")
+    for bad in (8, 24, 1024, 144):  # 144 is legal only for the row-block-group kernel (cin % 32 == 0)
         with pytest.raises(RuntimeError):
             hip.conv_gather_gemm(x, w, entry.fwd, tile_rows=bad)
 
