@@ -212,7 +212,6 @@ __global__ void __launch_bounds__(1024) rb_tile_order_kernel(const int32_t *__re
                                                              int32_t *__restrict__ order) {
   __shared__ int hist[kOrderBins];
   __shared__ int base[kOrderBins];
-  __shared__ int carry;
   const int tid = threadIdx.x;
   const int64_t nt1 = ntiles + 1;
   auto work_of = [&](int64_t t) {
@@ -224,7 +223,6 @@ __global__ void __launch_bounds__(1024) rb_tile_order_kernel(const int32_t *__re
     return w < kOrderBins - 1 ? w : kOrderBins - 1;
   };
   for (int i = tid; i < kOrderBins; i += 1024) hist[i] = 0;
-  if (tid == 0) carry = 0;
   __syncthreads();
   for (int64_t t = tid; t < ntiles; t += 1024) atomicAdd(&hist[work_of(t)], 1);
   __syncthreads();

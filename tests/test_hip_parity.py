@@ -185,6 +185,29 @@ def _scene_maps(hip, golden, which):
         (golden["kmap_k2s2_nbmaps"], golden["kmap_k2s2_nbsizes"]), inc.shape[0], outc.shape[0]
 
 
+@pytest.mark.parametrize("n", [1, 17, 40])
+def test_conv_on_tiny_maps_with_tile_order(hip, n):
+    """A handful of voxels: one (partly filled) row tile, a tile order of one entry, most offsets empty -- every wave
+    kernel (fp32 32 / 64 / 128 / 256 columns, half) against the oracle."""
+    from openpcseg_amd import functional as F
+    rng = np.random.default_rng(n)
+    cube = np.stack(np.meshgrid(np.arange(4), np.arange(4), np.arange(3), indexing="ij"), -1).reshape(-1, 3)
+    c = np.concatenate([cube[rng.permutation(len(cube))[:n]], np.zeros((n, 1), np.int64)], 1).astype(np.int32)
+    entry = F.build_kernel_map(t(c), t(c), (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    nbmaps, nbsizes = orc.build_kmap(c, c, 3)
+    assert np.array_equal(entry[0].cpu().numpy().astype(np.int64), nbmaps)
+    assert hip._tile_order(entry.fwd, 128).cpu().tolist() == [0]
+    for cin, cout in ((32, 32), (64, 64), (96, 128), (128, 256)):
+        x = rng.normal(size=(n, cin)).astype(np.float32)
+        w = (rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32)
+        ref = orc.conv_fwd(x, w, nbmaps, nbsizes, (n, n))
+        close(hip.conv_gather_gemm(t(x), t(w), entry.fwd), ref, 2e-5)
+        close(hip.conv_gather_gemm(t(x), t(w), entry.fwd, tile_rows=256), ref, 2e-5)
+        xh, wp = t(x).bfloat16(), hip.prepare_weights_h(t(w), torch.bfloat16, transpose=False)
+        refh = orc.conv_fwd(xh.float().cpu().numpy(), t(w).bfloat16().float().cpu().numpy(), nbmaps, nbsizes, (n, n))
+        close(hip.conv_gather_gemm_h(xh, wp, 27, cout, entry.fwd).float(), refh, 1e-2)
+
+
 @pytest.mark.parametrize("cin,cout", [(4, 32), (32, 32), (32, 64), (96, 96), (128, 96), (192, 128), (256, 256),
                                       (384, 256), (64, 20), (5, 33), (56, 112)])
 @pytest.mark.parametrize("tile", [64, 128])
