@@ -321,7 +321,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    # PCS_BENCH_FORCE_DIST=1 (test rig): the distributed code path (process group, DDP, sync BatchNorm, barrier,
+    # max-over-ranks) even for one rank, so that it runs over RCCL on a single-GPU box
+    distributed = world > 1 or os.environ.get("PCS_BENCH_FORCE_DIST") == "1"
     # PCS_BENCH_ONE_DEVICE=1 (test rigs with a single GPU): every rank uses cuda:0 and gloo carries the
     # collectives, to exercise the N > 1 code path; real runs use one GPU per rank and RCCL.
     one_dev = os.environ.get("PCS_BENCH_ONE_DEVICE") == "1"

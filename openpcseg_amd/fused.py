@@ -18,6 +18,16 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _syncing(sync):
+    """True when a sync-mode layer must exchange its statistics. PCS_SYNC_WORLD1=1 (test rig): also in a one-rank process
+    group, so that the whole collective path -- dedicated communicator, all-reduce, device-resident count -- runs over
+    RCCL on a box with a single GPU."""
+    if not sync or not (dist.is_available() and dist.is_initialized()):
+        return False
+    import os
+    return dist.get_world_size() > 1 or os.environ.get("PCS_SYNC_WORLD1") == "1"
+
+
 _STATS_GROUP = {}
 
 
@@ -64,7 +74,7 @@ class _FusedBN(Function):
         res = res.contiguous() if res is not None else None
         n, c = x.shape
         # [sum x | sum x^2 | n]: handed over by the producing convolution (its write-back computed them), else one pass
-        syncing = sync and _world() > 1
+        syncing = _syncing(sync)
         if pre is not None and pre.numel() == 2 * c + 1:
             sums = pre.clone() if syncing else pre  # the all-reduce below works in place
         else:
@@ -100,7 +110,7 @@ class _FusedBN(Function):
             dy = dy.contiguous()
         local = be.bn_bwd_stats(dy, x, gate, stat, relu)
         sums2 = local
-        if sync and _world() > 1:
+        if _syncing(sync):
             sums2 = local.clone()
             dist.all_reduce(sums2, group=_stats_group())
         dx, dres = be.bn_bwd_apply(dy, x, gate, stat, sums2, count, weight, relu, has_res, count_dev=count_dev)

@@ -159,6 +159,33 @@ def test_bench_two_ranks_on_one_device():
     assert res["roofline"]["launches"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_one_rank_over_rccl():
+    """The distributed path of bench.py over RCCL (backend "nccl") on ONE MI355X: a one-rank job launched like the driver
+    launches its ranks, forced through init_process_group("nccl"), DDP, FusedBatchNorm(sync=True) with its statistics
+    all-reduce on the dedicated high-priority communicator (PCS_SYNC_WORLD1), barrier and the max-over-ranks all-reduce.
+    The same frames without the process group must give the same loss."""
+    import json
+    import subprocess
+
+    def run(env_extra, launcher):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", PCS_BENCH_PREHEAT="0", **env_extra)  # same number of optimizer steps
+        cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--frames-per-gpu", "2",
+                          "--no-cpu-baseline"]
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        return json.loads(lines[0])
+
+    rccl = run({"PCS_BENCH_FORCE_DIST": "1", "PCS_SYNC_WORLD1": "1"},
+               [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())])
+    plain = run({}, [sys.executable])
+    assert rccl["n_gpus"] == 1 and rccl["value"] > 0 and rccl["roofline"]["launches"] > 0
+    assert abs(rccl["config"]["loss"] - plain["config"]["loss"]) <= 2e-3 * abs(plain["config"]["loss"])
+
+
 def _nccl_bn_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
