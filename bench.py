@@ -124,6 +124,7 @@ class ClockSampler:
     def __init__(self, dev_index, period_s=0.1):
         import threading
         self.period, self.samples, self.src = period_s, [], None
+        self.xcd_min, self.hotspot, self._throttle, self._thr0 = [], [], None, {}
         self._stop = threading.Event()
         self._read = self._probe(dev_index)
         self._thr = threading.Thread(target=self._run, daemon=True) if self._read else None
@@ -135,15 +136,35 @@ class ClockSampler:
             h = amdsmi.amdsmi_get_processor_handles()[dev_index]
             ct = getattr(amdsmi.AmdSmiClkType, "GFX", None) or amdsmi.AmdSmiClkType.SYS
 
+            def metrics():
+                try:
+                    return amdsmi.amdsmi_get_gpu_metrics_info(h)
+                except Exception:
+                    return {}
+
             def read():
                 clk = amdsmi.amdsmi_get_clock_info(h, ct).get("clk")
                 pw = amdsmi.amdsmi_get_power_info(h)
                 p = pw.get("current_socket_power")
                 if not isinstance(p, (int, float)):
                     p = pw.get("average_socket_power")
+                m = metrics()
+                xcd = [float(v) for v in (m.get("current_gfxclks") or []) if isinstance(v, (int, float)) and v > 0]
+                if xcd:  # the slowest XCD bounds a launch that spans all eight
+                    self.xcd_min.append(min(xcd))
+                t = m.get("temperature_hotspot")
+                if isinstance(t, (int, float)):
+                    self.hotspot.append(float(t))
                 return (float(clk) if isinstance(clk, (int, float)) else None,
                         float(p) if isinstance(p, (int, float)) else None)
+
+            def throttle():
+                m = metrics()
+                return {k: m[k] for k in ("ppt_residency_acc", "prochot_residency_acc", "socket_thm_residency_acc",
+                                          "vr_thm_residency_acc", "hbm_thm_residency_acc", "energy_accumulator")
+                        if isinstance(m.get(k), (int, float))}
             read()
+            self._throttle = throttle
             self.src = "amdsmi"
             return read
         except Exception:
@@ -173,6 +194,12 @@ class ClockSampler:
             self._stop.wait(self.period)
 
     def __enter__(self):
+        if self._throttle:
+            self.xcd_min, self.hotspot = [], []
+            try:
+                self._thr0 = self._throttle()
+            except Exception:
+                self._thr0 = {}
         if self._thr:
             self._thr.start()
         return self
@@ -191,6 +218,18 @@ class ClockSampler:
                "samples": len(clk), "source": self.src}
         if pw:
             out["socket_power_w_mean"] = round(sum(pw) / len(pw), 1)
+        if self.xcd_min:
+            out["slowest_xcd_mhz_mean"] = round(sum(self.xcd_min) / len(self.xcd_min), 1)
+            out["slowest_xcd_mhz_min"] = min(self.xcd_min)
+        if self.hotspot:
+            out["hotspot_c_max"] = max(self.hotspot)
+        if self._throttle and self._thr0:
+            try:  # throttler residency counters over the timed region (power / thermal limits acting on the clocks)
+                t1 = self._throttle()
+                out["throttle_residency_delta"] = {k.replace("_residency_acc", ""): t1[k] - self._thr0[k]
+                                                   for k in t1 if k in self._thr0 and k != "energy_accumulator"}
+            except Exception:
+                pass
         return out
 
 

@@ -710,7 +710,8 @@ int wgrad_plan(const int32_t *koff_host, int K, int ca, int cb, int *pch_out) {
   int64_t P = koff_host[K] - koff_host[0];
   // measured per shape (tools/conv_microbench.py): ~3072 workgroups when an offset's weight block needs >= 4 of them
   // (256-channel layers), ~1536 otherwise (64..128 channels: +2..16 %; fewer, longer splits = less partial traffic)
-  int64_t target = (nbq >= 4 ? 3072 : 1536) / nbq;
+  static const int tgt_env = getenv("PCS_WGRAD_TARGET") ? atoi(getenv("PCS_WGRAD_TARGET")) : 0;  // debug: workgroups per launch
+  int64_t target = (tgt_env > 0 ? tgt_env : (nbq >= 4 ? 3072 : 1536)) / nbq;
   if (target < K) target = K;
   int pch = (int)ceil_div(P > 0 ? P : 1, target);
   pch = (int)(ceil_div(pch, 32) * 32);
