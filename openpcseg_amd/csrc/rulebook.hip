@@ -205,26 +205,44 @@ __global__ void __launch_bounds__(256) rb_segments_kernel(const int32_t *__restr
 }
 
 // Heaviest-first order of the row tiles of one segment table: work(t) = 16-row blocks of tile t over all offsets (what
-// the fused convolution issues MFMAs for). One workgroup: histogram of the work values, descending prefix, scatter.
-// The order among equally heavy tiles is arbitrary -- it only decides which workgroup slot runs which tile, never a sum.
-constexpr int kOrderBins = 2048;  // work <= K * (tile_rows / 16 + 1) <= 32 * 33
+// the fused convolution issues MFMAs for). One workgroup: per-tile work (coalesced over the tiles of one offset, summed
+// with LDS atomics), histogram of the work values, descending prefix, scatter. The order among equally heavy tiles is
+// arbitrary -- it only decides which workgroup slot runs which tile, never a sum.
+constexpr int kOrderBins = 2048;    // work <= K * (tile_rows / 16 + 1) <= 32 * 33
+constexpr int kOrderTiles = 12288;  // tiles whose work fits the LDS (48 KB); more: the work is recomputed per pass
 __global__ void __launch_bounds__(1024) rb_tile_order_kernel(const int32_t *__restrict__ seg, int K, int64_t ntiles,
                                                              int32_t *__restrict__ order) {
   __shared__ int hist[kOrderBins];
   __shared__ int base[kOrderBins];
+  __shared__ int work_l[kOrderTiles];
+  __shared__ int wsum[16];
   const int tid = threadIdx.x;
   const int64_t nt1 = ntiles + 1;
-  auto work_of = [&](int64_t t) {
+  const bool in_lds = ntiles <= kOrderTiles;
+  auto clampw = [](int w) { return w < kOrderBins - 1 ? w : kOrderBins - 1; };
+  auto work_of = [&](int64_t t) {  // the slow way (one thread walks the offsets of a tile)
     int w = 0;
     for (int k = 0; k < K; ++k) {
       const int64_t o = (int64_t)k * nt1 + t;
       w += (seg[o + 1] - seg[o] + 15) >> 4;
     }
-    return w < kOrderBins - 1 ? w : kOrderBins - 1;
+    return clampw(w);
   };
   for (int i = tid; i < kOrderBins; i += 1024) hist[i] = 0;
+  if (in_lds) {
+    for (int i = tid; i < (int)ntiles; i += 1024) work_l[i] = 0;
+    __syncthreads();
+    const int64_t total = (int64_t)K * ntiles;
+    for (int64_t e = tid; e < total; e += 1024) {  // consecutive threads: consecutive tiles of one offset
+      const int k = (int)(e / ntiles);
+      const int t = (int)(e - (int64_t)k * ntiles);
+      const int64_t o = (int64_t)k * nt1 + t;
+      const int nb = (seg[o + 1] - seg[o] + 15) >> 4;
+      if (nb) atomicAdd(&work_l[t], nb);
+    }
+  }
   __syncthreads();
-  for (int64_t t = tid; t < ntiles; t += 1024) atomicAdd(&hist[work_of(t)], 1);
+  for (int64_t t = tid; t < ntiles; t += 1024) atomicAdd(&hist[in_lds ? clampw(work_l[t]) : work_of(t)], 1);
   __syncthreads();
   // base[w] = number of tiles heavier than w: two bins per thread, scanned from the heavy end
   {
@@ -236,7 +254,6 @@ __global__ void __launch_bounds__(1024) rb_tile_order_kernel(const int32_t *__re
       const int v = __shfl_up(incl, o, 64);
       if (lane >= o) incl += v;
     }
-    __shared__ int wsum[16];
     if (lane == 63) wsum[wid] = incl;
     __syncthreads();
     int off = 0;
@@ -246,7 +263,8 @@ __global__ void __launch_bounds__(1024) rb_tile_order_kernel(const int32_t *__re
     base[b1] = excl + h0;
   }
   __syncthreads();
-  for (int64_t t = tid; t < ntiles; t += 1024) order[atomicAdd(&base[work_of(t)], 1)] = (int32_t)t;
+  for (int64_t t = tid; t < ntiles; t += 1024)
+    order[atomicAdd(&base[in_lds ? clampw(work_l[t]) : work_of(t)], 1)] = (int32_t)t;
 }
 
 struct RbWs {

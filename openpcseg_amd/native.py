@@ -500,6 +500,13 @@ class HipBackend:
             kmap._seg[tile_rows] = seg
         return seg
 
+    @staticmethod
+    def _wants_order(kmap):
+        """The heaviest-first order pays where workgroups are long and few: the dense levels (>= 6 pairs per row:
+        +2..6 % per launch); on the sparse full-resolution levels it is worth < 1 % and its own kernel (one workgroup
+        over 3000-9000 tiles) costs as much, so those launches keep the row order."""
+        return kmap.n_dst > 0 and kmap.num_pairs_estimate() >= 6.0 * kmap.n_dst
+
     def _tile_order(self, kmap, tile_rows):
         """Heaviest-first order of the row tiles of (kmap, tile_rows), cached beside the segment table it is made from
         (one small kernel per map and tile height, shared by every layer, forward and backward, that uses the map)."""
@@ -534,7 +541,8 @@ class HipBackend:
     def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True):
         """dst[d] = sum_{(s,d) in offset k} src[s] @ weight[k] (+bias); kmap dst-sorted. bn_sums: a list; when the
         kernel can, the [sum x | sum x^2 | n] vector of dst (what bn_stats(dst) returns) is appended to it, computed in
-        the convolution's write-back instead of by a pass over dst."""
+        the convolution's write-back instead of by a pass over dst. ordered: True = heaviest-first tile order where it
+        pays (_wants_order), "force" = always, False = row order; results never depend on it."""
         src = _dev(src, "input", torch.float32)
         weight = _dev(weight, "weight", torch.float32)
         k, cin, cout = weight.shape
@@ -548,7 +556,7 @@ class HipBackend:
         seg = self._segments(kmap, t)
         dst = torch.empty((kmap.n_dst, cout), dtype=torch.float32, device=src.device)
         part = self._bn_partial(kmap, t, cin, cout, k, 0, bn_sums, src.device)
-        order = self._tile_order(kmap, t) if ordered and kmap.n_dst > 0 and self.lib.pcs_conv_uses_tile_order(cin, cout, k, 0) else None
+        order = self._tile_order(kmap, t) if (ordered == "force" or (ordered and self._wants_order(kmap))) and kmap.n_dst > 0 and self.lib.pcs_conv_uses_tile_order(cin, cout, k, 0) else None
         _check(self.lib.pcs_conv_gather_gemm_f32(_ptr(src), src.shape[0], cin, _ptr(weight), k, cout,
                                                  _ptr(kmap._pairs_raw), 0, _ptr(seg), t, kmap.n_dst,
                                                  _ptr(bias) if bias is not None else None, _ptr(dst),
@@ -593,7 +601,7 @@ class HipBackend:
         seg = self._segments(kmap, t)
         dst = torch.empty((kmap.n_dst, cout), dtype=src.dtype, device=src.device)
         part = self._bn_partial(kmap, t, cin, cout, k, self._HALF[src.dtype], bn_sums, src.device)
-        order = self._tile_order(kmap, t) if ordered and kmap.n_dst > 0 else None
+        order = self._tile_order(kmap, t) if (ordered == "force" or (ordered and self._wants_order(kmap))) and kmap.n_dst > 0 else None
         _check(self.lib.pcs_conv_gather_gemm_h(_ptr(src), src.shape[0], cin, _ptr(wp), k, cout, _ptr(kmap._pairs_raw), 0,
                                                _ptr(seg), t, kmap.n_dst, _ptr(bias) if bias is not None else None,
                                                _ptr(dst), self._HALF[src.dtype], _ptr(part) if part is not None else None,

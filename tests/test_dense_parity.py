@@ -123,12 +123,12 @@ def test_conv_is_independent_of_the_tile_order(hip, levels, stride, cin, cout, t
     x = torch.randn(n, cin, device=DEV)
     w = torch.randn(27, cin, cout, device=DEV) * 0.05
     a, b = [], []
-    ya = hip.conv_gather_gemm(x, w, entry.fwd, tile_rows=tile, bn_sums=a, ordered=True)
+    ya = hip.conv_gather_gemm(x, w, entry.fwd, tile_rows=tile, bn_sums=a, ordered="force")
     yb = hip.conv_gather_gemm(x, w, entry.fwd, tile_rows=tile, bn_sums=b, ordered=False)
     assert torch.equal(ya, yb) and len(a) == len(b) and all(torch.equal(p, q) for p, q in zip(a, b))
     for dtype in (torch.bfloat16, torch.float16):
         xh, wp = x.to(dtype), hip.prepare_weights_h(w, dtype, transpose=False)
-        assert torch.equal(hip.conv_gather_gemm_h(xh, wp, 27, cout, entry.fwd, tile_rows=tile, ordered=True),
+        assert torch.equal(hip.conv_gather_gemm_h(xh, wp, 27, cout, entry.fwd, tile_rows=tile, ordered="force"),
                            hip.conv_gather_gemm_h(xh, wp, 27, cout, entry.fwd, tile_rows=tile, ordered=False))
 
 

@@ -201,11 +201,11 @@ def test_conv_on_tiny_maps_with_tile_order(hip, n):
         x = rng.normal(size=(n, cin)).astype(np.float32)
         w = (rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32)
         ref = orc.conv_fwd(x, w, nbmaps, nbsizes, (n, n))
-        close(hip.conv_gather_gemm(t(x), t(w), entry.fwd), ref, 2e-5)
+        close(hip.conv_gather_gemm(t(x), t(w), entry.fwd, ordered="force"), ref, 2e-5)
         close(hip.conv_gather_gemm(t(x), t(w), entry.fwd, tile_rows=256), ref, 2e-5)
         xh, wp = t(x).bfloat16(), hip.prepare_weights_h(t(w), torch.bfloat16, transpose=False)
         refh = orc.conv_fwd(xh.float().cpu().numpy(), t(w).bfloat16().float().cpu().numpy(), nbmaps, nbsizes, (n, n))
-        close(hip.conv_gather_gemm_h(xh, wp, 27, cout, entry.fwd).float(), refh, 1e-2)
+        close(hip.conv_gather_gemm_h(xh, wp, 27, cout, entry.fwd, ordered="force").float(), refh, 1e-2)
 
 
 @pytest.mark.parametrize("cin,cout", [(4, 32), (32, 32), (32, 64), (96, 96), (128, 96), (192, 128), (256, 256),
