@@ -167,7 +167,10 @@ int pcs_downsample_unpack(const int64_t *keys, int64_t m, int32_t *coords, void 
 size_t pcs_rulebook_ws_bytes(int64_t nq, int32_t K);
 int pcs_rulebook_probe(const int32_t *qcoords, int64_t nq, const int32_t *offsets, int32_t K,
                        const void *table, int64_t capacity, int32_t *results,
-                       int64_t *nbsizes, void *ws, size_t ws_bytes, void *stream);
+                       int64_t *nbsizes, void *ws, size_t ws_bytes, int32_t symmetric, void *stream);
+/* symmetric != 0: the caller guarantees a submanifold map -- qcoords are the rows the table was built over, K is odd
+ * and offsets[K-1-k] == -offsets[k]. Only the first K/2 offsets are probed; a hit (j + offsets[k] -> i) is also
+ * recorded as (i + offsets[K-1-k] -> j) and the centre offset is the identity. Same results, half the probes. */
 int pcs_rulebook_fill(const int32_t *results, int64_t nq, int32_t K, const void *ws,
                       int32_t *pairs, int32_t *koff, void *stream);
 /* Per (k, tile) segment table for the output-stationary convolution: for tile t of

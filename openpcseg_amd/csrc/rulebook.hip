@@ -71,24 +71,37 @@ __global__ void __launch_bounds__(256) ds_unpack_kernel(const int64_t *__restric
 
 // ---------------------------------------------------------------------------------------------
 // pass 1: probe. grid (nblk, K). Each block covers kRowsPerBlock consecutive query rows.
+// SYM: submanifold map (query coordinates == table coordinates, offsets[K-1-k] == -offsets[k], K odd). A hit
+// (row j + offsets[k] -> row i) IS the hit (row i + offsets[K-1-k] -> row j), and the centre offset is the identity: only
+// the first K/2 offsets are probed (grid.y = K/2 + 1), the mirrored half of the hit matrix is scattered (its rows
+// pre-filled with -1) and its block counts are taken by a streaming pass over it (rb_count_kernel) -- half the random
+// table probes, which are what this kernel costs (1.9 ms per training step at 2 TB/s of sectors).
+template <bool SYM>
 __global__ void __launch_bounds__(256) rb_probe_kernel(const int4 *__restrict__ q, int64_t nq,
                                                        const int32_t *__restrict__ offsets,
                                                        TableView tab,
                                                        int32_t *__restrict__ results,
-                                                       int32_t *__restrict__ blockcnt) {
+                                                       int32_t *__restrict__ blockcnt, int K) {
   const int k = blockIdx.y;
   const int ox = offsets[3 * k], oy = offsets[3 * k + 1], oz = offsets[3 * k + 2];
   const int64_t base = (int64_t)blockIdx.x * kRowsPerBlock;
   int32_t *res = results + (int64_t)k * nq;
+  const bool centre = SYM && k == K / 2;
+  int32_t *mres = results + (int64_t)(K - 1 - k) * nq;           // SYM: row K-1-k of the hit matrix
   int hits = 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t j = base + r * 256 + threadIdx.x;
     int32_t v = -1;
     if (j < nq) {
-      int4 c = q[j];
-      v = table_lookup(tab, fnv60(c.x + ox, c.y + oy, c.z + oz, c.w));
+      if (centre) {
+        v = (int32_t)j;
+      } else {
+        int4 c = q[j];
+        v = table_lookup(tab, fnv60(c.x + ox, c.y + oy, c.z + oz, c.w));
+      }
       res[j] = v;
+      if (SYM && !centre && v >= 0) mres[v] = (int32_t)j;
     }
     hits += (v >= 0);
   }
@@ -99,6 +112,25 @@ __global__ void __launch_bounds__(256) rb_probe_kernel(const int4 *__restrict__ 
   __syncthreads();
   if (threadIdx.x == 0)
     blockcnt[(int64_t)k * gridDim.x + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// block counts of rows k0 .. k0 + gridDim.y - 1 of the hit matrix (the scattered half of a symmetric probe)
+__global__ void __launch_bounds__(256) rb_count_kernel(const int32_t *__restrict__ results, int64_t nq, int k0,
+                                                       int32_t *__restrict__ blockcnt) {
+  const int k = k0 + blockIdx.y;
+  const int64_t base = (int64_t)blockIdx.x * kRowsPerBlock;
+  const int32_t *res = results + (int64_t)k * nq;
+  int hits = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t j = base + r * 256 + threadIdx.x;
+    hits += (j < nq && res[j] >= 0);
+  }
+  __shared__ int wsum[4];
+  for (int o = 32; o > 0; o >>= 1) hits += __shfl_down(hits, o, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = hits;
+  __syncthreads();
+  if (threadIdx.x == 0) blockcnt[(int64_t)k * gridDim.x + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // pass 1b: single-workgroup exclusive scan of the K*nblk block counts (<= ~30k entries),
@@ -330,7 +362,7 @@ extern "C" size_t pcs_rulebook_ws_bytes(int64_t nq, int32_t K) {
 extern "C" int pcs_rulebook_probe(const int32_t *qcoords, int64_t nq, const int32_t *offsets,
                                   int32_t K, const void *table, int64_t capacity,
                                   int32_t *results, int64_t *nbsizes, void *ws, size_t ws_bytes,
-                                  void *stream) {
+                                  int32_t symmetric, void *stream) {
   if (nq < 0 || K <= 0 || K > 65535 || !table || capacity <= 0 || (capacity & (capacity - 1)) ||
       !offsets || !nbsizes || !ws) {
     set_error("pcs_rulebook_probe: bad args");
@@ -343,9 +375,21 @@ extern "C" int pcs_rulebook_probe(const int32_t *qcoords, int64_t nq, const int3
   const int64_t nblk = ceil_div(nq > 0 ? nq : 1, kRowsPerBlock);
   if (nq > 0) {
     if (!qcoords || !results || ((uintptr_t)qcoords & 15)) { set_error("pcs_rulebook_probe: bad pointers"); return PCS_EINVAL; }
-    hipLaunchKernelGGL(rb_probe_kernel, dim3((unsigned)nblk, K), dim3(256), 0, st,
-                       reinterpret_cast<const int4 *>(qcoords), nq, offsets,
-                       make_view(table, capacity), results, w.blockcnt);
+    if (symmetric && (K & 1) && K >= 3) {
+      const int half = K / 2;  // rows half+1 .. K-1 are scattered by the probes of rows 0 .. half-1
+      if (hipMemsetAsync(results + (int64_t)(half + 1) * nq, 0xFF, (size_t)half * nq * 4, st) != hipSuccess) {
+        set_error("pcs_rulebook_probe: memset failed");
+        return PCS_ELAUNCH;
+      }
+      hipLaunchKernelGGL(rb_probe_kernel<true>, dim3((unsigned)nblk, half + 1), dim3(256), 0, st,
+                         reinterpret_cast<const int4 *>(qcoords), nq, offsets,
+                         make_view(table, capacity), results, w.blockcnt, (int)K);
+      hipLaunchKernelGGL(rb_count_kernel, dim3((unsigned)nblk, half), dim3(256), 0, st, results, nq, half + 1, w.blockcnt);
+    } else {
+      hipLaunchKernelGGL(rb_probe_kernel<false>, dim3((unsigned)nblk, K), dim3(256), 0, st,
+                         reinterpret_cast<const int4 *>(qcoords), nq, offsets,
+                         make_view(table, capacity), results, w.blockcnt, (int)K);
+    }
   } else {
     if (hipMemsetAsync(w.blockcnt, 0, (size_t)K * nblk * 4, st) != hipSuccess) { set_error("pcs_rulebook_probe: memset failed"); return PCS_ELAUNCH; }
   }

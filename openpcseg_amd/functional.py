@@ -162,7 +162,7 @@ def build_kernel_map(in_coords, out_coords, kernel_size, in_stride, dilation):
     symmetric = bool(torch.equal(offsets.flip(0), -offsets))  # odd kernel sizes
     offsets = (offsets.pin_memory() if in_coords.is_cuda else offsets).to(in_coords.device, non_blocking=True)
     hint_key = (tuple(kernel_size), tuple(in_stride), tuple(dilation), in_coords is out_coords)  # map family
-    fwd = _be().build_kmap(in_coords, out_coords, offsets, hint_key=hint_key)
+    fwd = _be().build_kmap(in_coords, out_coords, offsets, hint_key=hint_key, symmetric=symmetric and in_coords is out_coords)
     return KmapEntry(fwd, in_coords, out_coords, offsets, symmetric, hint_key)
 
 

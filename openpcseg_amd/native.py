@@ -37,7 +37,7 @@ SIGNATURES = {
     "pcs_downsample_pack": (c_int32, [_P, c_int64, _P, c_int32, _P, c_int32, _P, _P, _P, _P]),
     "pcs_downsample_unpack": (c_int32, [_P, c_int64, _P, _P]),
     "pcs_rulebook_ws_bytes": (c_size_t, [c_int64, c_int32]),
-    "pcs_rulebook_probe": (c_int32, [_P, c_int64, _P, c_int32, _P, c_int64, _P, _P, _P, c_size_t, _P]),
+    "pcs_rulebook_probe": (c_int32, [_P, c_int64, _P, c_int32, _P, c_int64, _P, _P, _P, c_size_t, c_int32, _P]),
     "pcs_rulebook_fill": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P]),
     "pcs_rulebook_tile_segments": (c_int32, [_P, _P, c_int32, c_int64, c_int32, c_int32, _P, _P]),
     "pcs_rulebook_tile_order": (c_int32, [_P, c_int32, c_int64, _P, _P]),
@@ -455,10 +455,12 @@ class HipBackend:
         return out
 
     # -- rulebook -------------------------------------------------------------------------------
-    def build_kmap(self, ref_coords, query_coords, offsets, hint_key=None):
+    def build_kmap(self, ref_coords, query_coords, offsets, hint_key=None, symmetric=False):
         """pairs (ref_row, query_row) for hash(query + offsets[k]) == hash(ref); k-major, query
         ascending. No host sync: the per-offset sizes are copied to pinned memory asynchronously and read when
-        `koff_host` / `pairs` / `num_pairs` of the map are first needed (KernelMap, deferred sizes)."""
+        `koff_host` / `pairs` / `num_pairs` of the map are first needed (KernelMap, deferred sizes). symmetric: the
+        caller knows offsets[K-1-k] == -offsets[k]; with ref_coords is query_coords (submanifold map) only half of the
+        offsets are probed and the other half mirrored."""
         ref_coords = _dev(ref_coords, "coords", torch.int32)
         query_coords = _dev(query_coords, "coords", torch.int32)
         offsets = _dev(offsets, "offsets", torch.int32)
@@ -471,7 +473,8 @@ class HipBackend:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         _check(self.lib.pcs_rulebook_probe(_ptr(query_coords), nq, _ptr(offsets), k, _ptr(table.storage),
                                            table.capacity, _ptr(results), _ptr(nbsizes), _ptr(ws),
-                                           ws_bytes, _stream()), "pcs_rulebook_probe")
+                                           ws_bytes, int(bool(symmetric) and ref_coords is query_coords and k % 2 == 1),
+                                           _stream()), "pcs_rulebook_probe")
         sizes = torch.empty(k, dtype=torch.int64, pin_memory=True)
         sizes.copy_(nbsizes, non_blocking=True)
         event = torch.cuda.Event()

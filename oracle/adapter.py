@@ -98,7 +98,7 @@ class OracleBackend:
         out = np.unique(out[:, [3, 0, 1, 2]], axis=0)
         return torch.from_numpy(np.ascontiguousarray(out[:, [1, 2, 3, 0]], dtype=np.int32))
 
-    def build_kmap(self, ref_coords, query_coords, offsets, hint_key=None):
+    def build_kmap(self, ref_coords, query_coords, offsets, hint_key=None, symmetric=False):
         nbmaps, nbsizes = orc.build_kmap(_np(ref_coords), _np(query_coords), None, offsets=_np(offsets))
         return CpuKernelMap(nbmaps, nbsizes, ref_coords.shape[0], query_coords.shape[0])
 
