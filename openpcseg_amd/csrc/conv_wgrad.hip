@@ -275,7 +275,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce4_kernel(const float *__restr
 // 32-pair batches gathered once per workgroup ("wgrad4": half the global loads per MFMA, one barrier per 128 MFMAs,
 // two workgroups per CU) -- bit-identical results, 7-14 % SLOWER on the >= 96-channel layers and 2.5x slower on thin
 // ones. The PCS_ABLATEW debug builds show where wgrad2 stands: stride 8 256 x 256 1048 us with MFMAs only, 770 us
-// with loads only, 1185 us together; three waves per SIMD, each one batch ahead, already hide most of the rest.
+// with loads only, 1185 us together; three waves per SIMD, each one batch ahead, already hide most of the rest (a third
+// batch buffer -- rows two batches ahead -- is +1 % on the 48-wide blocks and -10 % on the 64-wide ones, which drop
+// to two waves per SIMD).
 // ================================================================================================
 struct Wgrad2Args {
   const void *fa;  // rows of ET (float, or bf16 / fp16 halfs converted to fp32 on load)
