@@ -3,7 +3,6 @@
 Usage: python tools/conv_tile_sweep.py "<level> <cin> <cout> <tile,tile,...> [bf16|fp16]" ...   (tile 0 = the picker's choice;
 <tile>+rows = row order instead of the heaviest-first tile order)
 Set PCS_CONV_DEBUG=1 to see the kernel instance and the resident workgroups per CU of every configuration."""
-import ctypes
 import os
 import sys
 

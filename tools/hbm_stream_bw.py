@@ -1,4 +1,6 @@
-import torch,time
+"""Practical streaming bandwidth of this GPU with plain torch ops (copy / add / sum / fill on 445 MB and 1.8 GB tensors):
+the yardstick for the HBM-bound kernels of profiles/round2_hbm_ops.md."""
+import torch
 x=torch.randn(1158864,96,device='cuda'); y=torch.empty_like(x)
 def t(fn,n=50):
     for _ in range(10): fn()

@@ -1,3 +1,5 @@
+"""Sort / cumsum variants for the Lovasz loss of the workload (19 classes x 1.4 M points): per-class sorts, one batched
+sort, flat composite keys -- all ~2 ms; a 2-D cumsum along the long axis is 15x slower than per-class ones."""
 import torch
 def t(fn,n=10):
     for _ in range(3): fn()
