@@ -43,18 +43,28 @@ def lovasz_softmax(probas, labels, ignore=None):
     """The same function with the present classes as the rows of (C', n) tensors: one sort, one gather and a dozen
     elementwise kernels for all classes instead of ~25 small launches per class (19 classes x 1.4 M points: the
     per-class loop spent ~5 ms of a 70 ms bf16 step in launch-bound kernels). The Lovasz gradient depends on the
-    labels only, so it is built outside autograd; (1 - fg).cumsum is position - fg.cumsum (integers, exact in fp32)."""
-    if ignore is not None:
-        keep = labels != ignore
-        probas, labels = probas[keep], labels[keep]
+    labels only, so it is built outside autograd; (1 - fg).cumsum is position - fg.cumsum (integers, exact in fp32).
+    Ignored points are not compacted away (a nonzero + gather forward, an index_put backward over (n, C)): their error
+    is set to zero, which sorts them behind every point that matters -- each term they could touch is multiplied by
+    a zero error, so the value and the gradient are the compacted ones."""
     if probas.numel() == 0:
         return probas.sum() * 0.0
-    n = probas.shape[0]
-    cls = (torch.bincount(labels, minlength=probas.shape[1]) > 0).nonzero().squeeze(1)  # one host sync
+    n, nc = probas.shape
+    cnt = torch.bincount(labels.clamp(0, nc - 1), minlength=nc)
+    valid = None
+    if ignore is not None:
+        valid = labels != ignore
+        if 0 <= ignore < nc:
+            cnt[ignore] = 0
+    cls = (cnt > 0).nonzero().squeeze(1)  # one host sync
+    if cls.numel() == 0:
+        return probas.sum() * 0.0
     pt = probas.t().index_select(0, cls)  # (C', n), rows = present classes
     with torch.no_grad():
         fg = (labels.unsqueeze(0) == cls.unsqueeze(1)).to(probas.dtype)
     err = (fg - pt).abs()
+    if valid is not None:
+        err = err * valid.to(probas.dtype).unsqueeze(0)
     err_sorted, perm = torch.sort(err, dim=1, descending=True)
     with torch.no_grad():
         fg_sorted = torch.gather(fg, 1, perm)
