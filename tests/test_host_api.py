@@ -218,3 +218,23 @@ def test_batched_lovasz_equals_the_per_class_loop():
         assert abs(float(a.detach()) - float(b.detach())) <= 1e-6 and (ga - gb).abs().max() <= 1e-7
     empty = torch.zeros(4, 20).softmax(1)
     assert float(lovasz_softmax(empty, torch.zeros(4, dtype=torch.long), ignore=0)) == 0.0
+
+
+def test_launch_shape_helpers_are_host_functions():
+    """The per-layer launch-shape entry points run on the host (no GPU needed): tile heights of the bench shapes
+    (profiles/round2_tile_sweep_*.md), which kernels read a tile order, which emit BatchNorm partials."""
+    lib = native.load_library()
+    pick = lib.pcs_conv_pick_tile_rows_dt
+    assert pick(1158864, 5112372, 27, 96, 96, 0) == 384 and pick(1158864, 5112372, 27, 96, 96, 1) == 192
+    assert pick(329421, 2752033, 27, 128, 128, 0) == 288 and pick(329421, 2752033, 27, 128, 128, 1) == 144
+    assert pick(36068, 331722, 27, 256, 256, 0) == 288 and pick(36068, 331722, 27, 256, 256, 2) == 288
+    assert pick(36068, 331722, 27, 16, 32, 0) == 128 and pick(0, 0, 27, 96, 96, 0) == 128
+    assert lib.pcs_conv_pick_tile_rows(113008, 1001308, 27, 256, 256) == pick(113008, 1001308, 27, 256, 256, 0)
+    for t in (pick(n, p, 27, ci, co, d) for n, p in ((1158864, 5112372), (113008, 1001308), (3000, 9000))
+              for ci, co in ((32, 32), (64, 64), (96, 96), (128, 96), (256, 256), (384, 256)) for d in (0, 1)):
+        assert 16 <= t <= 512 and t % 16 == 0
+    assert lib.pcs_conv_uses_tile_order(96, 96, 27, 0) == 1 and lib.pcs_conv_uses_tile_order(32, 32, 27, 0) == 1
+    assert lib.pcs_conv_uses_tile_order(16, 32, 27, 0) == 0 and lib.pcs_conv_uses_tile_order(4, 32, 27, 1) == 0
+    assert lib.pcs_conv_emits_bn_partials(128, 128, 27, 288, 0) == 1 and lib.pcs_conv_emits_bn_partials(96, 96, 27, 384, 0) == 1
+    assert lib.pcs_conv_emits_bn_partials(5, 33, 27, 128, 0) == 0
+
