@@ -436,12 +436,10 @@ int pcs::launch_conv_wave5(ConvArgs a, hipStream_t st) {
   // 4-wave workgroups while two of them fit a CU's LDS, else one 8-wave workgroup
   const size_t lds = (size_t)((a.tile_rows + 1) * (16 * nctt + 4)) * 4 + 1024;
   const bool nw8 = force_nw ? force_nw == 8 : 2 * lds > 160 * 1024;
-  // groups of 2 row blocks; PCS_CONV_V5=3/4: larger groups (debug: they spill at 6 / 8 column tiles)
-  static const int v5r = getenv("PCS_CONV_V5") ? atoi(getenv("PCS_CONV_V5")) : 2;
+  // groups of 2 row blocks (groups of 3 / 4 were instantiated and measured through round 2: within +-1 % where they fit
+  // the registers -- the W stream they save is not what bounds the kernel -- and spilling at 6 / 8 column tiles)
 #define PCS_CONV5_CASE(N)                                                                           \
   case N:                                                                                           \
-    if (v5r == 3) return launch_conv5<N, 4, 2, 3>(a, st);                                           \
-    if (v5r == 4) return launch_conv5<N, 4, 2, 4>(a, st);                                           \
     if (nw8) return launch_conv5<N, 8, 2, 2>(a, st); /* 8-wave workgroups */                          \
     return launch_conv5<N, 4, 2, 2>(a, st);
   switch (nctt) {

@@ -387,12 +387,8 @@ int launch_h(ConvArgsH a, hipStream_t st) {
   a.ncoltiles = (int)ceil_div(a.cout, 16 * nctt);
   const size_t lds = (size_t)((a.tile_rows + 1) * (16 * nctt + 4)) * 4 + 1024;
   const bool nw8 = 2 * lds > 160 * 1024;  // 4-wave workgroups while two of them fit a CU's LDS, else one 8-wave workgroup
-  static const int rr = getenv("PCS_CONVH_R") ? atoi(getenv("PCS_CONVH_R")) : 2;  // debug: row blocks per group (2 / 4)
 #define PCS_CONV5H_CASE(N)                                                                          \
   case N:                                                                                           \
-    if constexpr (N <= 4) {                                                                         \
-      if (rr == 4) return nw8 ? launch_conv5h<HT, N, 8, 2, 4>(a, st) : launch_conv5h<HT, N, 4, 2, 4>(a, st); \
-    }                                                                                               \
     return nw8 ? launch_conv5h<HT, N, 8, 2, 2>(a, st) : launch_conv5h<HT, N, 4, 2, 2>(a, st);
   switch (nctt) {
     PCS_CONV5H_CASE(2)
