@@ -50,7 +50,7 @@ extern "C" int pcs_transpose_kab_f32(const float *src, int32_t K, int32_t A, int
 
 // Bumped whenever a fused-conv kernel, its launch shape picker or its epilogue changes: measurements keyed to kernels
 // (profiles/*_conv_traffic.json) carry the revision they were taken on and bench.py refuses a stale one.
-extern "C" const char *pcs_conv_kernel_revision(void) { return "r2.5-wave5+commit-prio+tile-order+thin"; }
+extern "C" const char *pcs_conv_kernel_revision(void) { return "r3.0-wave5+tail"; }
 
 extern "C" int32_t pcs_conv_tile_rows(int32_t cin, int32_t cout) {
   (void)cin;
@@ -117,15 +117,14 @@ extern "C" int32_t pcs_conv_pick_tile_rows_dt(int64_t n_dst, int64_t n_pairs, in
   // 128 rows): one 8-wave workgroup per CU on the tallest tile the LDS holds pads 1.12-1.17x
   if (ceil_div(n_dst, 128) * ncol >= 8 * slots && ppr < 6.5) {
     int T = 384;
-    while (T > 128 && (size_t)((T + 1) * (16 * nctt + 4)) * 4 + 1024 > kMaxDynLds) T -= 32;
+    while (T > 128 && conv5_lds_est(T, nctt) > kMaxDynLds) T -= 32;
     if (T >= 192) return T;
   }
   int best = 128;
   double best_cost = launch_cost(n_dst, 128, ncol, ppr, K) * 0.97;
   for (int T = 80; T <= 192; T += 16) {
     if (T == 128) continue;
-    const size_t lds = (size_t)((T + 1) * (16 * nctt + 4)) * 4 + 5 * 33 * 4 + 16;
-    if (2 * (lds + 1024) > 160 * 1024) continue;  // keep two workgroups per CU
+    if (2 * conv5_lds_est(T, nctt) > 160 * 1024) continue;  // keep two workgroups per CU
     const double c = launch_cost(n_dst, T, ncol, ppr, K);
     if (c < best_cost) { best = T; best_cost = c; }
   }
@@ -144,15 +143,13 @@ extern "C" int32_t pcs_conv_emits_bn_partials(int32_t cin, int32_t cout, int32_t
   if (dtype == 0) {
     if (conv5_applies(cin, cout, K)) {
       nctt = conv5_nctt(cout, tile_rows);
-      const size_t lds = (size_t)((tile_rows + 1) * (16 * nctt + 4)) * 4 + 1024;
-      nt = 2 * lds > 160 * 1024 ? 512 : 256;
+      nt = 2 * conv5_lds_est(tile_rows, nctt) > 160 * 1024 ? 512 : 256;
     } else if (tile_rows != 64 && tile_rows != 128) {
       return 0;
     }
   } else {
     if (!convh_applies(cin, cout, K)) return 0;
-    const size_t lds = (size_t)((tile_rows + 1) * (16 * nctt + 4)) * 4 + 1024;
-    nt = 2 * lds > 160 * 1024 ? 512 : 256;
+    nt = 2 * conv5_lds_est(tile_rows, nctt) > 160 * 1024 ? 512 : 256;
   }
   return conv_stats_fit(tile_rows, 16 * nctt, nt) ? 1 : 0;
 }

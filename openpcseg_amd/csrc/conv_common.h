@@ -17,6 +17,12 @@
 #ifndef PCS_ALIAS
 #define PCS_ALIAS 0    /* wave5: 1 every offset reads W[0], 2 A rows read sequentially instead of gathered */
 #endif
+#ifndef PCS_COMMIT_ATOMIC
+#define PCS_COMMIT_ATOMIC 1  /* wave5 / wave5h: commit with LDS float atomics in ticket order (0: read-add-write under the ticket) */
+#endif
+#ifndef PCS_COMMIT_NOWAIT
+#define PCS_COMMIT_NOWAIT 1  /* atomic commit: hand the ticket on without waiting for the atomics to complete */
+#endif
 #if PCS_TRACE
 #define PCS_T(...) __VA_ARGS__
 #else
@@ -58,15 +64,34 @@ __device__ __forceinline__ uint16_t f2h(Fp16, float f) {
   return __builtin_bit_cast(uint16_t, h);
 }
 
-constexpr size_t kMaxDynLds = 160 * 1024 - 256;  // per-workgroup LDS ceiling of a gfx950 CU, minus the static part
+// LDS accumulate of the wave kernels' commit: one ds_add_f32 per lane (no return value, nothing to wait for)
+__device__ __forceinline__ void lds_add(float *p, float v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
-// 16-column MFMA tiles per column tile of the wave kernels: 1, 2, 3, 4, 6 or 8
+constexpr size_t kMaxDynLds = 160 * 1024 - 256;
+// sink rows below the accumulator tile of the wave5 kernels (atomic commit: one per lane group) and the LDS estimate
+// every launch-shape decision shares (tile + offset lists + slack)
+constexpr int kConvSinkRows = PCS_COMMIT_ATOMIC ? 4 : 1;
+inline size_t conv5_lds_est(int tile_rows, int nctt) { return (size_t)((tile_rows + kConvSinkRows) * (16 * nctt + 4)) * 4 + 1024; }  // per-workgroup LDS ceiling of a gfx950 CU, minus the static part
+
+// 16-column MFMA tiles per column tile of the wave kernels: 1, 2, 3, 4, 6 or 8. Up to 128 output columns are one
+// column tile; wider outputs take the width in {8, 6, 4} that pads the fewest columns (ties: the widest) -- 256 -> 8,
+// 192 -> 6, and the cr 1.75 widths 168 -> 6 (192), 224 -> 8 (256), 336 -> 8 (384), 448 -> 4 (448), 672 -> 6 (672).
+// The fragment order of the prepared half weights is defined by this function (conv_wave5h.hip).
 inline int conv_nctt(int cout) {
   int nctt = (cout + 15) / 16;
-  if (nctt > 8) nctt = 8;
-  if (nctt == 5) nctt = 6;
-  if (nctt == 7) nctt = 8;
-  return nctt;
+  if (nctt <= 8) {
+    if (nctt == 5) nctt = 6;
+    if (nctt == 7) nctt = 8;
+    return nctt;
+  }
+  int best = 8, best_pad = ((cout + 127) / 128) * 128 - cout;
+  for (int n = 6; n >= 4; n -= 2) {
+    const int pad = ((cout + 16 * n - 1) / (16 * n)) * 16 * n - cout;
+    if (pad < best_pad) { best = n; best_pad = pad; }
+  }
+  return best;
 }
 // fp32 wave5: 16-column MFMA tiles per column tile for (cout, tile height). >= 128 output columns on tiles of 176 rows
 // or more run as 64-column tiles (144 VGPRs: three waves per SIMD, two to three workgroups per CU; the taller tile pads
@@ -76,16 +101,17 @@ inline int conv5_nctt(int cout, int tile_rows) {
   if (cout >= 192 && tile_rows >= 192) return 4;
   return conv_nctt(cout);
 }
-// wave5 serves 16-byte-granular shapes with a 32-channel contraction granule and an even column tile (32-channel
-// layers too since round 2: 32->32 at stride 2 155 -> 131 us against the one-row-block-per-step wave4 kernel)
+// wave5 serves every 16-byte-granular shape from 32 input channels up with an even column tile: cin % 32 == 0 on the
+// straight-line pipeline, other cin % 4 == 0 on its TAIL instance (round 3: the cr 1.75 / cr 0.5 widths 56, 112, 168,
+// 336, 48 ... used to fall to the one-row-block-per-step wave4 kernel)
 inline bool conv5_applies(int cin, int cout, int K) {
-  return cin % 32 == 0 && cin >= 32 && cout % 4 == 0 && K <= 32 && conv_nctt(cout) % 2 == 0;
+  return cin % 4 == 0 && cin >= 32 && cout % 4 == 0 && K <= 32 && conv_nctt(cout) % 2 == 0;
 }
 
-// the half-precision wave kernel (conv_wave5h.hip) steps 32 channels per MFMA and needs no second pipeline stage:
-// every 16-byte-granular shape with a 32-channel contraction granule and an even column tile
+// the half-precision wave kernel (conv_wave5h.hip) steps 32 channels per MFMA: rows are 16-byte granular from
+// cin % 8 == 0 on; a last step of 8 / 16 / 24 channels meets zero-padded weight fragments (TAIL instance)
 inline bool convh_applies(int cin, int cout, int K) {
-  return cin % 32 == 0 && cin >= 32 && cout % 4 == 0 && K <= 32 && conv_nctt(cout) % 2 == 0;
+  return cin % 8 == 0 && cin >= 32 && cout % 4 == 0 && K <= 32 && conv_nctt(cout) % 2 == 0;
 }
 
 // Tile epilogue of the wave kernels. The fp32 accumulator tile acc_l[T+1][ACS] is complete (the caller has passed its

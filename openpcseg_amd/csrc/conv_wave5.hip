@@ -16,7 +16,12 @@ constexpr int kTraceBlocks = 8192;
 // applies each W operand block to a group of up to R consecutive row blocks of the same offset (R accumulator sets),
 // so the W stream per compact row drops R-fold where an offset has >= R row blocks in the tile -- with one row block
 // per step every 16 rows stream their own copy of W[k] (Cin x CT fp32, 37-131 KB) out of L2. The tile height is a
-// run-time parameter chosen per layer (pcs_conv_pick_tile_rows). Requires cin % 32 == 0.
+// run-time parameter chosen per layer (pcs_conv_pick_tile_rows).
+// TAIL = false: cin % 32 == 0 (an even number of whole 16-channel blocks: the straight-line two-stage pipeline).
+// TAIL = true: any cin % 4 == 0 (56, 112, 168, 336 ... of RPVNet cr 1.75, 48 of cr 0.5): the last block may hold
+// 4 / 8 / 12 channels -- its out-of-range lane groups read a clamped (in-row) address and contribute exact zeros --
+// and an odd number of blocks ends the group one pipeline stage early (the next group's first block lands in the
+// other register set and is moved over).
 // ================================================================================================
 template <int NCTT, int NW_, int R_>
 struct Conv5Cfg {
@@ -29,22 +34,24 @@ struct Conv5Cfg {
   static constexpr int N2 = (NCTT % 4) / 2;
   static constexpr int N1 = NCTT % 2;
   static constexpr int NWL = N4 + N2 + N1;  // W loads per contraction step
-  static constexpr size_t lds_bytes(int T) { return (size_t)((T + 1) * ACS) * 4 + 5 * 33 * 4 + 16; }
+  static constexpr int SINK = kConvSinkRows;  // atomic commit: padding rows of lane group g accumulate into sink row T + g
+  static constexpr size_t lds_bytes(int T) { return (size_t)((T + SINK) * ACS) * 4 + 5 * 33 * 4 + 16; }
 };
 
-template <int NCTT, int NW, int MINW, int R>
+template <int NCTT, int NW, int MINW, int R, bool TAIL>
 __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
   using C = Conv5Cfg<NCTT, NW, R>;
   const int T = a.tile_rows;  // any multiple of 16: the host picks it per layer (pcs_conv_pick_tile_rows)
   PCS_T(const long long tr_entry = wall_clock64(); long long tr_loop = 0, tr_ticket = 0, tr_commit = 0; int tr_groups = 0;)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float *acc_l = reinterpret_cast<float *>(smem);            // [T+1][ACS], row T = sink for padding rows
-  int *kl_k = reinterpret_cast<int *>(acc_l + (T + 1) * C::ACS);  // [32] offset id
+  float *acc_l = reinterpret_cast<float *>(smem);            // [T+SINK][ACS], rows >= T = sink for padding rows
+  int *kl_k = reinterpret_cast<int *>(acc_l + (T + C::SINK) * C::ACS);  // [32] offset id
   int *kl_s = kl_k + 32;                                     // [32] first pair
   int *kl_m = kl_s + 32;                                     // [32] #pairs
   int *kl_g = kl_m + 32;                                     // [33] first FULL group (prefix over the offsets)
   int *kl_h = kl_g + 33;                                     // [33] first partial group (prefix)
   int *commit = kl_h + 33;
+  const unsigned commit_lds = (unsigned)(size_t)(__attribute__((address_space(3))) int *)commit;  // LDS byte address
   __shared__ int nk_s;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // a scalar: wave-level loops and branches stay uniform
@@ -93,9 +100,9 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
       nk_s = nkk; kl_g[nkk] = total & 0xFFFF; kl_h[nkk] = total >> 16; *commit = 0;
     }
   }
-  {  // zero the tile: (T + 1) * ACS floats, a multiple of four
+  {  // zero the tile: (T + SINK) * ACS floats, a multiple of four
     float4 *z = reinterpret_cast<float4 *>(acc_l);
-    const int n4 = (T + 1) * (C::ACS / 4);
+    const int n4 = (T + C::SINK) * (C::ACS / 4);
     for (int i = tid; i < n4; i += C::NT) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
@@ -108,6 +115,8 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
   const int total_grp = nk > 0 ? total_full + __builtin_amdgcn_readfirstlane(kl_h[nk]) : 0;
 
   const int cin4 = a.cin - 4;
+  const int nb16 = TAIL ? (a.cin + 15) >> 4 : a.cin >> 4;  // 16-channel contraction blocks
+  const int cinp = nb16 * 16;
   int col4[C::N4 > 0 ? C::N4 : 1];
 #pragma unroll
   for (int q = 0; q < C::N4; ++q) {
@@ -134,7 +143,8 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
   };
   // PCS_ABLATE5 (debug builds): 3 = no operand loads inside the channel loop, 5 = no W loads, 6 = no A loads there
   auto load_frag = [&](Frag &f, const Ctx &cx, int c0, bool in_loop = false) {
-    const int ca = c0 + 4 * g;  // cin % 32 == 0: always inside the row
+    int ca = c0 + 4 * g;  // !TAIL: always inside the row
+    if (TAIL) ca = ca < cin4 ? ca : cin4;  // a lane group beyond cin re-reads the row's last piece; masked in mfma_frag
     (void)in_loop;
 #if PCS_ABLATE5 == 3
     if (in_loop) return;
@@ -235,13 +245,16 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
     const unsigned vmask = cur.vmask;
     const int nr = __builtin_amdgcn_readfirstlane(cur.nr);  // wave-uniform: a scalar, so the bodies below are real branches
     // MFMAs of one 16-channel block for the first NR row blocks of the group (NR is wave-uniform)
-    auto mfma_frag = [&](const Frag &f, auto nr_tag) {
+    // last_tag: the block is the layer's last one (only there can lane groups lie beyond cin)
+    auto mfma_frag = [&](const Frag &f, auto nr_tag, auto last_tag) {
       constexpr int NR = decltype(nr_tag)::value;
+      constexpr bool LAST = decltype(last_tag)::value;
+      const bool cok = !(TAIL && LAST) || (cinp - 16 + 4 * g < a.cin);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-          const bool ok = (vmask >> r) & 1u;
+          const bool ok = ((vmask >> r) & 1u) && cok;
           const float av = ok ? (e == 0 ? f.a[r].x : (e == 1 ? f.a[r].y : (e == 2 ? f.a[r].z : f.a[r].w))) : 0.f;
 #if PCS_ABLATE5 == 2   /* debug build: consume the operands with one VALU op each, no MFMA */
 #pragma unroll
@@ -269,8 +282,8 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
     Ctx nxt;
     // one scheduling region per block: per contraction step e the W loads of the NEXT block (plus,
     // first, its R A pieces), then this block's NR*NCTT MFMAs of step e
-#define PCS_PIPE5(LOAD, FR, NRV)                                                                   \
-  LOAD; mfma_frag(FR, std::integral_constant<int, NRV>{});                                         \
+#define PCS_PIPE5(LOAD, FR, NRV, LASTV)                                                            \
+  LOAD; mfma_frag(FR, std::integral_constant<int, NRV>{}, std::integral_constant<bool, LASTV>{});  \
   __builtin_amdgcn_sched_group_barrier(0x020, R + C::NWL, 0);                                      \
   __builtin_amdgcn_sched_group_barrier(0x008, NRV * NCTT, 0);                                      \
   __builtin_amdgcn_sched_group_barrier(0x020, C::NWL, 0);                                          \
@@ -281,20 +294,29 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
   __builtin_amdgcn_sched_group_barrier(0x008, NRV * NCTT, 0);                                      \
   __builtin_amdgcn_sched_barrier(0);
 #define PCS_BODY5(NRV)                                                                             \
-  {                                                                                                \
-    for (int c0 = 0; c0 < a.cin - 32; c0 += 32) {                                                  \
-      PCS_PIPE5(load_frag(f1, cur, c0 + 16, true), f0, NRV)                                        \
-      PCS_PIPE5(load_frag(f0, cur, c0 + 32, true), f1, NRV)                                        \
+  if (!TAIL || !(nb16 & 1)) { /* an even number of blocks */                                       \
+    for (int c0 = 0; c0 < cinp - 32; c0 += 32) {                                                   \
+      PCS_PIPE5(load_frag(f1, cur, c0 + 16, true), f0, NRV, false)                                 \
+      PCS_PIPE5(load_frag(f0, cur, c0 + 32, true), f1, NRV, false)                                 \
     }                                                                                              \
-    PCS_PIPE5(load_frag(f1, cur, a.cin - 16, true), f0, NRV)                                       \
+    PCS_PIPE5(load_frag(f1, cur, cinp - 16, true), f0, NRV, false)                                 \
     make_ctx(nxt, pr_n, vm_n, nr_n, in);                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                             \
-    PCS_PIPE5(load_frag(f0, nxt, 0), f1, NRV)                                                      \
+    PCS_PIPE5(load_frag(f0, nxt, 0), f1, NRV, true)                                                \
+  } else { /* odd: the loop leaves the last block in f0 */                                         \
+    for (int c0 = 0; c0 < cinp - 16; c0 += 32) {                                                   \
+      PCS_PIPE5(load_frag(f1, cur, c0 + 16, true), f0, NRV, false)                                 \
+      PCS_PIPE5(load_frag(f0, cur, c0 + 32, true), f1, NRV, false)                                 \
+    }                                                                                              \
+    make_ctx(nxt, pr_n, vm_n, nr_n, in);                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    PCS_PIPE5(load_frag(f1, nxt, 0), f0, NRV, true)                                                \
+    f0 = f1;                                                                                       \
   }
-    if (R >= 4 && nr == 4) PCS_BODY5((R >= 4 ? 4 : 1))
-    else if (R >= 3 && nr == 3) PCS_BODY5((R >= 3 ? 3 : 1))
-    else if (R >= 2 && nr == 2) PCS_BODY5((R >= 2 ? 2 : 1))
-    else PCS_BODY5(1)
+    if (R >= 4 && nr == 4) { PCS_BODY5((R >= 4 ? 4 : 1)) }
+    else if (R >= 3 && nr == 3) { PCS_BODY5((R >= 3 ? 3 : 1)) }
+    else if (R >= 2 && nr == 2) { PCS_BODY5((R >= 2 ? 2 : 1)) }
+    else { PCS_BODY5(1) }
 #undef PCS_BODY5
 #undef PCS_PIPE5
     // ---- in-order commit of the group's row blocks -------------------------------------------------------
@@ -308,11 +330,65 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) doff[r][j] = __shfl(cur.dloc[r], 4 * g + j, 64) * C::ACS;
+      for (int j = 0; j < 4; ++j) {
+        const int dl = __shfl(cur.dloc[r], 4 * g + j, 64);
+#if PCS_COMMIT_ATOMIC
+        doff[r][j] = (dl >= T ? T + g : dl) * C::ACS;  // padding rows: a sink row of this lane group's own (no same-address adds)
+#else
+        doff[r][j] = dl * C::ACS;
+#endif
+      }
+#if PCS_COMMIT_ATOMIC
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(doff[r][j]));  // formed BEFORE the ticket wait, not sunk into the critical section
+#endif
     if (lane == 0) {
       while (__hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != grp)
         __builtin_amdgcn_s_sleep(1);
     }
+#if PCS_COMMIT_ATOMIC
+    // Round 3: the accumulate is ONE ds_add_f32 per lane and tile element, issued while the wave holds the ticket and
+    // never waited for. The LDS executes a wave's instructions in order, so the adds of this group reach every address
+    // before the ticket store that follows them, and the next owner -- who starts issuing only after it has read the
+    // new ticket -- adds after us: the per-address order is the ticket order (bit-reproducible sums, the same fp32
+    // additions as the read-add-write form), but the chain link shrinks from [LDS read latency + add + write +
+    // completion wait] to the issue time of the adds.
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_setprio(3);
+    PCS_T(const long long tr_c = wall_clock64();)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r < nr) {  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float *d = acc_l + doff[r][j];
+#pragma unroll
+          for (int q = 0; q < C::N4; ++q) {
+            lds_add(d + 64 * q + 4 * l15 + 0, acc[r][4 * q + 0][j]);
+            lds_add(d + 64 * q + 4 * l15 + 1, acc[r][4 * q + 1][j]);
+            lds_add(d + 64 * q + 4 * l15 + 2, acc[r][4 * q + 2][j]);
+            lds_add(d + 64 * q + 4 * l15 + 3, acc[r][4 * q + 3][j]);
+          }
+          if (C::N2) {
+            lds_add(d + 64 * C::N4 + 2 * l15 + 0, acc[r][4 * C::N4 + 0][j]);
+            lds_add(d + 64 * C::N4 + 2 * l15 + 1, acc[r][4 * C::N4 + 1][j]);
+          }
+          if (C::N1) lds_add(d + 64 * C::N4 + 32 * C::N2 + l15, acc[r][NCTT - 1][j]);
+        }
+      }
+    }
+#if PCS_COMMIT_NOWAIT
+    // the ticket store stays behind the adds in program order and the LDS keeps that order; written as a bare
+    // ds_write_b32 -- the compiler puts s_waitcnt lgkmcnt(0) in front of its own store, i.e. the completion wait back
+    if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(commit_lds), "v"(grp + 1) : "memory");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) __hip_atomic_store(commit, grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+    __builtin_amdgcn_s_setprio(0);
+#else
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     __builtin_amdgcn_s_setprio(3);
     PCS_T(const long long tr_c = wall_clock64();)
@@ -352,6 +428,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) __hip_atomic_store(commit, grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_s_setprio(0);
+#endif
     PCS_T(const long long tr_d = wall_clock64(); tr_loop += tr_b - tr_a; tr_ticket += tr_c - tr_b; tr_commit += tr_d - tr_c; ++tr_groups;)
     cur = nxt;
     i = in;
@@ -386,13 +463,13 @@ void trace_prepare(hipStream_t st) {
 }
 #endif
 
-template <int NCTT, int NW, int MINW, int R>
+template <int NCTT, int NW, int MINW, int R, bool TAIL>
 int launch_conv5(const ConvArgs &a, hipStream_t st) {
   using C = Conv5Cfg<NCTT, NW, R>;
   const int64_t nblocks = a.xcd_remap == 2 ? ceil_div(a.ntiles, 8) * 8 * a.ncoltiles : a.ntiles * a.ncoltiles;
   if (nblocks <= 0) return PCS_OK;
   if (nblocks > 0x7FFFFFFF) { set_error("pcs_conv: grid too large"); return PCS_EUNSUPPORTED; }
-  auto kern = conv_os5_kernel<NCTT, NW, MINW, R>;
+  auto kern = conv_os5_kernel<NCTT, NW, MINW, R, TAIL>;
   const size_t lds = C::lds_bytes(a.tile_rows);
   if (lds > kMaxDynLds) { set_error("pcs_conv: tile_rows too large for this column tile"); return PCS_EUNSUPPORTED; }
   static bool attr_set = false;
@@ -409,8 +486,8 @@ int launch_conv5(const ConvArgs &a, hipStream_t st) {
     dbg_last = dbg_key;
     int nb = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), C::NT, lds);
-    fprintf(stderr, "[pcs_conv] wave5<%d,%d,%d,%d> T=%d cin=%d cout=%d grid=%lld lds=%zu resident WG/CU=%d (waves/SIMD=%d)\n", NCTT, NW,
-            MINW, R, a.tile_rows, a.cin, a.cout, (long long)nblocks, lds, nb, nb * NW / 4);
+    fprintf(stderr, "[pcs_conv] wave5<%d,%d,%d,%d%s> T=%d cin=%d cout=%d grid=%lld lds=%zu resident WG/CU=%d (waves/SIMD=%d)\n", NCTT, NW,
+            MINW, R, TAIL ? ",tail" : "", a.tile_rows, a.cin, a.cout, (long long)nblocks, lds, nb, nb * NW / 4);
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(C::NT), lds, st, a);
   return check_launch("pcs_conv_gather_gemm_f32(wave5)");
@@ -434,14 +511,14 @@ int pcs::launch_conv_wave5(ConvArgs a, hipStream_t st) {
   if (force_nctt && nctt > force_nctt) nctt = force_nctt;
   a.ncoltiles = (int)ceil_div(a.cout, 16 * nctt);
   // 4-wave workgroups while two of them fit a CU's LDS, else one 8-wave workgroup
-  const size_t lds = (size_t)((a.tile_rows + 1) * (16 * nctt + 4)) * 4 + 1024;
-  const bool nw8 = force_nw ? force_nw == 8 : 2 * lds > 160 * 1024;
+  const bool nw8 = force_nw ? force_nw == 8 : 2 * conv5_lds_est(a.tile_rows, nctt) > 160 * 1024;
   // groups of 2 row blocks (groups of 3 / 4 were instantiated and measured through round 2: within +-1 % where they fit
   // the registers -- the W stream they save is not what bounds the kernel -- and spilling at 6 / 8 column tiles)
+  const bool tail = (a.cin % 32) != 0;
 #define PCS_CONV5_CASE(N)                                                                           \
   case N:                                                                                           \
-    if (nw8) return launch_conv5<N, 8, 2, 2>(a, st); /* 8-wave workgroups */                          \
-    return launch_conv5<N, 4, 2, 2>(a, st);
+    if (nw8) return tail ? launch_conv5<N, 8, 2, 2, true>(a, st) : launch_conv5<N, 8, 2, 2, false>(a, st);  \
+    return tail ? launch_conv5<N, 4, 2, 2, true>(a, st) : launch_conv5<N, 4, 2, 2, false>(a, st);
   switch (nctt) {
     PCS_CONV5_CASE(2)
     PCS_CONV5_CASE(4)

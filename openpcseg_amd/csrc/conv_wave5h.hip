@@ -13,9 +13,11 @@
 //     weights are converted in the same pass (no separate cast kernel), stored column-major per offset ([column][contraction]) for the forward pass and for dgrad alike;
 //   * column tile f of a 64-column quad owns columns 64 q + 4 n + f (as in the fp32 kernel), so the commit and the
 //     epilogue move 16-byte LDS words.
-// Requires cin % 32 == 0, cout % 4 == 0 and an even number of 16-column tiles (convh_applies): every layer of the
-// segmentors except the 4/5-channel stems and the 1x1x1 convolutions; other shapes are converted to fp32 by the host
-// layer and take the fp32 kernels.
+// Requires cin % 8 == 0 (16-byte row pieces), cin >= 32, cout % 4 == 0 and an even number of 16-column tiles
+// (convh_applies): every layer of the segmentors except the 4/5-channel stems; other shapes are converted to fp32 by
+// the host layer and take the fp32 kernels. cin % 32 != 0 (56, 112, 168, 336 of RPVNet cr 1.75 ...) runs the TAIL
+// instance: the last step holds 8 / 16 / 24 channels, its out-of-range lane groups read a clamped in-row address
+// and are zeroed, and the prepared weights are zero-padded to the full step.
 #include "conv_common.h"
 
 using namespace pcs;
@@ -35,6 +37,13 @@ __device__ __forceinline__ f32x4 mfma_h(Fp16, const uint4 &a, const uint4 &b, f3
 // local column (inside a CT-wide column tile) that lane n of 16-column tile tl feeds -- the interleave the commit and
 // the epilogue of the wave kernels assume (quads of 4 tiles: 64 q + 4 n + f; a pair: + 2 n + f; a single: + n)
 __host__ __device__ inline int h_local_col(int nctt, int tl, int n) {
+#if PCS_COMMIT_ATOMIC
+  // atomic commit (one ds_add_f32 per lane and element): tile tl owns the 16 CONSECUTIVE columns 16 tl .. 16 tl + 15, so
+  // the 16 lanes of a row hit 16 consecutive LDS banks (the 4-interleave put every lane on banks = f mod 4: 4-way
+  // conflicts). The fragment order of the prepared weights makes any column assignment free on the operand side.
+  (void)nctt;
+  return 16 * tl + n;
+#endif
   const int n4 = nctt / 4, n2 = (nctt % 4) / 2;
   if (tl < 4 * n4) return 64 * (tl / 4) + 4 * n + (tl % 4);
   if (tl < 4 * n4 + 2 * n2) return 64 * n4 + 2 * n + (tl - 4 * n4);
@@ -97,21 +106,23 @@ struct Conv5hCfg {
   static constexpr int N4 = NCTT / 4;
   static constexpr int N2 = (NCTT % 4) / 2;
   static constexpr int N1 = NCTT % 2;
-  static constexpr size_t lds_bytes(int T) { return (size_t)((T + 1) * ACS) * 4 + 5 * 33 * 4 + 16; }
+  static constexpr int SINK = kConvSinkRows;
+  static constexpr size_t lds_bytes(int T) { return (size_t)((T + SINK) * ACS) * 4 + 5 * 33 * 4 + 16; }
 };
 
-template <typename HT, int NCTT, int NW, int MINW, int R>
+template <typename HT, int NCTT, int NW, int MINW, int R, bool TAIL>
 __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
   using C = Conv5hCfg<NCTT, NW, R>;
   const int T = a.tile_rows;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float *acc_l = reinterpret_cast<float *>(smem);            // [T+1][ACS], row T = sink for padding rows
-  int *kl_k = reinterpret_cast<int *>(acc_l + (T + 1) * C::ACS);  // [32] offset id
+  float *acc_l = reinterpret_cast<float *>(smem);            // [T+SINK][ACS], rows >= T = sink for padding rows
+  int *kl_k = reinterpret_cast<int *>(acc_l + (T + C::SINK) * C::ACS);  // [32] offset id
   int *kl_s = kl_k + 32;                                     // [32] first pair
   int *kl_m = kl_s + 32;                                     // [32] #pairs
   int *kl_g = kl_m + 32;                                     // [33] first FULL group (prefix over the offsets)
   int *kl_h = kl_g + 33;                                     // [33] first partial group (prefix)
   int *commit = kl_h + 33;
+  const unsigned commit_lds = (unsigned)(size_t)(__attribute__((address_space(3))) int *)commit;  // LDS byte address
   __shared__ int nk_s;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // a scalar: wave-level loops and branches stay uniform
@@ -160,9 +171,9 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
       nk_s = nkk; kl_g[nkk] = total & 0xFFFF; kl_h[nkk] = total >> 16; *commit = 0;
     }
   }
-  {  // zero the tile: (T + 1) * ACS floats, a multiple of four
+  {  // zero the tile: (T + SINK) * ACS floats, a multiple of four
     float4 *z = reinterpret_cast<float4 *>(acc_l);
-    const int n4 = (T + 1) * (C::ACS / 4);
+    const int n4 = (T + C::SINK) * (C::ACS / 4);
     for (int i = tid; i < n4; i += C::NT) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
@@ -176,6 +187,11 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
 #pragma unroll
   for (int t = 0; t < NCTT; ++t) btile[t] = (gt0 + t < a.nt16) ? t : 0;
   const int NS = a.ns;
+  // TAIL: channels 32 (NS-1) + 8 g .. +7 of the last step exist only below cin; lane groups beyond it step back to the
+  // row's last 8 channels (tail_back bytes) and contribute zeros
+  const int tail_over = TAIL ? 32 * (NS - 1) + 8 * g + 8 - a.cin : 0;
+  const bool tail_ok = tail_over <= 0;
+  const int tail_back = tail_ok ? 0 : 2 * tail_over;
 
   struct Frag {  // one 32-channel step: A pieces of the R row blocks + the NCTT B fragments
     uint4 a[R];
@@ -189,8 +205,9 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
     unsigned vmask;
   };
   auto load_frag = [&](Frag &f, const Ctx &cx, int s) {
+    const int aoff = TAIL ? s * 64 - (s == NS - 1 ? tail_back : 0) : s * 64;
 #pragma unroll
-    for (int r = 0; r < R; ++r) f.a[r] = *reinterpret_cast<const uint4 *>(cx.srow[r] + (size_t)s * 64);
+    for (int r = 0; r < R; ++r) f.a[r] = *reinterpret_cast<const uint4 *>(cx.srow[r] + aoff);
 #pragma unroll
     for (int t = 0; t < NCTT; ++t)
       f.b[t] = *reinterpret_cast<const uint4 *>(cx.Wk + ((size_t)btile[t] * NS + s) * 1024);
@@ -260,11 +277,12 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
       for (int t = 0; t < NCTT; ++t) acc[r][t] = (f32x4){0, 0, 0, 0};
     const unsigned vmask = cur.vmask;
     const int nr = __builtin_amdgcn_readfirstlane(cur.nr);  // wave-uniform: a scalar, so the bodies below are real branches
-    auto mfma_frag = [&](const Frag &f) {
+    auto mfma_frag = [&](const Frag &f, auto last_tag) {  // last_tag: the layer's last contraction step
+      constexpr bool LAST = decltype(last_tag)::value;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (r < nr) {  // wave-uniform
-          const bool ok = (vmask >> r) & 1u;
+          const bool ok = ((vmask >> r) & 1u) && (!(TAIL && LAST) || tail_ok);
           uint4 av = f.a[r];
           if (!ok) av = make_uint4(0u, 0u, 0u, 0u);  // padding rows contribute exact zeros
 #pragma unroll
@@ -278,20 +296,20 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
     int s = 0;
     for (; s + 2 < NS; s += 2) {
       load_frag(f1, cur, s + 1);
-      mfma_frag(f0);
+      mfma_frag(f0, std::false_type{});
       load_frag(f0, cur, s + 2);
-      mfma_frag(f1);
+      mfma_frag(f1, std::false_type{});
     }
     if (NS - s == 2) {
       load_frag(f1, cur, s + 1);
-      mfma_frag(f0);
+      mfma_frag(f0, std::false_type{});
       make_ctx(nxt, pr_n, vm_n, nr_n, in);
       load_frag(f0, nxt, 0);
-      mfma_frag(f1);
+      mfma_frag(f1, std::true_type{});
     } else {  // odd number of steps (cin = 96, 160, ...)
       make_ctx(nxt, pr_n, vm_n, nr_n, in);
       load_frag(f1, nxt, 0);
-      mfma_frag(f0);
+      mfma_frag(f0, std::true_type{});
       f0 = f1;
     }
     // ---- in-order commit of the group's row blocks (as conv_wave5.hip: row addresses formed before the ticket wait,
@@ -300,11 +318,47 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) doff[r][j] = __shfl(cur.dloc[r], 4 * g + j, 64) * C::ACS;
+      for (int j = 0; j < 4; ++j) {
+        const int dl = __shfl(cur.dloc[r], 4 * g + j, 64);
+#if PCS_COMMIT_ATOMIC
+        doff[r][j] = (dl >= T ? T + g : dl) * C::ACS;  // padding rows: a sink row of this lane group's own
+#else
+        doff[r][j] = dl * C::ACS;
+#endif
+      }
+#if PCS_COMMIT_ATOMIC
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(doff[r][j]));  // formed BEFORE the ticket wait, not sunk into the critical section
+#endif
     if (lane == 0) {
       while (__hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != grp)
         __builtin_amdgcn_s_sleep(1);
     }
+#if PCS_COMMIT_ATOMIC
+    // ds_add_f32 accumulate in ticket order, never waited for (see conv_wave5.hip); columns 16 t + l15: conflict-free rows
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r < nr) {  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float *d = acc_l + doff[r][j] + l15;
+#pragma unroll
+          for (int t = 0; t < NCTT; ++t) lds_add(d + 16 * t, acc[r][t][j]);
+        }
+      }
+    }
+#if PCS_COMMIT_NOWAIT
+    if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(commit_lds), "v"(grp + 1) : "memory");  // see conv_wave5.hip
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) __hip_atomic_store(commit, grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+    __builtin_amdgcn_s_setprio(0);
+#else
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     __builtin_amdgcn_s_setprio(3);
 #pragma unroll
@@ -342,6 +396,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) __hip_atomic_store(commit, grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_s_setprio(0);
+#endif
     cur = nxt;
     i = in;
   }
@@ -361,13 +416,13 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
                                    });
 }
 
-template <typename HT, int NCTT, int NW, int MINW, int R>
+template <typename HT, int NCTT, int NW, int MINW, int R, bool TAIL>
 int launch_conv5h(const ConvArgsH &a, hipStream_t st) {
   using C = Conv5hCfg<NCTT, NW, R>;
   const int64_t nblocks = a.order ? ceil_div(a.ntiles, 8) * 8 * a.ncoltiles : a.ntiles * a.ncoltiles;
   if (nblocks <= 0) return PCS_OK;
   if (nblocks > 0x7FFFFFFF) { set_error("pcs_conv_h: grid too large"); return PCS_EUNSUPPORTED; }
-  auto kern = conv_os5h_kernel<HT, NCTT, NW, MINW, R>;
+  auto kern = conv_os5h_kernel<HT, NCTT, NW, MINW, R, TAIL>;
   const size_t lds = C::lds_bytes(a.tile_rows);
   if (lds > kMaxDynLds) { set_error("pcs_conv_h: tile_rows too large for this column tile"); return PCS_EUNSUPPORTED; }
   static bool attr_set = false;
@@ -385,11 +440,12 @@ int launch_h(ConvArgsH a, hipStream_t st) {
   static const int force_nctt = getenv("PCS_CONVH_NCTT") ? atoi(getenv("PCS_CONVH_NCTT")) : 0;  // debug: narrower column tiles
   if (force_nctt && nctt > force_nctt && a.cout % (16 * force_nctt) == 0 && !a.stats) nctt = force_nctt;
   a.ncoltiles = (int)ceil_div(a.cout, 16 * nctt);
-  const size_t lds = (size_t)((a.tile_rows + 1) * (16 * nctt + 4)) * 4 + 1024;
-  const bool nw8 = 2 * lds > 160 * 1024;  // 4-wave workgroups while two of them fit a CU's LDS, else one 8-wave workgroup
+  const bool nw8 = 2 * conv5_lds_est(a.tile_rows, nctt) > 160 * 1024;  // 4-wave workgroups while two of them fit a CU's LDS, else one 8-wave workgroup
+  const bool tail = (a.cin % 32) != 0;
 #define PCS_CONV5H_CASE(N)                                                                          \
   case N:                                                                                           \
-    return nw8 ? launch_conv5h<HT, N, 8, 2, 2>(a, st) : launch_conv5h<HT, N, 4, 2, 2>(a, st);
+    if (tail) return nw8 ? launch_conv5h<HT, N, 8, 2, 2, true>(a, st) : launch_conv5h<HT, N, 4, 2, 2, true>(a, st);  \
+    return nw8 ? launch_conv5h<HT, N, 8, 2, 2, false>(a, st) : launch_conv5h<HT, N, 4, 2, 2, false>(a, st);
   switch (nctt) {
     PCS_CONV5H_CASE(2)
     PCS_CONV5H_CASE(4)
@@ -404,8 +460,8 @@ int launch_h(ConvArgsH a, hipStream_t st) {
 }  // namespace
 
 extern "C" size_t pcs_conv_prepared_weights_bytes(int32_t K, int32_t ccon, int32_t ccols) {
-  if (K <= 0 || ccon <= 0 || ccols <= 0 || ccon % 32) return 0;
-  return (size_t)K * (size_t)ceil_div(ccols, 16 * conv_nctt(ccols)) * conv_nctt(ccols) * (size_t)(ccon / 32) * 1024;
+  if (K <= 0 || ccon <= 0 || ccols <= 0 || ccon % 8) return 0;
+  return (size_t)K * (size_t)ceil_div(ccols, 16 * conv_nctt(ccols)) * conv_nctt(ccols) * (size_t)ceil_div(ccon, 32) * 1024;
 }
 
 extern "C" int pcs_conv_h_applies(int32_t cin, int32_t cout, int32_t K) { return convh_applies(cin, cout, K) ? 1 : 0; }
@@ -417,7 +473,7 @@ extern "C" int pcs_conv_prepare_weights_h(const float *W, int32_t K, int32_t A, 
     set_error("pcs_conv_prepare_weights_h: bad args / shape not served by the half kernels");
     return PCS_EINVAL;
   }
-  const int nctt = conv_nctt(ccols), nt16 = (int)ceil_div(ccols, 16 * nctt) * nctt, ns = ccon / 32;
+  const int nctt = conv_nctt(ccols), nt16 = (int)ceil_div(ccols, 16 * nctt) * nctt, ns = (int)ceil_div(ccon, 32);
   const int64_t total = (int64_t)K * nt16 * ns * 64;
   const int grid = stream_grid(total, 256);
   if (dtype == 1)
@@ -437,7 +493,7 @@ extern "C" int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t ci
     set_error("pcs_conv_gather_gemm_h: bad sizes");
     return PCS_EINVAL;
   }
-  if (!convh_applies(cin, cout, K)) { set_error("pcs_conv_gather_gemm_h: shape not served by the half kernels (needs cin %% 32 == 0, cout %% 4 == 0, an even number of 16-column tiles)"); return PCS_EUNSUPPORTED; }
+  if (!convh_applies(cin, cout, K)) { set_error("pcs_conv_gather_gemm_h: shape not served by the half kernels (needs cin %% 8 == 0, cin >= 32, cout %% 4 == 0, an even number of 16-column tiles)"); return PCS_EUNSUPPORTED; }
   if (n_dst == 0) return PCS_OK;
   if (!Wp || !seg || !dst || (n_src > 0 && !src)) { set_error("pcs_conv_gather_gemm_h: null pointer"); return PCS_EINVAL; }
   if ((((uintptr_t)src | (uintptr_t)Wp | (uintptr_t)bias) & 15) || ((uintptr_t)dst & 7)) { set_error("pcs_conv_gather_gemm_h: misaligned pointer"); return PCS_EINVAL; }
@@ -453,6 +509,6 @@ extern "C" int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t ci
   }
   const int nctt = conv_nctt(cout);
   a.nt16 = (int)ceil_div(cout, 16 * nctt) * nctt;
-  a.ns = cin / 32;
+  a.ns = (int)ceil_div(cin, 32);
   return dtype == 1 ? launch_h<Bf16>(a, as_stream(stream)) : launch_h<Fp16>(a, as_stream(stream));
 }

@@ -8,6 +8,13 @@ Same names, argument meaning and outputs as
   map_voxel_predictions R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:441-453 (`out[scene][inv].argmax(1)`)
 Device tensors in, device tensors out (pcs_cylinder_partition_f32, pcs_quantize_*, pcs_voxel_label_vote,
 pcs_rows_argmax_gather_f32); there is no CPU path -- NumPy callers keep the reference's own dataset code.
+
+Documented differences from the NumPy / torch originals (none reachable from the reference's datasets):
+  * a point label outside [0, num_classes) other than 67 raises IndexError, also when it is NEGATIVE (NumPy would
+    wrap-index the vote counter for -num_classes <= label < 0);
+  * map_voxel_predictions skips NaN logits (an all-NaN row gives class 0; torch.argmax returns the NaN's index);
+  * voxelize_with_label(check=True) reads the range flag back (one host sync per frame); check=False returns the
+    device flag as a fifth value so a caller can test it once per batch.
 """
 import torch
 
@@ -25,7 +32,7 @@ def cart2polar(input_xyz):
     return torch.stack((rho, phi, input_xyz[:, 2]), dim=1)
 
 
-def voxelize_with_label(point_coords, point_labels, num_classes):
+def voxelize_with_label(point_coords, point_labels, num_classes, check=True):
     """-> (voxel_coords (m,3) int32, voxel_labels (m,) int64, inds (m,) int64, inverse_map (n,) int64): the reference's
     sparse_quantize(point_coords, return_index, return_inverse) + per-voxel majority label (first arg-max; labels
     equal to 67 are not counted)."""
@@ -33,6 +40,8 @@ def voxelize_with_label(point_coords, point_labels, num_classes):
     vox, inds, inverse = be.quantize(point_coords, (1.0, 1.0, 1.0), True, True)
     labels, bad = be.voxel_label_vote(inverse, point_labels.reshape(-1).long(), vox.shape[0], num_classes,
                                       IGNORE_VOTE_LABEL)
+    if not check:
+        return vox, labels, inds, inverse, bad
     if int(bad.item()):
         raise IndexError("voxelize_with_label: a point label is outside [0, %d) (and is not %d)"
                          % (num_classes, IGNORE_VOTE_LABEL))

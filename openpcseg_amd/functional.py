@@ -349,7 +349,8 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
     output.cmaps.setdefault(output_stride, output_coords)
     output.kmaps = input.kmaps
     if bn_sums is not None:
-        output.bn_sums = bn_sums
+        # bound to the feature tensor they describe: FusedBatchNorm ignores them if feats was replaced or modified
+        output.bn_sums = (bn_sums, output_feats, output_feats._version)
     return output
 
 

@@ -35,13 +35,17 @@ def _stats_group():
     """A process group of its own for the BatchNorm statistics. On the default group the tiny (<= 6 KB) statistics
     all-reduces of backward queue FIFO behind DDP's 25 MB gradient buckets on the same RCCL communicator and stream
     -- each of the 63 BN layers then waits for a bucket to cross the xGMI ring before it can normalise its gradient.
-    A second communicator (high-priority stream on RCCL) lets them overtake. PCS_BN_GROUP=0 keeps the default group."""
+    A second communicator (high-priority stream on RCCL) lets them overtake. Two communicators issued concurrently
+    rely on every rank issuing its collectives in the same order: graphs that differ per rank (find_unused_parameters,
+    data-dependent branches) should set PCS_BN_GROUP=0, the safe fallback, which keeps everything on the default group."""
     import os
     if os.environ.get("PCS_BN_GROUP", "1") == "0":
         return None
-    key = dist.get_world_size(), dist.get_backend()
+    # keyed on the identity of the default group: destroy_process_group() + re-init must not hand back a dead group
+    key = id(dist.distributed_c10d._get_default_group()), dist.get_world_size(), dist.get_backend()
     g = _STATS_GROUP.get(key)
     if g is None:
+        _STATS_GROUP.clear()
         kw = {}
         if dist.get_backend() == "nccl":
             try:
@@ -147,9 +151,14 @@ class FusedBatchNorm(nn.Module):
         if self.training:
             if not self.counted_by_parent:  # a model may bump all its counters with one _foreach_add_ per step
                 self.num_batches_tracked += 1
+            # statistics handed over by the producing convolution are used only for the very tensor they describe
+            # (same object, untouched since): `x.F = dropout(x.F)`, `x.feats += b` in between fall back to the stats pass
+            pre = getattr(input, "bn_sums", None)
+            if pre is not None:
+                sums, of, ver = pre
+                pre = sums if (of is x and x._version == ver) else None
             y = _FusedBN.apply(x, r, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                               self.momentum, relu, self.sync, input.cmaps, input.stride, getattr(input, "bn_sums", None),
-                               tail)
+                               self.momentum, relu, self.sync, input.cmaps, input.stride, pre, tail)
         else:
             inv = torch.rsqrt(self.running_var.double() + self.eps)
             stat = torch.cat([self.running_mean.double(), inv]).contiguous()

@@ -160,8 +160,16 @@ def _cache_key(t):
     """Identity of a tensor's CONTENT for the caches hung on caller tensors: storage address, shape and the in-place
     version counter. An in-place update (`copy_`, `+=`, index assignment) bumps `_version`, so a static input buffer
     refilled between steps never sees a stale table / CSR (the reference recomputes hash, query and sort on every
-    call and has no such hazard)."""
-    return (t.data_ptr(), tuple(t.shape), t._version)
+    call and has no such hazard). Tensors made under torch.inference_mode() get a unique key (recomputed each call)."""
+    try:
+        version = t._version
+    except RuntimeError:  # inference tensors track no version counter: never served from a cache
+        _cache_key.uncached += 1
+        return ("uncached", _cache_key.uncached)
+    return (t.data_ptr(), tuple(t.shape), version)
+
+
+_cache_key.uncached = 0
 
 
 def _cached(holder, name, key, make):

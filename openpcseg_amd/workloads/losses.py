@@ -50,12 +50,14 @@ def lovasz_softmax(probas, labels, ignore=None):
     if probas.numel() == 0:
         return probas.sum() * 0.0
     n, nc = probas.shape
-    cnt = torch.bincount(labels.clamp(0, nc - 1), minlength=nc)
     valid = None
-    if ignore is not None:
+    if ignore is None:
+        cnt = torch.bincount(labels, minlength=nc)
+    else:
+        # presence counts over the VALID points only: an out-of-range ignore label (255, -100, -1) must not be counted
+        # into a clamped class (it would make that class "present" with no foreground point and add a max(err) term)
         valid = labels != ignore
-        if 0 <= ignore < nc:
-            cnt[ignore] = 0
+        cnt = torch.bincount(labels.clamp(0, nc - 1), weights=valid.to(torch.float32), minlength=nc)
     cls = (cnt > 0).nonzero().squeeze(1)  # one host sync
     if cls.numel() == 0:
         return probas.sum() * 0.0

@@ -9,8 +9,9 @@ Needs /root/reference (so it cannot run on the GPU box; the .npz files are commi
     is imported unmodified with import stubs for packages that are absent here.
 Known reference CPU-twin defects are worked around WITHOUT changing semantics:
   - kernel_hash_cpu uses row 0's batch index for every row (hash_cpu.cpp:29): called per batch;
-  - devoxelize_backward_cpu is wrong (devoxelize_cpu.cpp:51-53): not used for goldens.
-Usage: python tests/golden/make_golden.py [models | quantize | config2 | cylinder]
+  - devoxelize_backward_cpu is wrong (devoxelize_cpu.cpp:51-53): replaced by the restatement of
+    devoxelize_cuda.cu:37-57 where a golden needs a backward pass (main_full).
+Usage: python tests/golden/make_golden.py [models | quantize | config2 | config3 | config4 | config5 | cylinder]
 """
 import os
 import sys
@@ -329,34 +330,24 @@ def rpvnet_inputs(seed=5, n_points=2000, h=64, w=512):
 def run_reference_rpvnet():
     """RPVNet (config 5). range_lib has no CPU build in the reference: its two ops are served here by the
     restatement of RL:range_utils/src/*.cu (oracle.map_count / denselize_fwd); everything else is the reference."""
-    from oracle import oracle as orc
-
-    class _Dense(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, feat, cm, pxpy):
-            return torch.from_numpy(orc.denselize_fwd(feat.detach().numpy(), cm.numpy(), pxpy.numpy()))
-
-    fn = types.ModuleType("range_utils.nn.functional")
-    fn.map_count = lambda pxpy, b, h, w: torch.from_numpy(orc.map_count(pxpy.numpy(), b, h, w))
-    fn.denselize = lambda feat, cm, pxpy: _Dense.apply(feat, cm, pxpy)
-    for name in ("range_utils", "range_utils.nn"):
-        sys.modules[name] = types.ModuleType(name)
-    sys.modules["range_utils.nn.functional"] = fn
-    sys.modules["range_utils.nn"].functional = fn
-    sys.modules["range_utils"].nn = sys.modules["range_utils.nn"]
+    fn = install_range_stub()
     mod = import_reference_model("pcseg.model.segmentor.fusion.rpvnet.rpvnet")
     mod.rnf = fn
     # the reference's IF_DIST=False variant is broken (rpvnet.py:574 applies the SparseTensor BatchNorm wrapper
-    # to plain tensors), so the shipped IF_DIST=True variant is used -- in eval mode, where nn.SyncBatchNorm
-    # runs on the CPU (running statistics), and the logits are captured at the classifier.
+    # to plain tensors), so the shipped IF_DIST=True variant is used -- in TRAIN mode: with no process group
+    # initialised nn.SyncBatchNorm computes plain batch statistics (torch/nn/modules/batchnorm.py need_sync), so the
+    # logits stay O(10) and an absolute bound means something. The range image is 16 x 128 so that 2000 rays fill it
+    # (batch statistics over a mostly empty image blow the activations up).
     cfg = _cfg(NAME="RPVNet", IN_FEATURE_DIM=4, BLOCK="ResBlock", NUM_LAYER=[2] * 8,
                PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96], cr=0.25, LABEL_SMOOTHING=0.1)
     cfg["IF_DIST"] = True
     torch.manual_seed(0)
     model = mod.RPVNet(cfg, 20)
     seeded_state(model)
-    model.eval()
-    batch = rpvnet_inputs()
+    model.train()
+    import fullsize
+    fullsize.freeze_dropout(model)  # the range branch's hard-coded Dropout2d(0.2): random masks are not reproducible
+    batch = rpvnet_inputs(h=16, w=128)
     keep = {"rpv_feats": batch["lidar"].feats.numpy().copy(), "rpv_coords": batch["lidar"].coords.numpy().copy(),
             "rpv_labels": batch["targets"].feats.numpy().copy(), "rpv_range_image": batch["range_image"].numpy().copy(),
             "rpv_range_pxpy": batch["range_pxpy"].numpy().copy()}
@@ -365,20 +356,17 @@ def run_reference_rpvnet():
     orig = torch.Tensor.cuda
     torch.Tensor.cuda = lambda self, *a, **k: self
     try:
-        with torch.no_grad():
-            model(batch)
-    except KeyError:
-        pass  # the eval branch wants dataset-only keys (inverse_map, ...) after the classifier ran
+        ret, _, _ = model(batch)
     finally:
         torch.Tensor.cuda = orig
     keep["rpv_logits"] = cap["logits"].numpy()
+    keep["rpv_loss"] = np.array(float(ret["loss"].detach()))
     return keep
 
 
-def main_models():
-    """SPVCNN (config 3) and Cylinder_TS (config 4): the reference's own model code on the reference backend."""
-    import_reference_torchsparse()
-    ts_mod = types.ModuleType("torch_scatter")  # not installed here: torch_scatter semantics via scatter_reduce
+def install_scatter_stub():
+    """torch_scatter is not installed here: its two functions via torch.scatter_reduce (same semantics)."""
+    ts_mod = types.ModuleType("torch_scatter")
 
     def scatter_max(src, index, dim=0):
         m = int(index.max()) + 1
@@ -392,6 +380,39 @@ def main_models():
                                                            include_self=False)
     ts_mod.scatter_max, ts_mod.scatter_mean = scatter_max, scatter_mean
     sys.modules["torch_scatter"] = ts_mod
+
+
+def install_range_stub():
+    """range_lib has no CPU build in the reference: its ops are served by the restatement of RL:range_utils/src/*.cu
+    (oracle.map_count / denselize_fwd / denselize_bwd) -- parity unpinned for exactly these ops."""
+    from oracle import oracle as orc
+
+    class _Dense(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, feat, cm, pxpy):
+            ctx.save_for_backward(cm, pxpy)
+            return torch.from_numpy(orc.denselize_fwd(feat.detach().numpy(), cm.numpy(), pxpy.numpy()))
+
+        @staticmethod
+        def backward(ctx, gout):
+            cm, pxpy = ctx.saved_tensors
+            return torch.from_numpy(orc.denselize_bwd(gout.contiguous().numpy(), cm.numpy(), pxpy.numpy())), None, None
+
+    fn = types.ModuleType("range_utils.nn.functional")
+    fn.map_count = lambda pxpy, b, h, w: torch.from_numpy(orc.map_count(pxpy.numpy(), b, h, w))
+    fn.denselize = lambda feat, cm, pxpy: _Dense.apply(feat, cm, pxpy)
+    for name in ("range_utils", "range_utils.nn"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["range_utils.nn.functional"] = fn
+    sys.modules["range_utils.nn"].functional = fn
+    sys.modules["range_utils"].nn = sys.modules["range_utils.nn"]
+    return fn
+
+
+def main_models():
+    """SPVCNN (config 3) and Cylinder_TS (config 4): the reference's own model code on the reference backend."""
+    import_reference_torchsparse()
+    install_scatter_stub()
     g = {}
     g.update(run_reference_spvcnn())
     g.update(run_reference_cylinder())
@@ -418,51 +439,53 @@ def main_quantize():
     print("wrote quantize_golden.npz:", {k: v.shape for k, v in g.items() if k.endswith("_vox")})
 
 
-CONFIG2_ROW_STEP = 16  # rows of the full-frame logits kept in the fixture (every 16th voxel row)
+def main_full(cfg_name):
+    """BASELINE configs 2-5 at full size (tests/golden/fullsize.py holds the shared definitions): the reference's own
+    segmentor, fp32, ONE full synthetic frame (120 000 rays), TRAIN mode (batch statistics), forward + loss + backward
+    (R:train.py:360-371) on the reference's torchsparse + its compiled CPU backend. Inputs are regenerated from the
+    seed by the tests, so the fixture keeps their CRCs, every 16th row of the logits, float64 column sums over all rows,
+    the loss and per-parameter gradient fingerprints.
+    Substitutions, none of which changes semantics: devoxelize_backward_cpu (wrong in the reference's CPU twin,
+    devoxelize_cpu.cpp:51-53) -> the restatement of devoxelize_cuda.cu:37-57; torch_scatter / range_lib (no CPU build)
+    -> install_scatter_stub / install_range_stub (configs 4 / 5 inherit 'parity unpinned' for those two ops only)."""
+    import time
+    import fullsize as fs
+    ts = import_reference_torchsparse()
+    from oracle import oracle as orc
+    backend = sys.modules["torchsparse.backend"]
 
-
-def main_config2():
-    """BASELINE config 2 at full size: the reference's MinkUNet-18 cr1.0 (PLANES x 1.0, NUM_LAYER [2]*8), fp32, ONE full
-    synthetic frame (seed 0, 120 000 rays, 0.05 m voxels), train mode (batch statistics), forward + loss on the
-    reference's torchsparse + its compiled CPU backend. The input is regenerated from the seed by the tests
-    (openpcseg_amd.workloads.synthetic), so the fixture keeps its checksum, every 16th row of the logits, float64
-    column sums of all rows, and the loss."""
-    import_reference_torchsparse()
-    from openpcseg_amd.workloads.synthetic import make_batch
-    mod = import_reference_minkunet()
-    cfg = _AttrDict(NAME="MinkUNet", IGNORE_LABEL=0, IN_FEATURE_DIM=4, BLOCK="ResBlock", NUM_LAYER=[2] * 8,
-                    PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96], cr=1.0, DROPOUT_P=0.0, LABEL_SMOOTHING=0.1,
-                    IF_DIST=False)
+    def devox_bwd(gout, idx, w, n):
+        return torch.from_numpy(orc.devoxelize_bwd(gout.contiguous().numpy(), idx.numpy(), w.numpy(), int(n)))
+    backend.devoxelize_backward_cpu = devox_bwd
+    install_scatter_stub()
+    rnf = install_range_stub()
+    dotted, cls = fs.MODEL_PATH[cfg_name]
+    mod = import_reference_model(dotted)
+    if cfg_name == "config5":
+        mod.rnf = rnf
+    n_points = int(os.environ["PCS_GOLDEN_POINTS"]) if os.environ.get("PCS_GOLDEN_POINTS") else None
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    model = mod.MinkUNet(cfg, 20)
+    model = getattr(mod, cls)(_AttrDict(fs.MODEL_CFG[cfg_name]), 20)
     seeded_state(model)
     model.train()
-    batch = make_batch([0])
-    feats, coords = batch["lidar"].feats.clone(), batch["lidar"].coords.clone()
-    cap = {}
-    model.classifier.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", o.detach().clone()))
+    fs.freeze_dropout(model)
+    batch = fs.build_inputs(cfg_name, ts.SparseTensor, n_points)
+    g = fs.input_crcs(cfg_name, batch)
     orig = torch.Tensor.cuda
     torch.Tensor.cuda = lambda self, *a, **k: self
-    import time
     t0 = time.time()
     try:
-        ret, _, _ = model(batch)
+        logits, loss = fs.run_train_step(cfg_name, model, batch)
     finally:
         torch.Tensor.cuda = orig
-    print("reference forward: %.1f s" % (time.time() - t0))
-    logits = cap["logits"].numpy()
-    g = {"n_voxels": np.array(coords.shape[0]),
-         "coords_crc": np.array(zlib.crc32(coords.numpy().tobytes())),
-         "feats_crc": np.array(zlib.crc32(feats.numpy().tobytes())),
-         "labels_crc": np.array(zlib.crc32(batch["targets"].feats.numpy().tobytes())),
-         "row_step": np.array(CONFIG2_ROW_STEP),
-         "logits_rows": logits[::CONFIG2_ROW_STEP].copy(),
-         "logits_colsum": logits.astype(np.float64).sum(0),
-         "logits_abssum": np.abs(logits.astype(np.float64)).sum(0),
-         "loss": np.array(float(ret["loss"].detach()))}
-    np.savez_compressed(os.path.join(OUT, "config2_golden.npz"), **g)
-    print("wrote config2_golden.npz: voxels", coords.shape[0], "rows kept", g["logits_rows"].shape, "loss", g["loss"])
+    print("%s reference forward + backward: %.1f s" % (cfg_name, time.time() - t0))
+    g.update(fs.logits_fingerprint(logits, loss))
+    g.update(fs.grad_fingerprint(fs.model_grads(model)))
+    g["n_points"] = np.array(-1 if n_points is None else n_points)
+    np.savez_compressed(os.path.join(OUT, "%s_golden.npz" % cfg_name), **g)
+    print("wrote %s_golden.npz: rows" % cfg_name, logits.shape, "kept", g["logits_rows"].shape, "loss", loss,
+          "|logit| max %.2f" % np.abs(logits).max(), "params with grad", len(g["grad_names"]))
 
 
 def main_cylinder():
@@ -505,8 +528,8 @@ def main_cylinder():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cylinder":
         main_cylinder()
-    elif len(sys.argv) > 1 and sys.argv[1] == "config2":
-        main_config2()
+    elif len(sys.argv) > 1 and sys.argv[1] in ("config2", "config3", "config4", "config5"):
+        main_full(sys.argv[1])
     elif len(sys.argv) > 1 and sys.argv[1] == "models":
         main_models()
     elif len(sys.argv) > 1 and sys.argv[1] == "quantize":

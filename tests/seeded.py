@@ -19,6 +19,9 @@ def seeded_state(model):
             v = 0.5 + r
         elif name.endswith("running_mean"):
             v = 0.2 * (r - 0.5)
+        elif t.dim() == 4:  # Conv2d (out, in, kh, kw) of RPVNet's range branch: its un-normalised 1x1 shortcuts must not amplify
+            fan = t.shape[1] * t.shape[2] * t.shape[3]
+            v = (r - 0.5) * 2.0 / np.sqrt(fan) * 1.7
         elif t.dim() >= 2:
             fan = t.shape[-2] * (t.shape[0] if t.dim() == 3 else 1)
             v = (r - 0.5) * 2.0 / np.sqrt(fan) * 1.7

@@ -85,6 +85,14 @@ FWD_CASES = [
     (2, 64, 64, None), (2, 128, 64, 256), (2, 64, 64, 192), (4, 64, 32, 224), (4, 128, 128, 176), (8, 128, 256, 192),
     (1, 96, 96, 384), (1, 128, 96, None), (1, 96, 96, 128), (1, 96, 128, None),
 ]
+# BASELINE config 5 widths (RPVNet mk34 cr 1.75: PLANES x 1.75 = 56/56/112/224/448/448/224/168/168, decoder concat
+# inputs 672/336/224/224, R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:211-213) and other cin % 32 != 0 shapes: the
+# TAIL instances of conv_os5_kernel / conv_os5h_kernel (partial last contraction block, odd block counts, column
+# tiles that pad 56 -> 64, 112 -> 128, 168 -> 192, 336 -> 384 columns)
+TAIL_CASES = [(1, 56, 56, None), (2, 56, 112, None), (2, 112, 112, None), (1, 168, 168, None), (1, 224, 168, 256),
+              (4, 336, 224, None), (8, 224, 448, None), (8, 672, 448, None), (8, 448, 448, 224),
+              (2, 48, 48, None), (4, 100, 64, None), (4, 36, 24, 128), (8, 44, 200, None)]
+FWD_CASES += TAIL_CASES
 
 
 @pytest.mark.parametrize("stride,cin,cout,tile", FWD_CASES)
@@ -132,7 +140,8 @@ def test_conv_is_independent_of_the_tile_order(hip, levels, stride, cin, cout, t
                            hip.conv_gather_gemm_h(xh, wp, 27, cout, entry.fwd, tile_rows=tile, ordered=False))
 
 
-@pytest.mark.parametrize("stride,cin,cout", [(4, 128, 128), (4, 192, 128), (8, 256, 256), (8, 384, 256), (1, 128, 96)])
+@pytest.mark.parametrize("stride,cin,cout", [(4, 128, 128), (4, 192, 128), (8, 256, 256), (8, 384, 256), (1, 128, 96),
+                                             (2, 112, 56), (4, 336, 224), (1, 168, 168), (8, 672, 448), (4, 100, 36)])
 def test_conv_backward_dense_map(hip, levels, stride, cin, cout):
     """dgrad (conv_os5_kernel on the input-sorted map, transposed weights) and wgrad (wgrad2_kernel + split reduction)
     vs orc_conv_bwd on a BASELINE-density map."""
@@ -224,7 +233,10 @@ def close_half(y, ref, dtype):
 
 
 HALF_CASES = [(4, 128, 128, None), (4, 192, 128, 128), (8, 256, 256, None), (8, 384, 256, 256), (1, 96, 96, 384),
-              (1, 128, 96, None), (2, 64, 64, None), (4, 160, 96, 112), (8, 256, 20, None)]
+              (1, 128, 96, None), (2, 64, 64, None), (4, 160, 96, 112), (8, 256, 20, None),
+              # config 5 widths and other cin % 32 != 0 rows (cin % 8 == 0): TAIL instance, zero-padded weight fragments
+              (1, 56, 56, None), (2, 112, 112, None), (1, 168, 168, None), (4, 336, 224, None), (8, 224, 448, None),
+              (8, 672, 448, None), (4, 72, 40, 128), (2, 40, 56, None)]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -250,7 +262,8 @@ def test_half_conv_forward_dense_map(hip, levels, dtype, stride, cin, cout, tile
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("stride,cin,cout", [(4, 128, 128), (8, 384, 256), (1, 128, 96)])
+@pytest.mark.parametrize("stride,cin,cout", [(4, 128, 128), (8, 384, 256), (1, 128, 96), (2, 112, 56), (4, 336, 224),
+                                             (8, 672, 448)])
 def test_half_conv_backward_dense_map(hip, levels, dtype, stride, cin, cout):
     """dgrad on the half kernel (weights re-packed with transpose=True) and the fp32-accumulated weight gradient from
     half operands (pcs_conv_wgrad_h) vs orc_conv_bwd on the half-rounded operands."""

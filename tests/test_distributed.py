@@ -148,7 +148,7 @@ def test_bench_two_ranks_on_one_device():
     env = dict(os.environ, PCS_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--frames-per-gpu", "2"]
+           "--frames-per-gpu", "2", "--no-amp-line"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -168,10 +168,10 @@ def test_bench_one_rank_over_rccl():
     import json
     import subprocess
 
-    def run(env_extra, launcher):
+    def run(env_extra, launcher, extra=()):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", PCS_BENCH_PREHEAT="0", **env_extra)  # same number of optimizer steps
         cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--frames-per-gpu", "2",
-                          "--no-cpu-baseline"]
+                          "--no-cpu-baseline"] + list(extra)
         out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
         assert out.returncode == 0, out.stderr[-3000:]
         lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -181,9 +181,19 @@ def test_bench_one_rank_over_rccl():
     rccl = run({"PCS_BENCH_FORCE_DIST": "1", "PCS_SYNC_WORLD1": "1"},
                [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                 "--master-port", str(_free_port())])
-    plain = run({}, [sys.executable])
+    plain = run({}, [sys.executable], ["--no-amp-line"])
     assert rccl["n_gpus"] == 1 and rccl["value"] > 0 and rccl["roofline"]["launches"] > 0
     assert abs(rccl["config"]["loss"] - plain["config"]["loss"]) <= 2e-3 * abs(plain["config"]["loss"])
+    # the default run carries the bf16 step as a secondary record (the reference trains under --amp)
+    assert rccl["amp_bf16"]["value"] > 0 and rccl["amp_bf16"]["roofline"]["launches"] > 0 and "amp_bf16" not in plain
+    # device trace of one step of the distributed job: when RCCL launches kernels for the gradient buckets (a one-rank
+    # communicator may be served by copies), the first of them must start before backward's last conv has finished --
+    # i.e. DDP's bucketed all-reduce overlaps backward instead of trailing it
+    comm = rccl.get("comm")
+    assert comm is not None and "error" not in comm, comm
+    print("one-rank RCCL comm record:", comm)
+    if comm.get("rccl_kernels", 0) > 0 and comm.get("first_rccl_kernel_before_last_conv_ends") is not None:
+        assert comm["first_rccl_kernel_before_last_conv_ends"], comm
 
 
 def _nccl_bn_worker(rank, world, port, q):
@@ -253,3 +263,5 @@ def test_bench_two_ranks_over_rccl():
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["value"] > 0
+    assert res["comm"]["rccl_kernels"] > 0 and res["comm"]["first_rccl_kernel_before_last_conv_ends"], res["comm"]
+    assert res["amp_bf16"]["value"] > 0

@@ -218,6 +218,32 @@ def test_batched_lovasz_equals_the_per_class_loop():
         assert abs(float(a.detach()) - float(b.detach())) <= 1e-6 and (ga - gb).abs().max() <= 1e-7
     empty = torch.zeros(4, 20).softmax(1)
     assert float(lovasz_softmax(empty, torch.zeros(4, dtype=torch.long), ignore=0)) == 0.0
+    # ignore labels OUTSIDE [0, nc): the ignored points must not make a clamped class "present"
+    for ign in (255, -100, -1):
+        logits = torch.randn(4000, 20, requires_grad=True)
+        lab = torch.randint(0, 18, (4000,))      # classes 18, 19 absent: 19 is where a clamped 255 would land, 0 for negatives
+        lab[lab == 0] = 5
+        lab[torch.rand(4000) < 0.1] = ign
+        p = logits.softmax(1)
+        a, b = lovasz_softmax(p, lab, ignore=ign), lovasz_softmax_per_class(p, torch.where(lab == ign, lab, lab), ignore=ign)
+        ga, = torch.autograd.grad(a, logits, retain_graph=True)
+        gb, = torch.autograd.grad(b, logits)
+        assert abs(float(a.detach()) - float(b.detach())) <= 1e-6 and (ga - gb).abs().max() <= 1e-7, (ign, float(a), float(b))
+
+
+def test_cpu_baseline_worker_times_one_frame():
+    """bench.py's cpu_baseline leg (the reference's compiled CPU backend under the workload model, one frame, no
+    extrapolation) on a shrunken frame: the record carries value = 1 / (fwd + bwd), cores, kind and the sample text."""
+    import json
+    import subprocess
+    import sys as _sys
+    env = dict(os.environ, PCS_CPU_BASELINE_RAYS="1200", OMP_NUM_THREADS="8")
+    out = subprocess.run([_sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-baseline-worker", "1"], env=env,
+                         capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["kind"] in ("reference", "port") and rec["unit"] == "frames/s" and rec["cores"] in (1, 8)
+    assert abs(rec["value"] - 1.0 / rec["seconds_per_frame"]) <= 0.06 * rec["value"] and "1200 rays" in rec["sample"]
 
 
 def test_launch_shape_helpers_are_host_functions():
@@ -237,4 +263,11 @@ def test_launch_shape_helpers_are_host_functions():
     assert lib.pcs_conv_uses_tile_order(16, 32, 27, 0) == 0 and lib.pcs_conv_uses_tile_order(4, 32, 27, 1) == 0
     assert lib.pcs_conv_emits_bn_partials(128, 128, 27, 288, 0) == 1 and lib.pcs_conv_emits_bn_partials(96, 96, 27, 384, 0) == 1
     assert lib.pcs_conv_emits_bn_partials(5, 33, 27, 128, 0) == 0
+    # BASELINE config 5 (RPVNet cr 1.75) widths are served by the wave kernels in fp32 AND in half (round 3: TAIL instances)
+    for ci, co in ((56, 56), (56, 112), (112, 112), (224, 168), (168, 168), (336, 224), (224, 448), (672, 448), (448, 448)):
+        assert lib.pcs_conv_uses_tile_order(ci, co, 27, 0) == 1 and lib.pcs_conv_uses_tile_order(ci, co, 27, 1) == 1, (ci, co)
+        assert lib.pcs_conv_h_applies(ci, co, 27) == 1 and lib.pcs_conv_h_applies(co, ci, 8) == 1
+        assert lib.pcs_conv_prepared_weights_bytes(27, ci, co) > 0
+    assert lib.pcs_conv_h_applies(100, 64, 27) == 0 and lib.pcs_conv_uses_tile_order(100, 64, 27, 0) == 1  # cin % 4: fp32 only
+    assert lib.pcs_conv_h_applies(51, 51, 27) == 0 and lib.pcs_conv_uses_tile_order(51, 51, 27, 0) == 0   # cr 1.6: generic kernel
 

@@ -146,8 +146,9 @@ def _run_cylinder(env, gold):
 
 def _run_rpvnet(env, gold):
     """Config 5 (range-point-voxel fusion): adds range_utils.map_count / denselize (K13/K14) to the surface.
-    Eval mode with the shipped IF_DIST=True variant (the reference's IF_DIST=False RPVNet is broken,
-    rpvnet.py:574); logits captured at the classifier."""
+    TRAIN mode with the shipped IF_DIST=True variant (the reference's IF_DIST=False RPVNet is broken, rpvnet.py:574;
+    without a process group nn.SyncBatchNorm computes plain batch statistics): logits are O(10), the bound is the
+    absolute 1e-3 of north_star; logits captured at the classifier."""
     from openpcseg_amd.sparse import SparseTensor
     from seeded import seeded_state
     mg, mod = _load("pcseg.model.segmentor.fusion.rpvnet.rpvnet")
@@ -157,22 +158,22 @@ def _run_rpvnet(env, gold):
     cfg["IF_DIST"] = True
     model = mod.RPVNet(cfg, 20)
     seeded_state(model)
-    model.to(env.dev).eval()
+    model.to(env.dev).train()
+    import fullsize
+    fullsize.freeze_dropout(model)  # as the fixture: the range branch's Dropout2d(0.2) masks are not reproducible
     coords = env.t(gold["rpv_coords"])
     batch = {"lidar": SparseTensor(env.t(gold["rpv_feats"]), coords),
-             "targets": SparseTensor(env.t(gold["rpv_labels"]), coords),
+             "targets": SparseTensor(env.t(gold["rpv_labels"]), coords), "offset": None,
              "range_image": env.t(gold["rpv_range_image"]), "range_pxpy": env.t(gold["rpv_range_pxpy"])}
     cap = {}
     model.classifier.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", o.detach()))
-    try:
-        with torch.no_grad():
-            model(batch)
-    except KeyError:
-        pass  # the eval branch wants dataset-only keys (inverse_map, ...) after the classifier ran
-    # eval-mode BatchNorm runs on its initial running stats (identity), so the seeded weights grow the logits to
-    # ~1e9: the bound is relative (fp32 summation order is the only difference)
+    ret, _, _ = model(batch)
     ref = gold["rpv_logits"]
-    assert np.abs(_np(cap["logits"]) - ref).max() < 1e-5 * np.abs(ref).max()
+    assert np.abs(ref).max() < 100.0  # the fixture itself must be in the regime where an absolute bound is meaningful
+    assert np.abs(_np(cap["logits"]) - ref).max() < 1e-3
+    assert abs(float(ret["loss"].detach()) - float(gold["rpv_loss"])) < 1e-3
+    ret["loss"].backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
 # ---- CPU oracle backend (host logic; runs in the build container) -------------------------------------------------
@@ -213,67 +214,4 @@ def test_reference_rpvnet_on_hip(gold, env_hip):
     _run_rpvnet(env_hip, gold)
 
 
-# ---- BASELINE config 2 at FULL size: MinkUNet-18 cr1.0, one 120k-point frame, fp32 -------------------------------
-def _config2_batch(env):
-    import zlib
-    from openpcseg_amd.sparse import SparseTensor
-    from openpcseg_amd.workloads.synthetic import make_batch
-    g = np.load(os.path.join(ROOT, "tests", "golden", "config2_golden.npz"))
-    b = make_batch([0])
-    feats, coords, labels = b["lidar"].feats, b["lidar"].coords, b["targets"].feats
-    # the fixture holds checksums of the inputs the reference saw: the regenerated frame must be that frame
-    assert coords.shape[0] == int(g["n_voxels"])
-    assert zlib.crc32(coords.numpy().tobytes()) == int(g["coords_crc"])
-    assert zlib.crc32(feats.numpy().tobytes()) == int(g["feats_crc"])
-    assert zlib.crc32(labels.numpy().tobytes()) == int(g["labels_crc"])
-    dc = coords.to(env.dev)
-    return g, {"lidar": SparseTensor(feats.to(env.dev), dc), "targets": SparseTensor(labels.to(env.dev), dc),
-               "offset": None}
-
-
-def _check_config2(g, logits, loss):
-    step = int(g["row_step"])
-    ref = g["logits_rows"]
-    # per-point logits within 1e-3 of the reference's (north_star), relative to the logit scale of this seeded model
-    scale = max(1.0, float(np.abs(ref).max()))
-    assert np.abs(logits[::step] - ref).max() < 1e-3 * scale, (np.abs(logits[::step] - ref).max(), scale)
-    # all rows (not only the sampled ones): float64 column sums and absolute sums
-    n = logits.shape[0]
-    assert np.abs(logits.astype(np.float64).sum(0) - g["logits_colsum"]).max() < 1e-3 * scale * np.sqrt(n)
-    assert np.allclose(np.abs(logits.astype(np.float64)).sum(0), g["logits_abssum"], rtol=1e-4)
-    assert abs(loss - float(g["loss"])) < 1e-3 * max(1.0, abs(float(g["loss"])))
-
-
-@pytest.mark.gpu
-def test_config2_full_frame_reference_minkunet18_on_hip(env_hip):
-    """The reference's MinkUNet source, MinkUNet-18 cr1.0, ONE full frame (96 685 voxels), train mode: logits and loss
-    through libpcseg_hip.so vs the reference run on its own CPU backend (make_golden.py config2, 49 s there)."""
-    from seeded import seeded_state
-    mg, mod = _load("pcseg.model.segmentor.voxel.minkunet.minkunet")
-    g, batch = _config2_batch(env_hip)
-    cfg = mg._AttrDict(NAME="MinkUNet", IGNORE_LABEL=0, IN_FEATURE_DIM=4, BLOCK="ResBlock", NUM_LAYER=[2] * 8,
-                       PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96], cr=1.0, DROPOUT_P=0.0, LABEL_SMOOTHING=0.1,
-                       IF_DIST=False)
-    model = mod.MinkUNet(cfg, 20)
-    seeded_state(model)
-    model.to(env_hip.dev).train()
-    cap = {}
-    model.classifier.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", o.detach()))
-    ret, _, _ = model(batch)
-    _check_config2(g, _np(cap["logits"]), float(ret["loss"].detach()))
-    ret["loss"].backward()
-    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
-
-
-@pytest.mark.gpu
-def test_config2_full_frame_workload_minkunet18_on_hip(env_hip):
-    """The same frame and weights through this package's MinkUNet workload (fused BN / ReLU / residual passes, one-kernel
-    voxel_to_point map, conv-kernel classifier) -- what bench.py times -- against the same reference logits."""
-    from seeded import seeded_state
-    from openpcseg_amd.workloads.minkunet import MK18_LAYERS, MinkUNet
-    g, batch = _config2_batch(env_hip)
-    model = MinkUNet(num_class=20, num_layer=MK18_LAYERS, cr=1.0)
-    seeded_state(model)
-    model.to(env_hip.dev).train()
-    out = model(batch)
-    _check_config2(g, _np(out["logits"]), float(out["loss"].detach()))
+# BASELINE configs 2-5 at FULL size (logits AND gradients): tests/test_fullsize_parity.py

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-shape timing table of the fused conv / wgrad launches inside one MinkUNet-34 training
-step (HIP events on the launch stream). Usage: python tools/conv_layer_table.py [frames]"""
+step (HIP events on the launch stream). Usage: python tools/conv_layer_table.py [frames] [cr] [off|bf16|fp16]
+cr 1.75 on 4 frames = the voxel branch of BASELINE config 5 (RPVNet mk34 cr 1.75: widths 56/112/224/448/168, concat inputs
+672/336/224; BATCH_SIZE_PER_GPU 4, R:tools/cfgs/fusion/semantic_kitti/rpvnet_mk34_cr17_5.yaml)."""
 import collections
 import os
 import sys
@@ -16,13 +18,15 @@ from openpcseg_amd.workloads.synthetic import make_batch  # noqa: E402
 
 def main():
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    cr = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+    amp = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(sys.argv[3]) if len(sys.argv) > 3 else None
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    model = MinkUNet(num_class=20, num_layer=MK34_LAYERS).to(dev).train()
+    model = MinkUNet(num_class=20, num_layer=MK34_LAYERS, cr=cr).to(dev).train()
     batch = to_device(make_batch(list(range(frames))), dev)
     be = native.backend()
     rec = []
-    orig_g, orig_w = be.conv_gather_gemm, be.conv_wgrad
+    orig_g, orig_w, orig_gh, orig_wh = be.conv_gather_gemm, be.conv_wgrad, be.conv_gather_gemm_h, be.conv_wgrad_h
 
     def timed(kind, fn, shape_of):
         def wrapped(*a, **k):
@@ -36,12 +40,16 @@ def main():
 
     # the map object is kept and its pair count read after the step (reading it at launch time would wait for the GPU)
     be.conv_gather_gemm = timed("gemm", orig_g, lambda src, w, km, *r, **k: (km, w.shape[0], w.shape[1], w.shape[2]))
-    be.conv_wgrad = timed("wgrad", orig_w, lambda fa, fb, km, ac: (km, km.K, fa.shape[1], fb.shape[1]))
-    for it in range(2):
+    be.conv_wgrad = timed("wgrad", orig_w, lambda fa, fb, km, ac, **k: (km, km.K, fa.shape[1], fb.shape[1]))
+    be.conv_gather_gemm_h = timed("gemmh", orig_gh, lambda src, wp, k_, cout, km, *r, **k: (km, k_, src.shape[1], cout))
+    be.conv_wgrad_h = timed("wgradh", orig_wh, lambda fa, fb, km, ac: (km, km.K, fa.shape[1], fb.shape[1]))
+    for it in range(3):
         rec.clear()
-        out = model(fresh(batch))
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            out = model(fresh(batch))
         out["loss"].backward()
         torch.cuda.synchronize()
+    print("MinkUNet-34 cr %g, %d frames, %s" % (cr, frames, "fp32" if amp is None else str(amp)))
     agg = collections.OrderedDict()
     for kind, (km, k_, ci_, co_), e0, e1 in rec:
         key = (kind, km.n_dst, km.num_pairs, k_, ci_, co_)
@@ -49,12 +57,15 @@ def main():
         t[0] += 1
         t[1] += e0.elapsed_time(e1)
     print("%-6s %9s %9s %3s %4s %4s %4s %9s %8s %7s" % ("kind", "n_dst", "pairs", "K", "cin", "cout", "n", "ms_total", "us/call", "TF/s"))
-    tot = {"gemm": 0.0, "wgrad": 0.0}
+    tot = {"gemm": 0.0, "wgrad": 0.0, "gemmh": 0.0, "wgradh": 0.0}
+    flt = dict(tot)
     for (kind, n, p, k, ci, co), (cnt, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         fl = 2.0 * p * ci * co * cnt
         tot[kind] += ms
+        flt[kind] += fl
         print("%-6s %9d %9d %3d %4d %4d %4d %9.2f %8.0f %7.1f" % (kind, n, p, k, ci, co, cnt, ms, ms * 1e3 / cnt, fl / ms / 1e9))
     print("total ms:", tot)
+    print("TFLOP/s over all launches:", {k: round(flt[k] / tot[k] / 1e9, 1) for k in tot if tot[k] > 0})
 
 
 if __name__ == "__main__":
