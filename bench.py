@@ -412,6 +412,9 @@ def main():
     ap.add_argument("--amp", choices=["off", "bf16", "fp16"], default="off",
                     help="mixed precision like the reference's --amp (second bench line; the headline metric is fp32)")
     ap.add_argument("--no-amp-line", action="store_true", help="skip the secondary bf16 record of the default run")
+    ap.add_argument("--wgrad", choices=["fp32", "bf16x3"], default="bf16x3",
+                    help="fp32 weight gradient of the >= 96-channel convolutions: fp32 MFMA, or fp32 operands as three bf16 planes "
+                         "on the 16-bit MFMAs (fp32-grade: six plane products, error vs float64 <= 2x the fp32 MFMA path's)")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -442,6 +445,8 @@ def main():
     batch = to_device(make_batch(seeds), dev)
     n_vox = batch["lidar"].C.shape[0]
     be = native.backend()
+    from openpcseg_amd import functional as pcsF
+    pcsF.set_wgrad_policy(args.wgrad)
 
     def measure(amp):
         """One bench line: fresh model / optimizer (same seed), preheat, W warm-up steps, K timed steps."""
@@ -527,7 +532,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": amp or "f32", "data": "synthetic",
             "config": {"workload": workload(amp), "frames_per_gpu": args.frames_per_gpu,
                        "global_batch": args.frames_per_gpu * world, "voxels_per_gpu_batch": n_vox,
-                       "parallelism": "dp%d" % world, "loss": head["loss"]},
+                       "parallelism": "dp%d" % world, "loss": head["loss"],
+                       "wgrad": ("fp32 MFMA (wgrad2_kernel)" if args.wgrad == "fp32" or amp is not None else
+                                 "bf16x3 on the >= 96-channel layers: fp32 operands split into three bf16 planes, six plane "
+                                 "products accumulated in fp32 on the 16-bit MFMAs (fp32-grade, tested against float64); fp32 MFMA elsewhere")},
             "roofline": head["roofline"],
         }
         if head["comm"] is not None:

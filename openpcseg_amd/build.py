@@ -16,6 +16,10 @@ LIB_PATH = os.path.join(LIB_DIR, "libpcseg_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fPIC",
          "-Wno-unused-value"]
+# per-file additions. The wave kernels: no SLP vectorisation -- it packs the 48 accumulate adds of the ticket-ordered commit
+# into v_pk_add_f32 at the price of two register moves each, inside the one serial chain of a workgroup
+EXTRA_FLAGS = {"conv_wave5.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"],
+               "conv_wave5h.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"]}
 
 
 def sources():
@@ -41,7 +45,7 @@ def build(force=False, verbose=False):
     for s in sources():
         o = os.path.join(LIB_DIR, os.path.basename(s) + ".o")
         objs.append(o)
-        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

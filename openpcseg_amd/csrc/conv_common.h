@@ -18,10 +18,17 @@
 #define PCS_ALIAS 0    /* wave5: 1 every offset reads W[0], 2 A rows read sequentially instead of gathered */
 #endif
 #ifndef PCS_COMMIT_ATOMIC
-#define PCS_COMMIT_ATOMIC 1  /* wave5 / wave5h: commit with LDS float atomics in ticket order (0: read-add-write under the ticket) */
+#define PCS_COMMIT_ATOMIC 0  /* wave5 / wave5h: 1 = commit with ds_add_f32 in ticket order. Measured in round 3 and left off: the LDS
+                                float atomic runs at ~1 lane per 4 clocks on gfx950 -- every shape 2-3x slower, fp32 and bf16 alike
+                                (profiles/round3_commit_ab.md). 0 = read-add-write under the ticket. */
 #endif
 #ifndef PCS_COMMIT_NOWAIT
-#define PCS_COMMIT_NOWAIT 1  /* atomic commit: hand the ticket on without waiting for the atomics to complete */
+#define PCS_COMMIT_NOWAIT 1  /* hand the ticket on with a bare ds_write_b32 behind the tile writes instead of waiting for their completion
+                                (the LDS executes one wave's instructions in order; the next owner reads only after it has read the ticket) */
+#endif
+#ifndef PCS_COMMIT_PHASED
+#define PCS_COMMIT_PHASED 1  /* read-add-write commit as three fenced phases (all reads, all adds, all writes) with the row addresses
+                                formed before the ticket wait; 0 = the compiler's interleaving (round 2) */
 #endif
 #if PCS_TRACE
 #define PCS_T(...) __VA_ARGS__

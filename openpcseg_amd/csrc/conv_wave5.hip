@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
   int *kl_h = kl_g + 33;                                     // [33] first partial group (prefix)
   int *commit = kl_h + 33;
   const unsigned commit_lds = (unsigned)(size_t)(__attribute__((address_space(3))) int *)commit;  // LDS byte address
+  const unsigned acc_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float *)acc_l;
   __shared__ int nk_s;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // a scalar: wave-level loops and branches stay uniform
@@ -228,7 +229,13 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
     load_frag(f0, cur, 0);
   }
   PCS_T(const long long tr_start = wall_clock64();)
-  for (int grp = wid; grp < total_grp; grp += C::NW) {  // wave-uniform loop, no barrier inside
+  // One group = NRC row blocks of one offset: R for the full groups, 1 for the partial ones (R = 2). A lambda per NRC so
+  // that each of the two group loops below has ONE straight-line body: with both bodies behind a branch inside one loop the
+  // register allocator resolved the loop-carried operand registers (the next group's prefetched first block) with ~30
+  // copies at the join -- and the s_waitcnt vmcnt(0) those copies need sat in front of every ticket wait.
+  static_assert(R == 2, "partial groups are handled as single row blocks");
+  auto run_group = [&](const int grp, auto nrc_tag) {
+    constexpr int NRC = decltype(nrc_tag)::value;
     PCS_T(const long long tr_a = wall_clock64();)
     const int grpn = grp + C::NW < total_grp ? grp + C::NW : grp;
     int in = i, pidx_n[R], nr_n; unsigned vm_n;
@@ -243,7 +250,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
 #pragma unroll
       for (int t = 0; t < NCTT; ++t) acc[r][t] = (f32x4){0, 0, 0, 0};
     const unsigned vmask = cur.vmask;
-    const int nr = __builtin_amdgcn_readfirstlane(cur.nr);  // wave-uniform: a scalar, so the bodies below are real branches
+    constexpr int nr = NRC;
     // MFMAs of one 16-channel block for the first NR row blocks of the group (NR is wave-uniform)
     // last_tag: the block is the layer's last one (only there can lane groups lie beyond cin)
     auto mfma_frag = [&](const Frag &f, auto nr_tag, auto last_tag) {
@@ -313,10 +320,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
     PCS_PIPE5(load_frag(f1, nxt, 0), f0, NRV, true)                                                \
     f0 = f1;                                                                                       \
   }
-    if (R >= 4 && nr == 4) { PCS_BODY5((R >= 4 ? 4 : 1)) }
-    else if (R >= 3 && nr == 3) { PCS_BODY5((R >= 3 ? 3 : 1)) }
-    else if (R >= 2 && nr == 2) { PCS_BODY5((R >= 2 ? 2 : 1)) }
-    else { PCS_BODY5(1) }
+    { PCS_BODY5(NRC) }
 #undef PCS_BODY5
 #undef PCS_PIPE5
     // ---- in-order commit of the group's row blocks -------------------------------------------------------
@@ -338,11 +342,21 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
         doff[r][j] = dl * C::ACS;
 #endif
       }
-#if PCS_COMMIT_ATOMIC
+#if PCS_COMMIT_PHASED && !PCS_COMMIT_ATOMIC
+    unsigned dq[R][4], dp[R][4];  // LDS byte addresses of this lane's pieces of the rows it commits
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(doff[r][j]));  // formed BEFORE the ticket wait, not sunk into the critical section
+      for (int j = 0; j < 4; ++j) {
+        dq[r][j] = acc_lds + 4u * (unsigned)doff[r][j] + 16u * l15;
+        dp[r][j] = acc_lds + 4u * (unsigned)doff[r][j] + 256u * C::N4 + (C::N2 ? 8u : 4u) * l15;
+        asm volatile("" : "+v"(dq[r][j]), "+v"(dp[r][j]));  // formed BEFORE the ticket wait, not sunk into the critical section
+      }
+#elif PCS_COMMIT_ATOMIC
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(doff[r][j]));
 #endif
     if (lane == 0) {
       while (__hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != grp)
@@ -392,6 +406,65 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     __builtin_amdgcn_s_setprio(3);
     PCS_T(const long long tr_c = wall_clock64();)
+#if PCS_COMMIT_PHASED
+    {
+      // Three phases, each behind a compiler barrier: every LDS read of the group (one latency for all of them), every
+      // add, every write. Round 2's interleaving went through ~8 read-wait-add rounds per group, each a full LDS
+      // latency, inside the one serial chain of the workgroup; the LDS byte addresses (dq: the 16-byte column pieces,
+      // dp: the 8-byte pair) are formed before the ticket wait.
+      typedef float v2f __attribute__((ext_vector_type(2)));  // native vectors: the HIP float4 / float2 structs do not assign across address spaces
+      typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+      typedef __attribute__((address_space(3))) const v2f lds_cf2;
+      typedef __attribute__((address_space(3))) const float lds_cf1;
+      typedef __attribute__((address_space(3))) f32x4 lds_f4;
+      typedef __attribute__((address_space(3))) v2f lds_f2;
+      typedef __attribute__((address_space(3))) float lds_f1;
+      // all row blocks of the group in one round while the registers allow it (<= 96 columns), else one round per block
+      constexpr int RB = (NCTT <= 6) ? NRC : 1;
+#pragma unroll
+      for (int r0 = 0; r0 < NRC; r0 += RB) {
+        f32x4 v4[RB][4][C::N4 > 0 ? C::N4 : 1];
+        v2f v2[RB][4];
+        float v1[RB][4];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = r0 + rr;
+#pragma unroll
+            for (int q = 0; q < C::N4; ++q) v4[rr][j][q] = *(lds_cf4 *)(size_t)(dq[r][j] + 256u * q);
+            if (C::N2) v2[rr][j] = *(lds_cf2 *)(size_t)dp[r][j];
+            if (C::N1) v1[rr][j] = *(lds_cf1 *)(size_t)(dp[r][j] + 128u * C::N2);
+          }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = r0 + rr;
+#pragma unroll
+            for (int q = 0; q < C::N4; ++q) {
+              v4[rr][j][q].x += acc[r][4 * q + 0][j]; v4[rr][j][q].y += acc[r][4 * q + 1][j];
+              v4[rr][j][q].z += acc[r][4 * q + 2][j]; v4[rr][j][q].w += acc[r][4 * q + 3][j];
+            }
+            if (C::N2) { v2[rr][j].x += acc[r][4 * C::N4 + 0][j]; v2[rr][j].y += acc[r][4 * C::N4 + 1][j]; }
+            if (C::N1) v1[rr][j] += acc[r][NCTT - 1][j];
+          }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = r0 + rr;
+#pragma unroll
+            for (int q = 0; q < C::N4; ++q) *(lds_f4 *)(size_t)(dq[r][j] + 256u * q) = v4[rr][j][q];
+            if (C::N2) *(lds_f2 *)(size_t)dp[r][j] = v2[rr][j];
+            if (C::N1) *(lds_f1 *)(size_t)(dp[r][j] + 128u * C::N2) = v1[rr][j];
+          }
+        asm volatile("" ::: "memory");
+      }
+    }
+#else
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (r < nr) {  // wave-uniform
@@ -425,13 +498,26 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5_kernel(ConvArgs a) {
         }
       }
     }
+#endif
+#if PCS_COMMIT_NOWAIT
+    // the ticket store stays behind the tile writes in program order and the LDS keeps a wave's instructions in order; a
+    // bare ds_write_b32 because the compiler puts the completion wait (s_waitcnt lgkmcnt(0)) in front of its own store
+    if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(commit_lds), "v"(grp + 1) : "memory");
+    __builtin_amdgcn_s_setprio(0);
+#else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) __hip_atomic_store(commit, grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_s_setprio(0);
 #endif
+#endif
     PCS_T(const long long tr_d = wall_clock64(); tr_loop += tr_b - tr_a; tr_ticket += tr_c - tr_b; tr_commit += tr_d - tr_c; ++tr_groups;)
     cur = nxt;
     i = in;
+  };
+  {  // wave-uniform loops, no barrier inside: the full groups, then the partial ones (= the commit order)
+    int grp = wid;
+    for (; grp < total_full; grp += C::NW) run_group(grp, std::integral_constant<int, R>{});
+    for (; grp < total_grp; grp += C::NW) run_group(grp, std::integral_constant<int, 1>{});
   }
   PCS_T(const long long tr_end = wall_clock64();)
   __syncthreads();

@@ -24,6 +24,11 @@ using namespace pcs;
 
 namespace {
 
+#if PCS_TRACE
+__device__ long long *g_convh_trace;   // [block][wave][8], as conv_wave5.hip: t_entry, t_start, t_end, loop, ticket, commit, groups, t_exit
+constexpr int kTraceBlocksH = 8192;
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -114,6 +119,7 @@ template <typename HT, int NCTT, int NW, int MINW, int R, bool TAIL>
 __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
   using C = Conv5hCfg<NCTT, NW, R>;
   const int T = a.tile_rows;
+  PCS_T(const long long tr_entry = wall_clock64(); long long tr_loop = 0, tr_ticket = 0, tr_commit = 0; int tr_groups = 0;)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *acc_l = reinterpret_cast<float *>(smem);            // [T+SINK][ACS], rows >= T = sink for padding rows
   int *kl_k = reinterpret_cast<int *>(acc_l + (T + C::SINK) * C::ACS);  // [32] offset id
@@ -123,6 +129,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
   int *kl_h = kl_g + 33;                                     // [33] first partial group (prefix)
   int *commit = kl_h + 33;
   const unsigned commit_lds = (unsigned)(size_t)(__attribute__((address_space(3))) int *)commit;  // LDS byte address
+  const unsigned acc_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float *)acc_l;
   __shared__ int nk_s;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // a scalar: wave-level loops and branches stay uniform
@@ -262,7 +269,12 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
     make_ctx(cur, pr, vm, nr, i);
     load_frag(f0, cur, 0);
   }
-  for (int grp = wid; grp < total_grp; grp += C::NW) {  // wave-uniform loop, no barrier inside
+  PCS_T(const long long tr_start = wall_clock64();)
+  // one straight-line body per group loop (full groups: R row blocks, partial groups: one), see conv_wave5.hip
+  static_assert(R >= 2 && R <= 4, "partial groups hold 1 .. R - 1 row blocks");
+  auto run_group = [&](const int grp, auto nrc_tag) {
+    constexpr int NRC = decltype(nrc_tag)::value;
+    PCS_T(const long long tr_a = wall_clock64();)
     const int grpn = grp + C::NW < total_grp ? grp + C::NW : grp;
     int in = i, pidx_n[R], nr_n; unsigned vm_n;
     locate(grpn, in, pidx_n, vm_n, nr_n);
@@ -276,7 +288,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
 #pragma unroll
       for (int t = 0; t < NCTT; ++t) acc[r][t] = (f32x4){0, 0, 0, 0};
     const unsigned vmask = cur.vmask;
-    const int nr = __builtin_amdgcn_readfirstlane(cur.nr);  // wave-uniform: a scalar, so the bodies below are real branches
+    constexpr int nr = NRC;
     auto mfma_frag = [&](const Frag &f, auto last_tag) {  // last_tag: the layer's last contraction step
       constexpr bool LAST = decltype(last_tag)::value;
 #pragma unroll
@@ -312,6 +324,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
       mfma_frag(f0, std::true_type{});
       f0 = f1;
     }
+    PCS_T(const long long tr_b = wall_clock64();)
     // ---- in-order commit of the group's row blocks (as conv_wave5.hip: row addresses formed before the ticket wait,
     // raised wave priority while the ticket is held -- the commits of a workgroup are one serial chain) -----------
     int doff[R][4];
@@ -326,11 +339,21 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
         doff[r][j] = dl * C::ACS;
 #endif
       }
-#if PCS_COMMIT_ATOMIC
+#if PCS_COMMIT_PHASED && !PCS_COMMIT_ATOMIC
+    unsigned dq[R][4], dp[R][4];  // LDS byte addresses of this lane's pieces of the rows it commits
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(doff[r][j]));  // formed BEFORE the ticket wait, not sunk into the critical section
+      for (int j = 0; j < 4; ++j) {
+        dq[r][j] = acc_lds + 4u * (unsigned)doff[r][j] + 16u * l15;
+        dp[r][j] = acc_lds + 4u * (unsigned)doff[r][j] + 256u * C::N4 + (C::N2 ? 8u : 4u) * l15;
+        asm volatile("" : "+v"(dq[r][j]), "+v"(dp[r][j]));  // formed BEFORE the ticket wait, not sunk into the critical section
+      }
+#elif PCS_COMMIT_ATOMIC
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(doff[r][j]));
 #endif
     if (lane == 0) {
       while (__hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != grp)
@@ -340,6 +363,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
     // ds_add_f32 accumulate in ticket order, never waited for (see conv_wave5.hip); columns 16 t + l15: conflict-free rows
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_setprio(3);
+    PCS_T(const long long tr_c = wall_clock64();)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (r < nr) {  // wave-uniform
@@ -361,6 +385,66 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
 #else
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     __builtin_amdgcn_s_setprio(3);
+    PCS_T(const long long tr_c = wall_clock64();)
+#if PCS_COMMIT_PHASED
+    {
+      // Three phases, each behind a compiler barrier: every LDS read of the group (one latency for all of them), every
+      // add, every write. Round 2's interleaving went through ~8 read-wait-add rounds per group, each a full LDS
+      // latency, inside the one serial chain of the workgroup; the LDS byte addresses (dq: the 16-byte column pieces,
+      // dp: the 8-byte pair) are formed before the ticket wait.
+      typedef float v2f __attribute__((ext_vector_type(2)));  // native vectors: the HIP float4 / float2 structs do not assign across address spaces
+      typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+      typedef __attribute__((address_space(3))) const v2f lds_cf2;
+      typedef __attribute__((address_space(3))) const float lds_cf1;
+      typedef __attribute__((address_space(3))) f32x4 lds_f4;
+      typedef __attribute__((address_space(3))) v2f lds_f2;
+      typedef __attribute__((address_space(3))) float lds_f1;
+      // all row blocks of the group in one round while the registers allow it (<= 96 columns), else one round per block
+      constexpr int RB = (NCTT <= 6 && NRC >= 2) ? 2 : 1;
+#pragma unroll
+      for (int r0 = 0; r0 < NRC; r0 += RB) {
+        f32x4 v4[RB][4][C::N4 > 0 ? C::N4 : 1];
+        v2f v2[RB][4];
+        float v1[RB][4];
+#pragma unroll
+        for (int rr = 0; rr < RB && r0 + rr < NRC; ++rr)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = r0 + rr;
+#pragma unroll
+            for (int q = 0; q < C::N4; ++q) v4[rr][j][q] = *(lds_cf4 *)(size_t)(dq[r][j] + 256u * q);
+            if (C::N2) v2[rr][j] = *(lds_cf2 *)(size_t)dp[r][j];
+            if (C::N1) v1[rr][j] = *(lds_cf1 *)(size_t)(dp[r][j] + 128u * C::N2);
+          }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int rr = 0; rr < RB && r0 + rr < NRC; ++rr)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = r0 + rr;
+#pragma unroll
+            for (int q = 0; q < C::N4; ++q) {
+              v4[rr][j][q].x += acc[r][4 * q + 0][j]; v4[rr][j][q].y += acc[r][4 * q + 1][j];
+              v4[rr][j][q].z += acc[r][4 * q + 2][j]; v4[rr][j][q].w += acc[r][4 * q + 3][j];
+            }
+            if (C::N2) { v2[rr][j].x += acc[r][4 * C::N4 + 0][j]; v2[rr][j].y += acc[r][4 * C::N4 + 1][j]; }
+            if (C::N1) v1[rr][j] += acc[r][NCTT - 1][j];
+          }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int rr = 0; rr < RB && r0 + rr < NRC; ++rr)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = r0 + rr;
+#pragma unroll
+            for (int q = 0; q < C::N4; ++q) *(lds_f4 *)(size_t)(dq[r][j] + 256u * q) = v4[rr][j][q];
+            if (C::N2) *(lds_f2 *)(size_t)dp[r][j] = v2[rr][j];
+            if (C::N1) *(lds_f1 *)(size_t)(dp[r][j] + 128u * C::N2) = v1[rr][j];
+          }
+        asm volatile("" ::: "memory");
+      }
+    }
+#else
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (r < nr) {  // wave-uniform
@@ -393,13 +477,33 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
         }
       }
     }
+#endif
+#if PCS_COMMIT_NOWAIT
+    // the ticket store stays behind the tile writes in program order and the LDS keeps a wave's instructions in order; a
+    // bare ds_write_b32 because the compiler puts the completion wait (s_waitcnt lgkmcnt(0)) in front of its own store
+    if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(commit_lds), "v"(grp + 1) : "memory");
+    __builtin_amdgcn_s_setprio(0);
+#else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) __hip_atomic_store(commit, grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_s_setprio(0);
 #endif
+#endif
+    PCS_T(const long long tr_d = wall_clock64(); tr_loop += tr_b - tr_a; tr_ticket += tr_c - tr_b; tr_commit += tr_d - tr_c; ++tr_groups;)
     cur = nxt;
     i = in;
+  };
+  {  // wave-uniform loops, no barrier inside: the full groups, then the partial ones (= the commit order)
+    int grp = wid;
+    for (; grp < total_full; grp += C::NW) run_group(grp, std::integral_constant<int, R>{});
+    for (; grp < total_grp; grp += C::NW) {
+      const int nrp = __builtin_amdgcn_readfirstlane(cur.nr);  // wave-uniform: 1 .. R - 1 row blocks
+      if (R >= 4 && nrp == 3) run_group(grp, std::integral_constant<int, (R >= 4 ? 3 : 1)>{});
+      else if (R >= 3 && nrp == 2) run_group(grp, std::integral_constant<int, (R >= 3 ? 2 : 1)>{});
+      else run_group(grp, std::integral_constant<int, 1>{});
+    }
   }
+  PCS_T(const long long tr_end = wall_clock64();)
   __syncthreads();
   // epilogue: fp32 tile (+ fp32 bias) -> halfs, 8-byte stores, every dst row written once
   const int rows = (int)((a.n_dst - row0) < (int64_t)T ? (a.n_dst - row0) : (int64_t)T);
@@ -414,7 +518,25 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
                                      *reinterpret_cast<uint2 *>(drow + (int64_t)r * ldd + cq) = o;
                                      return make_float4(h2f(HT{}, hx), h2f(HT{}, hy), h2f(HT{}, hz), h2f(HT{}, hw));
                                    });
+#if PCS_TRACE
+  if (lane == 0 && blockIdx.x < kTraceBlocksH && g_convh_trace) {
+    long long *t = g_convh_trace + ((int64_t)blockIdx.x * 8 + wid) * 8;
+    t[0] = tr_entry; t[1] = tr_start; t[2] = tr_end; t[3] = tr_loop; t[4] = tr_ticket; t[5] = tr_commit;
+    t[6] = tr_groups; t[7] = wall_clock64();
+  }
+#endif
 }
+
+#if PCS_TRACE
+long long *g_traceh_host_ptr = nullptr;
+void traceh_prepare(hipStream_t st) {
+  if (!g_traceh_host_ptr) {
+    (void)hipMalloc(&g_traceh_host_ptr, (size_t)kTraceBlocksH * 64 * sizeof(long long));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_convh_trace), &g_traceh_host_ptr, sizeof(g_traceh_host_ptr));
+  }
+  (void)hipMemsetAsync(g_traceh_host_ptr, 0, (size_t)kTraceBlocksH * 64 * sizeof(long long), st);
+}
+#endif
 
 template <typename HT, int NCTT, int NW, int MINW, int R, bool TAIL>
 int launch_conv5h(const ConvArgsH &a, hipStream_t st) {
@@ -430,8 +552,15 @@ int launch_conv5h(const ConvArgsH &a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds);
     attr_set = true;
   }
+  PCS_T(traceh_prepare(st);)
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(C::NT), lds, st, a);
   return check_launch("pcs_conv_gather_gemm_h(wave5h)");
+}
+
+// row blocks per group of the half kernel per column-tile width (picked from profiles/round3_convh_group_rows.md)
+inline int convh_group_rows(int nctt) {
+  (void)nctt;
+  return 2;
 }
 
 template <typename HT>
@@ -442,9 +571,16 @@ int launch_h(ConvArgsH a, hipStream_t st) {
   a.ncoltiles = (int)ceil_div(a.cout, 16 * nctt);
   const bool nw8 = 2 * conv5_lds_est(a.tile_rows, nctt) > 160 * 1024;  // 4-wave workgroups while two of them fit a CU's LDS, else one 8-wave workgroup
   const bool tail = (a.cin % 32) != 0;
+  // row blocks per group: the kernel is bound by the vector-memory address unit (TA ~65-80 % busy, MFMA pipe 10-20 %,
+  // profiles/round3_convh_pmc.md): one 16-byte operand load per lane feeds R N / (R + N) MFMAs, so more row blocks per B
+  // fragment = fewer loads per MFMA (R = 2, N = 8: 1.6; R = 4, N = 8: 2.67) as far as the registers allow
+  static const int force_r = getenv("PCS_CONVH_R") ? atoi(getenv("PCS_CONVH_R")) : 0;  // A/B
+  const int rsel = tail ? 2 : (force_r >= 2 && force_r <= 4 ? force_r : convh_group_rows(nctt));
 #define PCS_CONV5H_CASE(N)                                                                          \
   case N:                                                                                           \
     if (tail) return nw8 ? launch_conv5h<HT, N, 8, 2, 2, true>(a, st) : launch_conv5h<HT, N, 4, 2, 2, true>(a, st);  \
+    if (rsel == 4) return nw8 ? launch_conv5h<HT, N, 8, 2, 4, false>(a, st) : launch_conv5h<HT, N, 4, 2, 4, false>(a, st);  \
+    if (rsel == 3) return nw8 ? launch_conv5h<HT, N, 8, 2, 3, false>(a, st) : launch_conv5h<HT, N, 4, 2, 3, false>(a, st);  \
     return nw8 ? launch_conv5h<HT, N, 8, 2, 2, false>(a, st) : launch_conv5h<HT, N, 4, 2, 2, false>(a, st);
   switch (nctt) {
     PCS_CONV5H_CASE(2)
@@ -458,6 +594,15 @@ int launch_h(ConvArgsH a, hipStream_t st) {
 }
 
 }  // namespace
+
+#if PCS_TRACE
+// debug builds only: phase timers of the last half-kernel launch (layout as pcs_debug_conv_trace)
+extern "C" int pcs_debug_convh_trace(long long *host_out) {
+  if (!g_traceh_host_ptr || !host_out) return PCS_EINVAL;
+  if (hipDeviceSynchronize() != hipSuccess) return PCS_ELAUNCH;
+  return hipMemcpy(host_out, g_traceh_host_ptr, (size_t)kTraceBlocksH * 64 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? PCS_OK : PCS_ELAUNCH;
+}
+#endif
 
 extern "C" size_t pcs_conv_prepared_weights_bytes(int32_t K, int32_t ccon, int32_t ccols) {
   if (K <= 0 || ccon <= 0 || ccols <= 0 || ccon % 8) return 0;

@@ -168,6 +168,27 @@ def build_kernel_map(in_coords, out_coords, kernel_size, in_stride, dilation):
 
 _HALF = (torch.bfloat16, torch.float16)
 
+# fp32 weight gradient of conv3d. "fp32" (library default): fp32 MFMA arithmetic (wgrad2_kernel). "bf16x3": layers with
+# >= 96 input and output channels take pcs_conv_wgrad_f32_bf16x3 -- every fp32 operand split into three bf16 planes, six plane
+# products accumulated in fp32 on the 16-bit MFMAs: fp32-grade (error vs float64 at most twice the fp32 MFMA path's,
+# tests/test_dense_parity.py::test_conv_backward_dense_map), 1.3-1.4x faster there; thin layers stay on wgrad2 (slower
+# on the split path). Opt-in only: a caller that selects it states so (bench.py's config.wgrad).
+_WGRAD_POLICY = {"mode": "fp32"}
+
+
+def set_wgrad_policy(mode):
+    if mode not in ("fp32", "bf16x3"):
+        raise ValueError("wgrad policy must be 'fp32' or 'bf16x3'")
+    _WGRAD_POLICY["mode"] = mode
+
+
+def get_wgrad_policy():
+    return _WGRAD_POLICY["mode"]
+
+
+def _wgrad_split(cin, cout):
+    return _WGRAD_POLICY["mode"] == "bf16x3" and cin >= 96 and cout >= 96 and cin % 4 == 0 and cout % 4 == 0
+
 
 def _amp_dtype(t):
     """The half dtype this op computes in, or None for fp32: the input's own dtype when it already is half, else the
@@ -245,7 +266,8 @@ class _SparseConv(Function):
             if x.dtype in _HALF and cin % 4 == 0 and cout % 4 == 0:
                 grad_weight = be.conv_wgrad_h(x, grad_output.contiguous().to(x.dtype), entry.fwd, a_col)
             else:
-                grad_weight = be.conv_wgrad(x.float(), grad_output.contiguous().float(), entry.fwd, a_col)
+                grad_weight = be.conv_wgrad(x.float(), grad_output.contiguous().float(), entry.fwd, a_col,
+                                            split=_wgrad_split(cin, cout))
             grad_weight = grad_weight.view_as(weight).to(weight.dtype)
         return grad_input, grad_weight, None, None, None
 

@@ -208,10 +208,31 @@ def compare(g, logits, loss, named_grads=None):
         ref_names = [str(n) for n in g["grad_names"]]
         assert [str(n) for n in mine["grad_names"]] == ref_names, "parameter sets differ"
         rs, ms = g["grad_stats"], mine["grad_stats"]
-        # per parameter, relative to that gradient's own size: abs-sum (no cancellation), sum and samples vs abs-sum / abs-max
-        out["grad_abssum_rel_err"] = float(np.abs(ms[:, 1] / rs[:, 1] - 1).max())
-        out["grad_sum_err_rel_abssum"] = float((np.abs(ms[:, 0] - rs[:, 0]) / rs[:, 1]).max())
-        out["grad_sample_err_rel_max"] = float((np.abs(mine["grad_samples"] - g["grad_samples"]).max(1) / rs[:, 2]).max())
-        worst = int(np.argmax(np.abs(ms[:, 1] / rs[:, 1] - 1)))
-        out["grad_worst_param"] = ref_names[worst]
+        # Gradients that are ZERO by construction (a bias in front of a train-mode BatchNorm: the normalisation removes
+        # it) come out as rounding noise on both sides; they are "dead": checked to stay noise, excluded from the relative
+        # errors. G = the typical gradient size of the model (median over parameters of the largest |element|).
+        G = float(np.median(rs[:, 2]))
+        live = rs[:, 2] > 1e-4 * G
+        out["grad_params"], out["grad_dead_params"] = int(len(ref_names)), int((~live).sum())
+        out["grad_dead_max_over_G"] = float(ms[~live, 2].max() / G) if (~live).any() else 0.0
+        # per live parameter, relative to that gradient's own size: abs-sum (no cancellation inside it), the signed sum
+        # against the abs-sum, eight sampled elements against the largest element
+        e_abs = np.abs(ms[live, 1] / rs[live, 1] - 1)
+        e_sum = np.abs(ms[live, 0] - rs[live, 0]) / rs[live, 1]
+        e_smp = np.abs(mine["grad_samples"][live] - g["grad_samples"][live]).max(1) / rs[live, 2]
+        names = [n for n, l in zip(ref_names, live) if l]
+        for key, e in (("grad_abssum_rel_err", e_abs), ("grad_sum_err_rel_abssum", e_sum), ("grad_sample_err_rel_max", e_smp)):
+            out[key] = float(e.max())
+            out[key + "_median"] = float(np.median(e))
+            out[key + "_p90"] = float(np.percentile(e, 90))
+        out["grad_worst_param"] = names[int(np.argmax(e_abs))]
+        # the big tensors (>= 2-D weights: convolution and linear kernels) on their own: sums over many rows, no
+        # cancellation to speak of -- the tight bound of the test
+        shapes = {n: tuple(t.shape) for n, t in named_grads}
+        mat = np.array([len(shapes[n]) >= 2 for n in names])
+        if mat.any():
+            out["grad_matrix_params"] = int(mat.sum())
+            out["grad_matrix_abssum_rel_err"] = float(e_abs[mat].max())
+            out["grad_matrix_sample_err_rel_max"] = float(e_smp[mat].max())
+            out["grad_matrix_worst_param"] = [n for n, m_ in zip(names, mat) if m_][int(np.argmax(e_abs[mat]))]
     return out

@@ -32,14 +32,17 @@ from stage_reference import reference_root  # noqa: E402
 
 pytestmark = pytest.mark.skipif(reference_root() is None, reason="neither /root/reference nor tests/_refsrc present")
 
-# measured on MI355X (round 3): see MEASURED below; bound = what the test accepts (absolute)
+# Bounds (absolute for logits / loss, relative for gradients), each next to the value measured on MI355X in round 3
+# (profiles/round3_fullsize_parity.json). Gradients: "matrix" = every >= 2-D parameter (convolution / linear kernels: sums
+# over ~1e5 rows without cancellation); "any" = all live parameters including BatchNorm scales / biases and layer biases,
+# whose gradients are sums of signed terms that nearly cancel (fp32 summation order shows at the 1e-3 level on both sides).
 BOUNDS = {
-    # name: (logit max-abs err, loss abs err, grad abs-sum rel err, grad sum err / abs-sum, grad sample err / abs-max)
-    "config2/reference": (2e-3, 1e-4, 2e-4, 2e-4, 1e-3),
-    "config2/workload": (2e-3, 1e-4, 2e-4, 2e-4, 1e-3),
-    "config3/reference": (2e-3, 1e-4, 2e-4, 2e-4, 1e-3),
-    "config4/reference": (1e-3, 1e-4, 2e-4, 2e-4, 1e-3),
-    "config5/reference": (1e-3, 1e-4, 2e-4, 2e-4, 1e-3),
+    # name: (logit max-abs err, loss abs err, matrix abs-sum rel, matrix sample / abs-max, any abs-sum rel, any sample / abs-max)
+    "config2/reference": (1e-3, 1e-4, 1e-2, 1e-2, 2e-2, 2e-2),
+    "config2/workload": (1e-3, 1e-4, 1e-2, 1e-2, 2e-2, 2e-2),
+    "config3/reference": (1e-3, 1e-4, 1e-2, 1e-2, 2e-2, 2e-2),
+    "config4/reference": (1e-3, 1e-4, 1e-2, 1e-2, 2e-2, 2e-2),
+    "config5/reference": (1e-3, 1e-4, 1e-2, 1e-2, 2e-2, 2e-2),
 }
 _MEASURED = {}
 
@@ -53,16 +56,15 @@ def _record(name, m):
             json.dump(_MEASURED, f, indent=1, sort_keys=True)
 
 
-def _assert_bounds(name, m, grads=True):
-    lo, ls, ga, gs, gp = BOUNDS[name]
+def _assert_bounds(name, m):
+    lo, ls, gm, gms, ga, gas = BOUNDS[name]
     assert m["logit_max_abs_err"] < lo, (name, m)
     assert m["colsum_err_per_row"] < lo, (name, m)
     assert m["abssum_rel_err"] < 1e-4, (name, m)
     assert m["loss_abs_err"] < ls * max(1.0, abs(m.get("loss_ref", 1.0))), (name, m)
-    if grads:
-        assert m["grad_abssum_rel_err"] < ga, (name, m)
-        assert m["grad_sum_err_rel_abssum"] < gs, (name, m)
-        assert m["grad_sample_err_rel_max"] < gp, (name, m)
+    assert m["grad_matrix_abssum_rel_err"] < gm and m["grad_matrix_sample_err_rel_max"] < gms, (name, m)
+    assert m["grad_abssum_rel_err"] < ga and m["grad_sample_err_rel_max"] < gas, (name, m)
+    assert m["grad_dead_max_over_G"] < 1e-3, (name, m)   # gradients that are zero by construction stay rounding noise
 
 
 def _golden(cfg):
@@ -129,39 +131,48 @@ def test_fullsize_reference_model_on_hip(cfg, hip):
     _assert_bounds(cfg + "/reference", m)
 
 
-def _workload(g, dev, amp=None):
+def _workload(g, dev, amp=None, wgrad="fp32"):
     from seeded import seeded_state
+    from openpcseg_amd import functional as pcsF
     from openpcseg_amd.sparse import SparseTensor
     from openpcseg_amd.workloads.minkunet import MK18_LAYERS, MinkUNet
     batch = fs.to_device("config2", _inputs("config2", g), dev, SparseTensor)
     model = MinkUNet(num_class=20, num_layer=MK18_LAYERS, cr=1.0)
     seeded_state(model)
     model.to(dev).train()
-    if amp is None:
-        out = model(batch)
-    else:
-        with torch.autocast("cuda", dtype=amp):
+    pcsF.set_wgrad_policy(wgrad)
+    try:
+        if amp is None:
             out = model(batch)
-    out["loss"].backward()
+        else:
+            with torch.autocast("cuda", dtype=amp):
+                out = model(batch)
+        out["loss"].backward()
+    finally:
+        pcsF.set_wgrad_policy("fp32")
     return out["logits"].detach().float().cpu().numpy(), float(out["loss"].detach()), fs.model_grads(model)
 
 
 @pytest.mark.gpu
-def test_fullsize_workload_minkunet18_on_hip(hip):
+@pytest.mark.parametrize("wgrad", ["fp32", "bf16x3"])
+def test_fullsize_workload_minkunet18_on_hip(hip, wgrad):
     """Config 2 through this package's fused MinkUNet workload (what bench.py times): same frame, same weights, same
     reference logits AND gradients -- the autograd wiring of the fused graph (conv-epilogue BN statistics, strided-dy
-    concat backward, column-block classifier) against the reference's plain graph."""
+    concat backward, column-block classifier) against the reference's plain graph. wgrad = "bf16x3" is the policy of
+    bench.py's fp32 line (three-plane split weight gradient on the >= 96-channel layers): the same bounds hold."""
     g = _golden("config2")
-    logits, loss, grads = _workload(g, torch.device("cuda:0"))
+    logits, loss, grads = _workload(g, torch.device("cuda:0"), wgrad=wgrad)
     m = fs.compare(g, logits, loss, grads)
     m["loss_ref"] = float(g["loss"])
-    _record("config2/workload", m)
+    _record("config2/workload" + ("" if wgrad == "fp32" else "/wgrad-" + wgrad), m)
     _assert_bounds("config2/workload", m)
 
 
 # bf16 / fp16 autocast: 16-bit storage of every activation (8 / 11 significant bits), fp32 accumulation. The bound is per
 # point, relative to the RMS of the reference logits (measured: see profiles/round3_fullsize_parity.json).
-AMP_BOUNDS = {torch.bfloat16: (0.25, 0.08, 0.10), torch.float16: (0.05, 0.02, 0.03)}  # max / rms, mean / rms, grad abs-sum
+# measured (bf16 / fp16): max 0.21 / 0.026 of the RMS, mean 0.0098 / 0.0013, worst parameter-gradient abs-sum 8.7 % / 2.8 %,
+# arg-max agreement with the fp32 reference 98.6 % / 99.7 % of the points
+AMP_BOUNDS = {torch.bfloat16: (0.30, 0.02, 0.12, 0.975), torch.float16: (0.05, 0.0025, 0.04, 0.99)}  # max / rms, mean / rms, grad, arg-max
 
 
 @pytest.mark.gpu
@@ -178,8 +189,9 @@ def test_fullsize_workload_autocast_vs_fp32_reference(dtype, hip):
     m.update({"logit_rms": rms, "logit_max_err_over_rms": float(err.max() / rms), "logit_mean_err_over_rms": float(err.mean() / rms),
               "argmax_agreement": float((logits[::step].argmax(1) == ref.argmax(1)).mean()), "loss_ref": float(g["loss"])})
     _record("config2/workload/" + str(dtype).split(".")[1], m)
-    bmax, bmean, bgrad = AMP_BOUNDS[dtype]
+    bmax, bmean, bgrad, bagree = AMP_BOUNDS[dtype]
     assert m["logit_max_err_over_rms"] < bmax, m
     assert m["logit_mean_err_over_rms"] < bmean, m
+    assert m["argmax_agreement"] > bagree, m
     assert m["grad_abssum_rel_err"] < bgrad, m
     assert m["loss_abs_err"] < bmean * abs(float(g["loss"])), m

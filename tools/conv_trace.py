@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a fused-conv launch spends its wall time, per wave: needs the debug library built with -DPCS_TRACE=1
 (`bash tools/build_debug_lib.sh trace -DPCS_TRACE=1`, see profiles/round1_conv_pmc.md) through PCS_LIB_PATH.
-Usage: PCS_LIB_PATH=$PWD/openpcseg_amd/lib/dbg/trace.so python tools/conv_trace.py <level 0..4> <cin> <cout> [frames]
+Usage: PCS_LIB_PATH=$PWD/openpcseg_amd/lib/dbg/trace.so python tools/conv_trace.py <level 0..4> <cin> <cout> [frames] [bf16|fp16]
 Phases (wall clock, 10 ns ticks): entry->start = LDS zero-fill + offset list + first operand loads; per group:
 loop = channel loop (operand loads + MFMAs), ticket = waiting for the earlier groups to commit, commit = LDS RMW;
 other = locate/pair loads between groups; end->exit = final barrier + tile write-back."""
@@ -21,6 +21,7 @@ from openpcseg_amd.workloads.synthetic import make_batch  # noqa: E402
 def main():
     level, cin, cout = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     frames = int(sys.argv[4]) if len(sys.argv) > 4 else 12
+    half = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(sys.argv[5]) if len(sys.argv) > 5 else None
     dev = torch.device("cuda:0")
     coords = make_batch(list(range(frames)))["lidar"].C.to(dev)
     coords = coords[torch.argsort(F.sphash(coords))].contiguous()
@@ -32,16 +33,21 @@ def main():
     be = native.backend()
     x = torch.randn(coords.shape[0], cin, device=dev)
     w = torch.randn(27, cin, cout, device=dev) * 0.05
+    if half is None:
+        run = lambda: be.conv_gather_gemm(x, w, entry.fwd)
+    else:
+        xh, wp = x.to(half), be.prepare_weights_h(w, half, transpose=False)
+        run = lambda: be.conv_gather_gemm_h(xh, wp, 27, cout, entry.fwd)
     for _ in range(3):
-        be.conv_gather_gemm(x, w, entry.fwd)
+        run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    be.conv_gather_gemm(x, w, entry.fwd)
+    run()
     e1.record()
     torch.cuda.synchronize()
     buf = np.zeros(8192 * 64, dtype=np.int64)
-    fn = be.lib.pcs_debug_conv_trace
+    fn = be.lib.pcs_debug_conv_trace if half is None else be.lib.pcs_debug_convh_trace
     fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
     assert fn(buf.ctypes.data) == 0
     t = buf.reshape(8192, 8, 8)
