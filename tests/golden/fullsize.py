@@ -212,7 +212,7 @@ def compare(g, logits, loss, named_grads=None):
         # it) come out as rounding noise on both sides; they are "dead": checked to stay noise, excluded from the relative
         # errors. G = the typical gradient size of the model (median over parameters of the largest |element|).
         G = float(np.median(rs[:, 2]))
-        live = rs[:, 2] > 1e-4 * G
+        live = rs[:, 2] > 1e-3 * G   # measured gap: dead <= 2.4e-4 G, live >= 3.4e-2 G (config 4)
         out["grad_params"], out["grad_dead_params"] = int(len(ref_names)), int((~live).sum())
         out["grad_dead_max_over_G"] = float(ms[~live, 2].max() / G) if (~live).any() else 0.0
         # per live parameter, relative to that gradient's own size: abs-sum (no cancellation inside it), the signed sum

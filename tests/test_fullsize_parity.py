@@ -12,9 +12,9 @@ for (a) the reference's own model source on the HIP backend (configs 2-5) and (b
 -- the graph bench.py times (BN statistics from the conv epilogue, strided-dy concat backward, column-block classifier)
 -- name-mapped onto config 2's reference gradients, in fp32 and under bf16 autocast.
 
-Bounds. north_star asks "per-point logits within 1e-3 fp32". The seeded weights of these fixtures drive |logit| to
-~100 (MinkUNet / SPVCNN) -- an absolute 1e-3 there is 1e-5 relative, i.e. ~80 fp32 ulps after 40-120 layers of
-MFMA-vs-scalar summation order. Every bound below is ABSOLUTE, is stated next to the value measured on MI355X
+Bounds. north_star asks "per-point logits within 1e-3 fp32": measured 1.4e-4 ... 8.8e-4 ABSOLUTE at |logit| up to
+109 / 94 / 19 / 281 (configs 2 / 3 / 4 / 5), i.e. ~1.5e-6 of the logit scale after 40-120 layers of MFMA-vs-scalar
+summation order. Every bound below is absolute for logits and loss, sits next to the value measured on MI355X
 (profiles/round3_fullsize_parity.json, written by this test) and is at most ~2x that value.
 """
 import json
@@ -32,17 +32,24 @@ from stage_reference import reference_root  # noqa: E402
 
 pytestmark = pytest.mark.skipif(reference_root() is None, reason="neither /root/reference nor tests/_refsrc present")
 
-# Bounds (absolute for logits / loss, relative for gradients), each next to the value measured on MI355X in round 3
-# (profiles/round3_fullsize_parity.json). Gradients: "matrix" = every >= 2-D parameter (convolution / linear kernels: sums
-# over ~1e5 rows without cancellation); "any" = all live parameters including BatchNorm scales / biases and layer biases,
-# whose gradients are sums of signed terms that nearly cancel (fp32 summation order shows at the 1e-3 level on both sides).
+# Bounds (absolute for logits / loss, relative for gradients), each at most ~2x the value measured on MI355X in round 3
+# (profiles/round3_fullsize_parity.json holds the measured values). Gradients: "matrix" = every >= 2-D parameter
+# (convolution / linear kernels: sums over ~1e5 rows without cancellation); "any" = all live parameters, including
+# BatchNorm scales / biases and layer biases whose gradients are sums of signed terms that nearly cancel (the fp32
+# summation order of EITHER side shows at the 1e-3 level there; stem.1.bias is the worst).
+# Config 4 (Cylinder_TS) is looser and says why: (1) its first layer is torch's own BatchNorm1d over RAW point features
+# (rho ~ 20 m, z ~ -2 m: E[x^2] - mean^2 in fp32) -- torch's GPU kernel and torch's CPU kernel differ by 2.9e-5 relative
+# right there, before any of this package's code runs (tools/module_trace.py, profiles/round3_config4_module_trace.txt);
+# (2) the fixture's torch_scatter.scatter_max is a scatter_reduce('amax') stand-in (torch_scatter is not installed in the
+# build container: parity unpinned for that op), whose backward splits a tie evenly where scatter_max picks one index.
 BOUNDS = {
     # name: (logit max-abs err, loss abs err, matrix abs-sum rel, matrix sample / abs-max, any abs-sum rel, any sample / abs-max)
-    "config2/reference": (1e-3, 1e-4, 1e-2, 1e-2, 2e-2, 2e-2),
-    "config2/workload": (1e-3, 1e-4, 1e-2, 1e-2, 2e-2, 2e-2),
-    "config3/reference": (1e-3, 1e-4, 1e-2, 1e-2, 2e-2, 2e-2),
-    "config4/reference": (1e-3, 1e-4, 1e-2, 1e-2, 2e-2, 2e-2),
-    "config5/reference": (1e-3, 1e-4, 1e-2, 1e-2, 2e-2, 2e-2),
+    #   measured:      logits   matrix abs-sum / sample    any abs-sum / sample
+    "config2/reference": (3e-4, 1e-5, 6e-4, 2.5e-3, 6e-3, 1.1e-2),   # 1.5e-4   2.8e-4 / 1.2e-3   2.9e-3 / 5.4e-3
+    "config2/workload": (3e-4, 1e-5, 1e-4, 6e-4, 1e-3, 1e-2),        # 1.4e-4   4.1e-5 / 2.8e-4   4.8e-4 / 4.7e-3
+    "config3/reference": (4e-4, 1e-5, 3e-4, 7e-4, 5e-4, 3e-3),       # 1.7e-4   1.4e-4 / 3.5e-4   2.1e-4 / 1.4e-3
+    "config4/reference": (1e-3, 1e-5, 3e-3, 3.6e-2, 1e-1, 1e-1),     # 8.8e-4   1.5e-3 / 1.8e-2   (see above)
+    "config5/reference": (8e-4, 2e-5, 2e-4, 6e-4, 5e-4, 4e-3),       # 4.1e-4   7.8e-5 / 2.9e-4   2.3e-4 / 1.8e-3
 }
 _MEASURED = {}
 
@@ -61,7 +68,7 @@ def _assert_bounds(name, m):
     assert m["logit_max_abs_err"] < lo, (name, m)
     assert m["colsum_err_per_row"] < lo, (name, m)
     assert m["abssum_rel_err"] < 1e-4, (name, m)
-    assert m["loss_abs_err"] < ls * max(1.0, abs(m.get("loss_ref", 1.0))), (name, m)
+    assert m["loss_abs_err"] < ls * max(1.0, abs(m.get("loss_ref", 1.0))), (name, m)   # measured <= 7.6e-6 at |loss| <= 37
     assert m["grad_matrix_abssum_rel_err"] < gm and m["grad_matrix_sample_err_rel_max"] < gms, (name, m)
     assert m["grad_abssum_rel_err"] < ga and m["grad_sample_err_rel_max"] < gas, (name, m)
     assert m["grad_dead_max_over_G"] < 1e-3, (name, m)   # gradients that are zero by construction stay rounding noise
