@@ -202,8 +202,9 @@ int pcs_rulebook_tile_order(const int32_t *seg, int32_t K, int64_t ntiles, int32
  *   src (n_src, cin), W (K, cin, cout), dst (n_dst, cout); pairs (P,2) with the src row in
  *   column src_col and the dst row in column 1-src_col, sorted k-major / dst ascending;
  *   seg from pcs_rulebook_tile_segments with the same tile_rows; bias (cout) or NULL.
- *   tile_rows: a multiple of 16 in [16, 512]; shapes outside the 16-byte-granular, cin % 32 == 0 kernel
- *   take 64 or 128 only (PCS_EUNSUPPORTED otherwise).
+ *   tile_rows: a multiple of 16 in [16, 512]; shapes outside the wave kernels (cin % 4 == 0, cin >= 32, cout % 4 == 0,
+ *   an even number of 16-column tiles, K <= 32 -- cin % 32 == 0 on the straight-line instance, other widths such as
+ *   56 / 112 / 168 / 336 of RPVNet cr 1.75 on the TAIL instance) take 64 or 128 only (PCS_EUNSUPPORTED otherwise).
  * pcs_conv_tile_rows returns the default tile height for (cin, cout); pcs_conv_pick_tile_rows the
  * height for one layer call: with few dst rows (deep strides) the launch is only a few waves of
  * workgroups over the CUs, and the height is chosen so that the last wave is full.
@@ -219,8 +220,8 @@ int32_t pcs_conv_pick_tile_rows_dt(int64_t n_dst, int64_t n_pairs, int32_t K, in
  *   pcs_bn_reduce_partials turns them into the `sums` vector of pcs_bn_finalize_f32. Only for shapes / tile heights
  *   with pcs_conv_emits_bn_partials(...) != 0 (PCS_EUNSUPPORTED otherwise).
  *   tile_order (may be NULL): ceil(n_dst / tile_rows) int32 from pcs_rulebook_tile_order for the same seg; NULL =
- *   tiles in row order (XCD-contiguous ranges). Only the wave kernels (16-byte-granular shapes, cin % 32 == 0; every
- *   shape of the half kernels) use it.
+ *   tiles in row order (XCD-contiguous ranges). Only the wave kernels (16-byte-granular shapes from 32 input channels
+ *   up; every shape of the half kernels) use it.
  */
 int32_t pcs_conv_emits_bn_partials(int32_t cin, int32_t cout, int32_t K, int32_t tile_rows, int32_t dtype);
 int32_t pcs_conv_uses_tile_order(int32_t cin, int32_t cout, int32_t K, int32_t dtype); /* 1: the shape's kernel reads tile_order */
@@ -373,8 +374,9 @@ int pcs_unique_emit(const int32_t *flags, const int64_t *rank, const int64_t *pe
  * The mixed-precision path of the reference: under `--amp` its ops cast their inputs to half
  * (TS:torchsparse/nn/functional/conv.py:19) and convolution_cuda.cu:61,120-127 runs gather / mm / scatter
  * in half. dtype: 1 = bfloat16, 2 = float16 (features, prepared weights and outputs share it).
- * Served shapes: pcs_conv_h_applies(cin, cout, K) != 0 (cin % 32 == 0, cout % 4 == 0, an even number of
- * 16-column tiles, K <= 32); callers convert other shapes (4/5-channel stems) to fp32 and use the _f32 entries.
+ * Served shapes: pcs_conv_h_applies(cin, cout, K) != 0 (cin % 8 == 0, cin >= 32, cout % 4 == 0, an even number of
+ * 16-column tiles, K <= 32; a last contraction step of 8 / 16 / 24 channels meets zero-padded weight fragments);
+ * callers convert other shapes (4/5-channel stems) to fp32 and use the _f32 entries.
  *   prepare : W (K, A, B) fp32 master weights -> Wp, the weights in MFMA fragment order, converted to `dtype`.
  *             transpose = 0: forward (contraction over A = cin, columns B = cout); transpose = 1: dgrad
  *             (contraction over B, columns A). Wp bytes = pcs_conv_prepared_weights_bytes(K, contraction, columns).

@@ -188,20 +188,6 @@ def get_wgrad_policy():
     return _WGRAD_POLICY["mode"]
 
 
-# PCS_BWD_OVERLAP=1: wgrad on a second HIP stream beside dgrad. Off by default: bench.py prices the fused conv on the
-# HIP-event duration of each launch, and a launch that shares the chip with another kernel has no duration of its own
-# (the overlapped step is measured separately, profiles/round3_bwd_overlap.txt).
-_BWD_OVERLAP = os.environ.get("PCS_BWD_OVERLAP", "0") == "1"
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    s = _SIDE_STREAMS.get(device)
-    if s is None:
-        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
-    return s
-
-
 def _wgrad_split(cin, cout):
     return _WGRAD_POLICY["mode"] == "bf16x3" and cin >= 96 and cout >= 96 and cin % 4 == 0 and cout % 4 == 0
 
@@ -266,31 +252,9 @@ class _SparseConv(Function):
         k, cin, cout = w3.shape
         grad_input = grad_weight = None
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        # dgrad and wgrad of one layer are independent: with both wanted, the weight gradient runs on a second HIP stream
-        # beside the input gradient, so the tail of either launch (the last ~10 % of a big-tile launch runs at half
-        # occupancy) is filled by the other; the main stream waits for the side stream before this node returns.
-        side = _side_stream(grad_output.device) if (need_dx and need_dw and grad_output.is_cuda and _BWD_OVERLAP) else None
-        if need_dw:
-            # fwd pairs are (in_row, out_row) of the NON-transposed conv; a transposed conv's
-            # input lives on the out rows (column 1)
-            a_col = 1 if transposed else 0
-            half_w = x.dtype in _HALF and cin % 4 == 0 and cout % 4 == 0
-            xa = x if half_w else x.float()
-            ga = grad_output.contiguous().to(x.dtype) if half_w else grad_output.contiguous().float()
-
-            def wgrad():
-                if half_w:
-                    gw = be.conv_wgrad_h(xa, ga, entry.fwd, a_col)
-                else:
-                    gw = be.conv_wgrad(xa, ga, entry.fwd, a_col, split=_wgrad_split(cin, cout))
-                return gw.view_as(weight).to(weight.dtype)
-            if side is not None:
-                main = torch.cuda.current_stream(grad_output.device)
-                side.wait_stream(main)  # operands (and the map tensors) are ready on the main stream
-                with torch.cuda.stream(side):
-                    grad_weight = wgrad()
-            else:
-                grad_weight = wgrad()
+        # (round 3 tried the weight gradient on a second HIP stream beside dgrad to fill each other's launch tails; dropped:
+        # a launch that shares the chip has no duration of its own for the roofline, and the lazily built per-map caches
+        # would need cross-stream ordering)
         if need_dx:
             dmap = entry.fwd if transposed else entry.rev
             if hd is not None and be.conv_h_applies(cout, cin, k):
@@ -301,8 +265,16 @@ class _SparseConv(Function):
                 grad_input = be.conv_gather_gemm(grad_output.contiguous().float(), wt, dmap)
             # the gradient leaves in the dtype the forward input arrived in (what autograd expects)
             grad_input = grad_input.to(x.dtype if hd is None else hd)
-        if side is not None:
-            torch.cuda.current_stream(grad_output.device).wait_stream(side)
+        if need_dw:
+            # fwd pairs are (in_row, out_row) of the NON-transposed conv; a transposed conv's
+            # input lives on the out rows (column 1)
+            a_col = 1 if transposed else 0
+            if x.dtype in _HALF and cin % 4 == 0 and cout % 4 == 0:
+                grad_weight = be.conv_wgrad_h(x, grad_output.contiguous().to(x.dtype), entry.fwd, a_col)
+            else:
+                grad_weight = be.conv_wgrad(x.float(), grad_output.contiguous().float(), entry.fwd, a_col,
+                                            split=_wgrad_split(cin, cout))
+            grad_weight = grad_weight.view_as(weight).to(weight.dtype)
         return grad_input, grad_weight, None, None, None
 
 

@@ -192,6 +192,10 @@ def test_bench_one_rank_over_rccl():
     comm = rccl.get("comm")
     assert comm is not None and "error" not in comm, comm
     print("one-rank RCCL comm record:", comm)
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):  # kept for profiles/: what the device trace of the RCCL job looked like
+        with open(os.path.join(ROOT, "gpurun_out", "one_rank_rccl_bench.json"), "w") as f:
+            json.dump({"comm": comm, "amp_bf16_comm": rccl["amp_bf16"].get("comm"), "value": rccl["value"],
+                       "plain_value": plain["value"]}, f, indent=1)
     if comm.get("rccl_kernels", 0) > 0 and comm.get("first_rccl_kernel_before_last_conv_ends") is not None:
         assert comm["first_rccl_kernel_before_last_conv_ends"], comm
 
