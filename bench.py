@@ -48,7 +48,7 @@ class ConvMeter:
 
     def __init__(self, be):
         self.be = be
-        self.orig = {"f32": be.conv_gather_gemm, "half": be.conv_gather_gemm_h}
+        self.orig = {"f32": be.conv_gather_gemm, "half": be.conv_gather_gemm_h, "x3": be.conv_gather_gemm_x3}
         self.records, self.enabled = [], False
 
     def __enter__(self):
@@ -70,15 +70,20 @@ class ConvMeter:
         def wrapped16(src, wp, k, cout, kmap, bias=None, tile_rows=None, **kw):
             return timed(lambda: self.orig["half"](src, wp, k, cout, kmap, bias, tile_rows, **kw), "half", kmap, k,
                          src.shape[1], cout, src.shape[0])
-        self.be.conv_gather_gemm, self.be.conv_gather_gemm_h = wrapped32, wrapped16
+
+        def wrappedx3(src, wp, k, cout, kmap, bias=None, tile_rows=None, **kw):
+            return timed(lambda: self.orig["x3"](src, wp, k, cout, kmap, bias, tile_rows, **kw), "x3", kmap, k,
+                         src.shape[1], cout, src.shape[0])
+        self.be.conv_gather_gemm, self.be.conv_gather_gemm_h, self.be.conv_gather_gemm_x3 = wrapped32, wrapped16, wrappedx3
         return self
 
     def __exit__(self, *a):
         self.be.conv_gather_gemm, self.be.conv_gather_gemm_h = self.orig["f32"], self.orig["half"]
+        self.be.conv_gather_gemm_x3 = self.orig["x3"]
 
-    def summary(self, amp):
+    def summary(self, amp, split=False):
         kind = "half" if amp else "f32"
-        recs = [r for r in self.records if r[5] == kind]
+        recs = [r for r in self.records if r[5] == kind or (split and not amp and r[5] == "x3")]
         if not recs:
             return None
         e = 2.0 if amp else 4.0
@@ -92,6 +97,17 @@ class ConvMeter:
         tflops = flops / (ms * 1e-3) / 1e12
         common = {"launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": round(flops / n),
                   "algorithmic_bytes_per_launch": round(abytes / n)}
+        if split and not amp:
+            # fp32 operands as three bf16 planes, six plane products per algorithmic product on the 16-bit MFMA pipe: its
+            # roof for ALGORITHMIC flops is the dense bf16 peak / 6 (the thin layers the split kernel does not serve stay
+            # on the fp32 MFMA kernel and are part of the same average)
+            nx = sum(1 for r in recs if r[5] == "x3")
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+            return dict({"kernel": "conv_os5x_kernel (pcs_conv_gather_gemm_f32_bf16x3: fwd + dgrad; %d of %d launches, the rest "
+                                   "on conv_os5_kernel)" % (nx, n), "bound": "mfma", "achieved": round(tflops, 3),
+                         "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
+                         "peak_note": "dense bf16 MFMA peak / 6 plane products per algorithmic product",
+                         "vs_fp32_mfma_peak": round(tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None}, **common)
         # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/conv_traffic.sh; rocprofv3 cannot run
         # inside bench.py). The file names the kernel revision it was measured on; a stale file is refused.
         traffic, note = None, "no PMC traffic file for this kernel revision (run tools/conv_traffic.sh)"
@@ -412,6 +428,7 @@ def main():
     ap.add_argument("--amp", choices=["off", "bf16", "fp16"], default="off",
                     help="mixed precision like the reference's --amp (second bench line; the headline metric is fp32)")
     ap.add_argument("--no-amp-line", action="store_true", help="skip the secondary bf16 record of the default run")
+    ap.add_argument("--no-split-line", action="store_true", help="skip the fp32_bf16x3 record (split-kernel convolutions) of the default run")
     ap.add_argument("--wgrad", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="fp32 weight gradient of the >= 96-channel convolutions: fp32 MFMA, or fp32 operands as three bf16 planes "
                          "on the 16-bit MFMAs (fp32-grade: six plane products, error vs float64 <= 2x the fp32 MFMA path's)")
@@ -448,8 +465,9 @@ def main():
     from openpcseg_amd import functional as pcsF
     pcsF.set_wgrad_policy(args.wgrad)
 
-    def measure(amp):
+    def measure(amp, conv="fp32"):
         """One bench line: fresh model / optimizer (same seed), preheat, W warm-up steps, K timed steps."""
+        pcsF.set_conv_policy(conv)
         torch.manual_seed(0)
         model = MinkUNet(num_class=20, num_layer=MK34_LAYERS, cr=1.0, dist=distributed).to(dev).train()
         if distributed:
@@ -497,7 +515,7 @@ def main():
                     dist.barrier()
                 dt = time.perf_counter() - t0
             meter.enabled = False
-            roof = meter.summary(amp)
+            roof = meter.summary(amp, split=(conv == "bf16x3"))
             clk = clocks.summary()
             if roof is not None:
                 roof["clock"] = clk
@@ -510,6 +528,7 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         comm = comm_profile(step, rank) if distributed and not one_dev else None
+        pcsF.set_conv_policy("fp32")
         frames = args.frames_per_gpu * world * args.steps
         return {"value": round(frames / dt, 3), "ms_per_step": round(dt / args.steps * 1e3, 2),
                 "loss": round(float(loss.detach()), 4), "roofline": roof, "comm": comm}
@@ -524,6 +543,9 @@ def main():
     head = measure(amp)
     # the reference trains under --amp (R:dist_train.sh:18): the default run carries the bf16 step as a secondary record
     second = measure("bf16") if amp is None and not args.no_amp_line else None
+    # third record: the fp32 step with forward / input-gradient convolutions on the three-plane split kernel (fp32 in and out,
+    # fp32-grade arithmetic on the bf16 MFMAs; opt-in, never the headline value)
+    third = measure(None, conv="bf16x3") if amp is None and not args.no_split_line else None
     if rank == 0:
         res = {
             "metric": "LiDAR frames/sec training MinkUNet-34 SemanticKITTI",
@@ -546,6 +568,14 @@ def main():
                                "loss": second["loss"], "roofline": second["roofline"]}
             if second["comm"] is not None:
                 res["amp_bf16"]["comm"] = second["comm"]
+        if third is not None:
+            res["fp32_bf16x3"] = {"value": third["value"], "unit": "frames/s", "ms_per_step": third["ms_per_step"], "dtype": "f32",
+                                  "steps": args.steps, "warmup": args.warmup, "loss": third["loss"],
+                                  "workload": workload(None) + "; forward and input-gradient convolutions with fp32 operands "
+                                              "split into three bf16 planes, six plane products accumulated in fp32 "
+                                              "(conv_os5x_kernel: fp32-grade, not bit-identical to fp32 FMA chains); weight "
+                                              "gradient as in the headline line",
+                                  "roofline": third["roofline"]}
         if world == 1 and not args.no_cpu_baseline and amp is None:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

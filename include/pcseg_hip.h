@@ -34,7 +34,7 @@ extern "C" {
 #define PCS_ELAUNCH (-3)  /* hipLaunch / hipMemsetAsync failed (pcs_last_error has text) */
 #define PCS_EUNSUPPORTED (-4)
 
-#define PCS_ABI_VERSION 4
+#define PCS_ABI_VERSION 5
 
 int pcs_abi_version(void);
 const char *pcs_last_error(void);
@@ -369,6 +369,26 @@ int pcs_quantize_emit(const int32_t *flags, const int64_t *rank, const int64_t *
  * order doubles as the CSR of the segmented spvoxelize that follows. */
 int pcs_unique_emit(const int32_t *flags, const int64_t *rank, const int64_t *perm, const int64_t *sorted_keys,
                     int64_t n, int64_t *uniq, int64_t *inverse, int64_t *rowptr, void *stream);
+
+/* ---- fp32 convolution on the 16-bit MFMAs ("bf16x3", opt-in) ------------------------------------------
+ * The same operator as pcs_conv_gather_gemm_f32 (TS:torchsparse/backend/convolution/convolution_cuda.cu:53-165 in fp32),
+ * fp32 features in and out, with every operand split into three bf16 planes and six plane products accumulated in fp32:
+ * fp32-grade results (not bit-identical to an fp32 FMA chain), for callers that select it explicitly. gfx950 runs
+ * fp32-input MFMAs at 1/16 of the bf16 rate and has no TF32 path.
+ *   applies : cin % 8 == 0, cin >= 32, cout % 4 == 0, cout >= 32, K <= 32.
+ *   prepare : W (K, A, B) fp32 -> Wp: three planes in MFMA fragment order (transpose = 1: the dgrad weights);
+ *             bytes = pcs_conv_prepared_weights_x3_bytes(K, contraction, columns).
+ *   conv    : arguments as pcs_conv_gather_gemm_f32 with Wp instead of W; tile_rows as picked for the fp32 kernels.
+ */
+int pcs_conv_x3_applies(int32_t cin, int32_t cout, int32_t K);
+int32_t pcs_conv_x3_column_tiles(int32_t cout);
+int32_t pcs_conv_x3_emits_bn_partials(int32_t cin, int32_t cout, int32_t K, int32_t tile_rows);
+size_t pcs_conv_prepared_weights_x3_bytes(int32_t K, int32_t ccon, int32_t ccols);
+int pcs_conv_prepare_weights_x3(const float *W, int32_t K, int32_t A, int32_t B, int32_t transpose, void *Wp, void *stream);
+int pcs_conv_gather_gemm_f32_bf16x3(const float *src, int64_t n_src, int32_t cin, const void *Wp, int32_t K, int32_t cout,
+                                    const int32_t *pairs, int32_t src_col, const int32_t *seg, int32_t tile_rows,
+                                    int64_t n_dst, const float *bias, float *dst, double *bn_partial,
+                                    const int32_t *tile_order, void *stream);
 
 /* ---- half-precision convolution (bf16 / fp16 storage, 16-bit MFMA, fp32 accumulate) --------------
  * The mixed-precision path of the reference: under `--amp` its ops cast their inputs to half

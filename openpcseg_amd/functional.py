@@ -188,6 +188,23 @@ def get_wgrad_policy():
     return _WGRAD_POLICY["mode"]
 
 
+# fp32 forward / input-gradient convolution. "fp32" (library default): fp32 MFMA arithmetic (conv_os5_kernel). "bf16x3": layers
+# the split kernel serves (cin % 8 == 0, cin >= 32, cout >= 32) run conv_os5x_kernel -- fp32 in and out, every operand as three
+# bf16 planes, six plane products accumulated in fp32 on the 16-bit MFMAs (csrc/conv_wave5x.hip): fp32-grade, not bit-identical
+# to an fp32 FMA chain. Opt-in only; a caller that selects it states so (bench.py's `fp32_bf16x3` record).
+_CONV_POLICY = {"mode": "fp32"}
+
+
+def set_conv_policy(mode):
+    if mode not in ("fp32", "bf16x3"):
+        raise ValueError("conv policy must be 'fp32' or 'bf16x3'")
+    _CONV_POLICY["mode"] = mode
+
+
+def get_conv_policy():
+    return _CONV_POLICY["mode"]
+
+
 def _wgrad_split(cin, cout):
     return _WGRAD_POLICY["mode"] == "bf16x3" and cin >= 96 and cout >= 96 and cin % 4 == 0 and cout % 4 == 0
 
@@ -228,6 +245,10 @@ class _SparseConv(Function):
             x = input.contiguous().to(hd)
             wp = be.prepare_weights_h(w3.detach().float().contiguous(), hd, transpose=False)
             out = be.conv_gather_gemm_h(x, wp, k, cout, kmap, **kw)
+        elif hd is None and input.is_cuda and _CONV_POLICY["mode"] == "bf16x3" and be.conv_x3_applies(cin, cout, k):
+            x = input.contiguous().float()
+            wp = be.prepare_weights_x3(w3.detach().float().contiguous(), transpose=False)
+            out = be.conv_gather_gemm_x3(x, wp, k, cout, kmap, **kw)
         else:
             x = input.contiguous().float()
             out = be.conv_gather_gemm(x, w3.float().contiguous(), kmap, **kw)
@@ -260,6 +281,9 @@ class _SparseConv(Function):
             if hd is not None and be.conv_h_applies(cout, cin, k):
                 wp = be.prepare_weights_h(w3.detach().float().contiguous(), hd, transpose=True)
                 grad_input = be.conv_gather_gemm_h(grad_output.contiguous().to(hd), wp, k, cin, dmap)
+            elif hd is None and grad_output.is_cuda and _CONV_POLICY["mode"] == "bf16x3" and be.conv_x3_applies(cout, cin, k):
+                wp = be.prepare_weights_x3(w3.detach().float().contiguous(), transpose=True)
+                grad_input = be.conv_gather_gemm_x3(grad_output.contiguous().float(), wp, k, cin, dmap)
             else:
                 wt = be.transpose_weights(w3.detach().float().contiguous())
                 grad_input = be.conv_gather_gemm(grad_output.contiguous().float(), wt, dmap)

@@ -82,6 +82,13 @@ SIGNATURES = {
     "pcs_conv_prepare_weights_h": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_conv_gather_gemm_h": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32, _P, c_int32, c_int64,
                                          _P, _P, c_int32, _P, _P, _P]),
+    "pcs_conv_x3_applies": (c_int32, [c_int32, c_int32, c_int32]),
+    "pcs_conv_x3_column_tiles": (c_int32, [c_int32]),
+    "pcs_conv_x3_emits_bn_partials": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    "pcs_conv_prepared_weights_x3_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "pcs_conv_prepare_weights_x3": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "pcs_conv_gather_gemm_f32_bf16x3": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32, _P, c_int32, c_int64,
+                                                  _P, _P, _P, _P, _P]),
     "pcs_conv_wgrad_f32_bf16x3": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P,
                                             _P, c_size_t, _P]),
     "pcs_conv_wgrad_h": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P, _P, c_size_t, c_int32, _P]),
@@ -91,7 +98,7 @@ SIGNATURES = {
     "pcs_rows_argmax_gather_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
 }
 
-ABI_VERSION = 4  # include/pcseg_hip.h PCS_ABI_VERSION (4: tile order of the fused convolution)
+ABI_VERSION = 5  # include/pcseg_hip.h PCS_ABI_VERSION (5: fp32 convolution on the bf16 MFMAs, pcs_conv_*_x3; 4: tile order)
 _lib = None
 
 
@@ -618,6 +625,48 @@ class HipBackend:
                                                _ptr(dst), self._HALF[src.dtype], _ptr(part) if part is not None else None,
                                                _ptr(order) if order is not None else None,
                                                _stream()), "pcs_conv_gather_gemm_h")
+        if part is not None:
+            self._bn_reduce(part, t, kmap, cout, bn_sums)
+        return dst
+
+    # -- fp32 convolution on the 16-bit MFMAs (three bf16 planes per operand, opt-in) ------------------------------
+    def conv_x3_applies(self, cin, cout, k):
+        return bool(self.lib.pcs_conv_x3_applies(int(cin), int(cout), int(k)))
+
+    def prepare_weights_x3(self, weight, transpose):
+        """fp32 weights (K, A, B) -> three bf16 planes in MFMA fragment order (uint8 buffer) for conv_gather_gemm_x3.
+        transpose=False: forward (contract over A); True: dgrad (contract over B)."""
+        weight = _dev(weight, "weight", torch.float32)
+        k, a, b = weight.shape
+        con, cols = (b, a) if transpose else (a, b)
+        nbytes = self.lib.pcs_conv_prepared_weights_x3_bytes(k, con, cols)
+        if nbytes == 0 or not self.conv_x3_applies(con, cols, k):
+            raise RuntimeError("openpcseg_amd: shape (%d, %d, %d) is not served by the bf16x3 kernel" % (k, a, b))
+        wp = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+        _check(self.lib.pcs_conv_prepare_weights_x3(_ptr(weight), k, a, b, int(bool(transpose)), _ptr(wp), _stream()),
+               "pcs_conv_prepare_weights_x3")
+        return wp
+
+    def conv_gather_gemm_x3(self, src, wp, k, cout, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True):
+        """fp32 fused conv on the bf16 MFMAs: src (n, cin) fp32, wp = prepare_weights_x3(...); fp32 out (fp32-grade)."""
+        src = _dev(src, "input", torch.float32)
+        cin = src.shape[1]
+        if k != kmap.K:
+            raise ValueError("kernel volume %d does not match the kernel map (%d)" % (k, kmap.K))
+        if bias is not None:
+            bias = _dev(bias, "bias", torch.float32)
+        t = tile_rows or self.tile_rows(cin, cout, kmap)   # the fp32 kernels' heights (same fp32 accumulator tile, <= its width)
+        seg = self._segments(kmap, t)
+        dst = torch.empty((kmap.n_dst, cout), dtype=torch.float32, device=src.device)
+        part = None
+        if bn_sums is not None and kmap.n_dst > 0 and self.lib.pcs_conv_x3_emits_bn_partials(cin, cout, k, t):
+            part = torch.empty(((kmap.n_dst + t - 1) // t) * 2 * cout, dtype=torch.float64, device=src.device)
+        order = self._tile_order(kmap, t) if (ordered == "force" or (ordered and self._wants_order(kmap))) and kmap.n_dst > 0 else None
+        _check(self.lib.pcs_conv_gather_gemm_f32_bf16x3(_ptr(src), src.shape[0], cin, _ptr(wp), k, cout, _ptr(kmap._pairs_raw),
+                                                        0, _ptr(seg), t, kmap.n_dst, _ptr(bias) if bias is not None else None,
+                                                        _ptr(dst), _ptr(part) if part is not None else None,
+                                                        _ptr(order) if order is not None else None, _stream()),
+               "pcs_conv_gather_gemm_f32_bf16x3")
         if part is not None:
             self._bn_reduce(part, t, kmap, cout, bn_sums)
         return dst

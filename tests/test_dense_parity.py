@@ -212,6 +212,97 @@ def test_rulebook_bench_batch_bit_exact(hip):
     assert np.array_equal(e2[1].cpu().numpy(), ns2) and np.array_equal(e2[0].cpu().numpy().astype(np.int64), nb2)
 
 
+# ---- fp32 convolution on the bf16 MFMAs (three planes per operand, six products; opt-in) --------------------------------
+X3_CASES = [(4, 128, 128, None), (4, 192, 128, 224), (8, 256, 256, None), (8, 384, 256, 256), (1, 96, 96, 384), (1, 96, 96, 192),
+            (1, 128, 96, None), (2, 64, 64, None), (1, 32, 32, None), (2, 32, 64, 128), (4, 160, 96, 112), (8, 256, 32, None),
+            (1, 56, 56, None), (2, 112, 112, None), (1, 168, 168, None), (4, 336, 224, None), (8, 672, 448, None), (2, 40, 56, None)]
+
+
+@pytest.mark.parametrize("stride,cin,cout,tile", X3_CASES)
+def test_conv_x3_forward_dense_map(hip, levels, stride, cin, cout, tile):
+    """conv_os5x_kernel (fp32 in / out, operands as three bf16 planes, six plane products) vs the oracle at the fp32
+    bound, bit-reproducible, with bias and BatchNorm partials; and fp32-GRADE: against a float64 evaluation its error is
+    at most twice the fp32 MFMA kernel's (the same statement the three-plane wgrad is held to)."""
+    entry, nbmaps, nbsizes, n = level_map(levels, stride)
+    rng = np.random.default_rng(stride * 100000 + cin * 100 + cout + 3)
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    w = (rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    dx, dw = t(x), t(w)
+    assert hip.conv_x3_applies(cin, cout, 27)
+    wp = hip.prepare_weights_x3(dw, transpose=False)
+    y = hip.conv_gather_gemm_x3(dx, wp, 27, cout, entry.fwd, tile_rows=tile)
+    assert y.dtype == torch.float32 and y.shape == (n, cout)
+    ref = orc.conv_fwd(x, w, nbmaps, nbsizes, (n, n))
+    close(y, ref, 2e-5)
+    assert torch.equal(y, hip.conv_gather_gemm_x3(dx, wp, 27, cout, entry.fwd, tile_rows=tile))
+    got = []
+    yb = hip.conv_gather_gemm_x3(dx, wp, 27, cout, entry.fwd, bias=t(bias), tile_rows=tile, bn_sums=got)
+    close(yb, ref + bias[None, :], 2e-5)
+    if got:
+        yd = yb.double()
+        assert torch.allclose(got[0][:cout], yd.sum(0), rtol=0, atol=1e-6 * float(yd.abs().sum(0).max()))
+        assert torch.allclose(got[0][cout:2 * cout], (yd * yd).sum(0), rtol=1e-6)
+    # fp32-grade: error against the double-precision result, on a row sample (torch fp64 index_add on the device)
+    rows = torch.arange(0, n, 7, device=DEV)
+    pairs = entry.fwd.pairs.long()
+    koff = entry.fwd.koff_host
+    y64 = torch.zeros(n, cout, dtype=torch.float64, device=DEV)
+    x64, w64 = dx.double(), dw.double()
+    for k in range(27):
+        pk = pairs[koff[k]:koff[k + 1]]
+        if pk.numel():
+            y64.index_add_(0, pk[:, 1], x64[pk[:, 0]] @ w64[k])
+    y32 = hip.conv_gather_gemm(dx, dw, entry.fwd, tile_rows=tile)
+    e3 = float((y.double() - y64)[rows].abs().max())
+    e32 = float((y32.double() - y64)[rows].abs().max())
+    assert e3 <= 2.0 * e32 + 1e-7 * float(y64.abs().max()), (e3, e32)
+
+
+@pytest.mark.parametrize("stride,cin,cout", [(4, 128, 128), (8, 384, 256), (1, 128, 96), (2, 112, 56), (4, 336, 224)])
+def test_conv_x3_dgrad_dense_map(hip, levels, stride, cin, cout):
+    """dgrad on the split kernel (weights prepared with transpose=True, input-sorted map) vs orc_conv_bwd."""
+    entry, nbmaps, nbsizes, n = level_map(levels, stride)
+    rng = np.random.default_rng(stride * 100000 + cin * 100 + cout + 5)
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    gy = rng.normal(size=(n, cout)).astype(np.float32)
+    w = (rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32)
+    ogx, _ = orc.conv_bwd(x, gy, w, nbmaps, nbsizes)
+    wpt = hip.prepare_weights_x3(t(w), transpose=True)
+    gx = hip.conv_gather_gemm_x3(t(gy), wpt, 27, cin, entry.rev)
+    close(gx, ogx, 2e-5)
+
+
+def test_conv3d_policy_bf16x3(hip, levels):
+    """functional.set_conv_policy('bf16x3'): conv3d forward and input gradient take the split kernel on the shapes it serves
+    and agree with the fp32 MFMA path at the fp32 bound; the policy is off by default and restored here."""
+    from openpcseg_amd import functional as F
+    from openpcseg_amd.sparse import SparseTensor
+    assert F.get_conv_policy() == "fp32"
+    c = t(levels[4])
+    g = torch.Generator(device=DEV).manual_seed(13)
+    x = torch.randn(c.shape[0], 64, device=DEV, generator=g)
+    w1 = (torch.randn(27, 64, 128, device=DEV, generator=g) * 0.03).requires_grad_(True)
+    w2 = (torch.randn(27, 128, 16, device=DEV, generator=g) * 0.03).requires_grad_(True)   # 16 columns: stays on fp32 MFMA
+
+    def run():
+        for w in (w1, w2):
+            w.grad = None
+        xs = SparseTensor(x.clone().requires_grad_(True), c, 4)
+        y = F.conv3d(F.conv3d(xs, w1, 3), w2, 3)
+        y.F.square().sum().backward()
+        return y.F.detach(), w1.grad.clone(), w2.grad.clone(), xs.F.grad.clone()
+    base = run()
+    F.set_conv_policy("bf16x3")
+    try:
+        split = run()
+    finally:
+        F.set_conv_policy("fp32")
+    for a, b in zip(split, base):
+        assert a.dtype == torch.float32 and (a - b).abs().max() <= 2e-5 * b.abs().max(), ((a - b).abs().max(), b.abs().max())
+    assert not torch.equal(split[0], base[0])   # it really ran another kernel
+
+
 # ---- half-precision path (bf16 / fp16 storage, 16-bit MFMA, fp32 accumulate) -------------------------------------
 def _round_half(a, dtype):
     """fp32 array -> the nearest bf16 / fp16 values, as fp32 (what the kernels see as their operands)."""

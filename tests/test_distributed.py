@@ -148,7 +148,7 @@ def test_bench_two_ranks_on_one_device():
     env = dict(os.environ, PCS_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--frames-per-gpu", "2", "--no-amp-line"]
+           "--frames-per-gpu", "2", "--no-amp-line", "--no-split-line"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -181,11 +181,12 @@ def test_bench_one_rank_over_rccl():
     rccl = run({"PCS_BENCH_FORCE_DIST": "1", "PCS_SYNC_WORLD1": "1"},
                [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                 "--master-port", str(_free_port())])
-    plain = run({}, [sys.executable], ["--no-amp-line"])
+    plain = run({}, [sys.executable], ["--no-amp-line", "--no-split-line"])
     assert rccl["n_gpus"] == 1 and rccl["value"] > 0 and rccl["roofline"]["launches"] > 0
     assert abs(rccl["config"]["loss"] - plain["config"]["loss"]) <= 2e-3 * abs(plain["config"]["loss"])
     # the default run carries the bf16 step as a secondary record (the reference trains under --amp)
     assert rccl["amp_bf16"]["value"] > 0 and rccl["amp_bf16"]["roofline"]["launches"] > 0 and "amp_bf16" not in plain
+    assert rccl["fp32_bf16x3"]["value"] > 0 and "fp32_bf16x3" not in plain   # and the split-kernel fp32 step
     # device trace of one step of the distributed job: when RCCL launches kernels for the gradient buckets (a one-rank
     # communicator may be served by copies), the first of them must start before backward's last conv has finished --
     # i.e. DDP's bucketed all-reduce overlaps backward instead of trailing it

@@ -138,7 +138,7 @@ def test_fullsize_reference_model_on_hip(cfg, hip):
     _assert_bounds(cfg + "/reference", m)
 
 
-def _workload(g, dev, amp=None, wgrad="fp32"):
+def _workload(g, dev, amp=None, wgrad="fp32", conv="fp32"):
     from seeded import seeded_state
     from openpcseg_amd import functional as pcsF
     from openpcseg_amd.sparse import SparseTensor
@@ -148,6 +148,7 @@ def _workload(g, dev, amp=None, wgrad="fp32"):
     seeded_state(model)
     model.to(dev).train()
     pcsF.set_wgrad_policy(wgrad)
+    pcsF.set_conv_policy(conv)
     try:
         if amp is None:
             out = model(batch)
@@ -157,18 +158,21 @@ def _workload(g, dev, amp=None, wgrad="fp32"):
         out["loss"].backward()
     finally:
         pcsF.set_wgrad_policy("fp32")
+        pcsF.set_conv_policy("fp32")
     return out["logits"].detach().float().cpu().numpy(), float(out["loss"].detach()), fs.model_grads(model)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("wgrad", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("wgrad", ["fp32", "bf16x3", "bf16x3+conv"])
 def test_fullsize_workload_minkunet18_on_hip(hip, wgrad):
     """Config 2 through this package's fused MinkUNet workload (what bench.py times): same frame, same weights, same
     reference logits AND gradients -- the autograd wiring of the fused graph (conv-epilogue BN statistics, strided-dy
     concat backward, column-block classifier) against the reference's plain graph. wgrad = "bf16x3" is the policy of
-    bench.py's fp32 line (three-plane split weight gradient on the >= 96-channel layers): the same bounds hold."""
+    bench.py's fp32 line (three-plane split weight gradient on the >= 96-channel layers); "bf16x3+conv" adds the split
+    forward / input-gradient kernel (bench.py's fp32_bf16x3 record): the same bounds hold for all three."""
     g = _golden("config2")
-    logits, loss, grads = _workload(g, torch.device("cuda:0"), wgrad=wgrad)
+    logits, loss, grads = _workload(g, torch.device("cuda:0"), wgrad=wgrad.split("+")[0],
+                                    conv="bf16x3" if wgrad.endswith("+conv") else "fp32")
     m = fs.compare(g, logits, loss, grads)
     m["loss_ref"] = float(g["loss"])
     _record("config2/workload" + ("" if wgrad == "fp32" else "/wgrad-" + wgrad), m)
