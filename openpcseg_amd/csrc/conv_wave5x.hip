@@ -20,6 +20,10 @@
 //   * column tiles are at most 96 wide: >= 112 output columns run as 64-column tiles (as the fp32 kernel does).
 #include "conv_common.h"
 
+#ifndef PCS_ABLATEX
+#define PCS_ABLATEX 0  /* debug builds: 1 no operand split (planes = raw bits), 2 no B reloads inside a group, 3 no A reloads, 4 no MFMA */
+#endif
+
 using namespace pcs;
 
 namespace {
@@ -119,7 +123,7 @@ struct Conv5xCfg {
 template <int NCTT, int NW, int MINW, int R, bool TAIL>
 __global__ void __launch_bounds__(64 * NW, MINW) conv_os5x_kernel(ConvArgsX a) {
   using C = Conv5xCfg<NCTT, NW, R>;
-  static_assert(NCTT % 2 == 0 && R == 2, "tile pairs; partial groups are single row blocks");
+  static_assert(NCTT % 2 == 0 && R >= 2 && R <= 4, "tile pairs; partial groups hold 1 .. R - 1 row blocks");
   const int T = a.tile_rows;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *acc_l = reinterpret_cast<float *>(smem);            // [T+1][ACS], row T = sink for padding rows
@@ -298,15 +302,22 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5x_kernel(ConvArgsX a) {
         const bool ok = ((vmask >> r) & 1u) && lane_ok;
         uint4 x0 = araw[r][0], x1 = araw[r][1];
         if (!ok) { x0 = make_uint4(0u, 0u, 0u, 0u); x1 = x0; }
+#if PCS_ABLATEX == 1
+        ap[r][0] = x0; ap[r][1] = x1; ap[r][2] = make_uint4(x0.x ^ x1.y, x0.y, x1.z, x0.w);
+#else
         split3(__uint_as_float(x0.x), __uint_as_float(x0.y), ap[r][0].x, ap[r][1].x, ap[r][2].x);
         split3(__uint_as_float(x0.z), __uint_as_float(x0.w), ap[r][0].y, ap[r][1].y, ap[r][2].y);
         split3(__uint_as_float(x1.x), __uint_as_float(x1.y), ap[r][0].z, ap[r][1].z, ap[r][2].z);
         split3(__uint_as_float(x1.z), __uint_as_float(x1.w), ap[r][0].w, ap[r][1].w, ap[r][2].w);
+#endif
       }
       // the operands of the NEXT step: this group's step s + 1, or step 0 of the wave's next group
       const bool more = s + 1 < NS;
       const Ctx &cn = more ? cur : nxt;
       const int sn = more ? s + 1 : 0;
+#if PCS_ABLATEX == 3
+      if (!more)
+#endif
       load_a(cn, sn);
       const char *wk_n = cn.Wk + (int64_t)sn * 1024;
 #pragma unroll
@@ -315,11 +326,17 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5x_kernel(ConvArgsX a) {
 #define PCS_X3_PROD(PA, PB_)                                                                        \
   _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                  \
   _Pragma("unroll") for (int r = 0; r < NRC; ++r)                                                    \
-      acc[r][t + tt] = mfma_x(ap[r][PA], bfr[PB_][t + tt], acc[r][t + tt]);
+      acc[r][t + tt] = PCS_ABLATEX == 4 ? (f32x4){acc[r][t + tt][0] + __uint_as_float(ap[r][PA].x ^ bfr[PB_][t + tt].x), 0, 0, 0} \
+                                         : mfma_x(ap[r][PA], bfr[PB_][t + tt], acc[r][t + tt]);
         PCS_X3_PROD(2, 0) PCS_X3_PROD(0, 2) PCS_X3_PROD(1, 1) PCS_X3_PROD(1, 0) PCS_X3_PROD(0, 1) PCS_X3_PROD(0, 0)
 #undef PCS_X3_PROD
-        load_b(wk_n, t);      // rolling single buffer: behind the last MFMA that reads these fragments
-        load_b(wk_n, t + 1);
+#if PCS_ABLATEX == 2
+        if (!more)
+#endif
+        {
+          load_b(wk_n, t);      // rolling single buffer: behind the last MFMA that reads these fragments
+          load_b(wk_n, t + 1);
+        }
       }
     }
     // ---- in-order commit of the group's row blocks (conv_wave5.hip: addresses before the ticket wait, three fenced phases,
@@ -384,7 +401,12 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5x_kernel(ConvArgsX a) {
   {  // wave-uniform loops, no barrier inside: the full groups, then the partial ones (= the commit order)
     int grp = wid;
     for (; grp < total_full; grp += C::NW) run_group(grp, std::integral_constant<int, R>{});
-    for (; grp < total_grp; grp += C::NW) run_group(grp, std::integral_constant<int, 1>{});
+    for (; grp < total_grp; grp += C::NW) {
+      const int nrp = __builtin_amdgcn_readfirstlane(cur.nr);  // wave-uniform: 1 .. R - 1 row blocks
+      if (R >= 4 && nrp == 3) run_group(grp, std::integral_constant<int, (R >= 4 ? 3 : 1)>{});
+      else if (R >= 3 && nrp == 2) run_group(grp, std::integral_constant<int, (R >= 3 ? 2 : 1)>{});
+      else run_group(grp, std::integral_constant<int, 1>{});
+    }
   }
   __syncthreads();
   const int rows = (int)((a.n_dst - row0) < (int64_t)T ? (a.n_dst - row0) : (int64_t)T);
@@ -486,16 +508,28 @@ extern "C" int pcs_conv_gather_gemm_f32_bf16x3(const float *src, int64_t n_src, 
   const bool nw8 = 2 * lds > 160 * 1024;  // 4-wave workgroups while two of them fit a CU's LDS, else one 8-wave workgroup
   const bool tail = (cin % 32) != 0;
   hipStream_t st = as_stream(stream);
+  // Row blocks per group. The kernel is bound by the vector-memory address path (TA 78-87 % busy, MFMA pipe 29-37 %,
+  // profiles/round3_convx.md): per row block and step a column tile costs 2 A loads + 3 N / R weight-fragment loads, so R is
+  // the lever -- four row blocks per group at <= 64 columns, three at 96 (what the 256 registers of two waves per SIMD hold).
+  static const int force_r = getenv("PCS_CONVX_R") ? atoi(getenv("PCS_CONVX_R")) : 0;  // A/B
+  // measured (profiles/round3_convx.md): R = 4 at 64 columns 1.11x R = 2 (256->256 985 -> 868 us), R = 3 at 96 columns 1.08-1.10x,
+  // 32 columns lose with R > 2
+  const int rsel = force_r >= 2 && force_r <= 4 ? (nctt == 6 && force_r > 3 ? 3 : force_r) : (nctt == 6 ? 3 : (nctt == 4 ? 4 : 2));
+#define PCS_CONV5X_R(N, RR)                                                                         \
+  if (tail) return nw8 ? launch_conv5x<N, 8, 2, RR, true>(a, st) : launch_conv5x<N, 4, 2, RR, true>(a, st);  \
+  return nw8 ? launch_conv5x<N, 8, 2, RR, false>(a, st) : launch_conv5x<N, 4, 2, RR, false>(a, st);
 #define PCS_CONV5X_CASE(N)                                                                          \
   case N:                                                                                           \
-    if (tail) return nw8 ? launch_conv5x<N, 8, 2, 2, true>(a, st) : launch_conv5x<N, 4, 2, 2, true>(a, st);  \
-    return nw8 ? launch_conv5x<N, 8, 2, 2, false>(a, st) : launch_conv5x<N, 4, 2, 2, false>(a, st);
+    if (rsel == 4 && N < 6) { PCS_CONV5X_R(N, (N < 6 ? 4 : 3)) }                                      \
+    if (rsel >= 3) { PCS_CONV5X_R(N, 3) }                                                           \
+    { PCS_CONV5X_R(N, 2) }
   switch (nctt) {
     PCS_CONV5X_CASE(2)
     PCS_CONV5X_CASE(4)
     PCS_CONV5X_CASE(6)
   }
 #undef PCS_CONV5X_CASE
+#undef PCS_CONV5X_R
   set_error("pcs_conv_gather_gemm_f32_bf16x3: unreachable");
   return PCS_EINVAL;
 }
