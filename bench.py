@@ -366,14 +366,16 @@ def comm_profile(step, rank):
     """One extra, untimed step under torch.profiler (N > 1 only): RCCL kernel time per step and how much of it ran
     beside compute kernels -- DDP's bucketed gradient all-reduce is supposed to overlap the rest of backward
     (R:train.py:215-219 wraps the model in DistributedDataParallel). Every rank runs the step; rank 0 reports."""
+    if rank != 0:  # every rank runs the step (its collectives); only rank 0 traces it
+        step()
+        torch.cuda.synchronize()
+        return None
     try:
         from torch.profiler import ProfilerActivity, profile
         torch.cuda.synchronize()
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
             step()
             torch.cuda.synchronize()
-        if rank != 0:
-            return None
         return comm_overlap_summary(prof.events())
     except Exception as e:  # measurement aid only: never fatal for the bench line
         return {"error": str(e)[:200]}

@@ -603,6 +603,7 @@ class HipBackend:
         wp = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
         _check(self.lib.pcs_conv_prepare_weights_h(_ptr(weight), k, a, b, int(bool(transpose)), self._HALF[dtype], _ptr(wp),
                                                    _stream()), "pcs_conv_prepare_weights_h")
+        wp._pcs_prepared = ("half", dtype, k, con, cols)  # what the opaque buffer holds: checked by the conv call
         return wp
 
     def conv_gather_gemm_h(self, src, wp, k, cout, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True):
@@ -613,6 +614,9 @@ class HipBackend:
         cin = src.shape[1]
         if k != kmap.K:
             raise ValueError("kernel volume %d does not match the kernel map (%d)" % (k, kmap.K))
+        meta = getattr(wp, "_pcs_prepared", None)
+        if meta is not None and meta != ("half", src.dtype, k, cin, cout):
+            raise ValueError("openpcseg_amd: prepared weights %s do not match this call (%s)" % (meta, ("half", src.dtype, k, cin, cout)))
         if bias is not None:
             bias = _dev(bias, "bias", torch.float32)
         t = tile_rows or self.tile_rows(cin, cout, kmap, self._HALF[src.dtype])
@@ -645,6 +649,7 @@ class HipBackend:
         wp = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
         _check(self.lib.pcs_conv_prepare_weights_x3(_ptr(weight), k, a, b, int(bool(transpose)), _ptr(wp), _stream()),
                "pcs_conv_prepare_weights_x3")
+        wp._pcs_prepared = ("x3", k, con, cols)
         return wp
 
     def conv_gather_gemm_x3(self, src, wp, k, cout, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True):
@@ -653,6 +658,9 @@ class HipBackend:
         cin = src.shape[1]
         if k != kmap.K:
             raise ValueError("kernel volume %d does not match the kernel map (%d)" % (k, kmap.K))
+        meta = getattr(wp, "_pcs_prepared", None)
+        if meta is not None and meta != ("x3", k, cin, cout):
+            raise ValueError("openpcseg_amd: prepared weights %s do not match this call (%s)" % (meta, ("x3", k, cin, cout)))
         if bias is not None:
             bias = _dev(bias, "bias", torch.float32)
         t = tile_rows or self.tile_rows(cin, cout, kmap)   # the fp32 kernels' heights (same fp32 accumulator tile, <= its width)
