@@ -402,7 +402,10 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
     output.kmaps = input.kmaps
     if bn_sums is not None:
         # bound to the feature tensor they describe: FusedBatchNorm ignores them if feats was replaced or modified
-        output.bn_sums = (bn_sums, output_feats, output_feats._version)
+        try:
+            output.bn_sums = (bn_sums, output_feats, output_feats._version)
+        except RuntimeError:  # inference tensors track no version counter: the BatchNorm runs its own statistics pass
+            pass
     return output
 
 
