@@ -10,9 +10,13 @@ builds, 56 fused sparse convs, 4 trilinear devoxelisations), CE + Lovasz loss, b
 synthetic ~120k-point scans (openpcseg_amd/workloads/synthetic.py), voxelised on the host by
 the reference's dataset transform BEFORE the timed region and resident in HBM; rulebooks are
 rebuilt every step (no cross-iteration cache, as in the reference).
-Prints ONE JSON line (rank 0) with the throughput, the roofline of the dominant kernel
-(fused gather-GEMM conv, fp32 MFMA) measured live with HIP events on the launch stream, and
-the reference's CPU backend timed on the host cores for a bounded sample (baseline only).
+Prints ONE JSON line (rank 0): `value` = the fp32 step (fp32 MFMA convolutions; weight gradient policy in
+`config.wgrad`) with the roofline of the dominant kernel (fused gather-GEMM conv) measured live with HIP
+events on the launch stream; `amp_bf16` = the same step under torch.autocast(bf16) (the reference trains
+under --amp); `fp32_bf16x3` = the fp32 step with the forward / input-gradient convolutions on the
+three-plane split kernel (fp32 in / out on the bf16 MFMAs, opt-in, fp32-grade); `comm` (N > 1) = RCCL time
+per step and its overlap with backward from a device trace; `cpu_baseline` = the reference's own compiled
+CPU backend on ONE full frame of the workload (N = 1 only, baseline only).
 """
 import argparse
 import json

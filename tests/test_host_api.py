@@ -271,3 +271,43 @@ def test_launch_shape_helpers_are_host_functions():
     assert lib.pcs_conv_h_applies(100, 64, 27) == 0 and lib.pcs_conv_uses_tile_order(100, 64, 27, 0) == 1  # cin % 4: fp32 only
     assert lib.pcs_conv_h_applies(51, 51, 27) == 0 and lib.pcs_conv_uses_tile_order(51, 51, 27, 0) == 0   # cr 1.6: generic kernel
 
+
+
+def test_comm_overlap_summary_on_synthetic_trace():
+    """bench.py's `comm` record: RCCL kernel time per step, the part that ran beside compute kernels, and whether the first
+    all-reduce kernel started before the last backward convolution finished -- on a hand-made device trace."""
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+
+    def ev(name, t0, t1):
+        return types.SimpleNamespace(name=name, device_type="DeviceType.CUDA", time_range=types.SimpleNamespace(start=t0, end=t1))
+    events = [ev("conv_os5_kernel<4>", 0, 1000), ev("wgrad2_kernel", 1000, 1800), ev("ncclDevKernel_AllReduce_Sum_f32", 900, 1500),
+              ev("conv_os5_kernel<6>", 1800, 2600), ev("ncclDevKernel_AllReduce_Sum_f32", 2500, 3100), ev("multi_tensor_apply", 3100, 3200),
+              types.SimpleNamespace(name="cpu_op", device_type="DeviceType.CPU", time_range=types.SimpleNamespace(start=0, end=5000))]
+    rec = bench.comm_overlap_summary(events)
+    assert rec["rccl_kernels"] == 2 and abs(rec["rccl_ms_per_step"] - 1.2) < 1e-9
+    assert abs(rec["overlapped_with_compute_ms"] - 0.7) < 1e-9 and abs(rec["exposed_ms"] - 0.5) < 1e-9   # 600 + 100 us beside compute
+    assert rec["first_rccl_kernel_before_last_conv_ends"] is True and abs(rec["first_rccl_to_last_conv_end_ms"] - 1.7) < 1e-9
+    assert bench.comm_overlap_summary([events[0]])["rccl_kernels"] == 0
+
+
+def test_arithmetic_policies_are_opt_in():
+    """The fp32 library path computes in fp32 MFMA arithmetic unless a caller selects a split policy explicitly."""
+    from openpcseg_amd import functional as F
+    assert F.get_conv_policy() == "fp32" and F.get_wgrad_policy() == "fp32"
+    for setter in (F.set_conv_policy, F.set_wgrad_policy):
+        with pytest.raises(ValueError):
+            setter("tf32")
+    F.set_conv_policy("bf16x3")
+    F.set_wgrad_policy("bf16x3")
+    try:
+        assert F.get_conv_policy() == "bf16x3" and F._wgrad_split(96, 96) and not F._wgrad_split(64, 96)
+    finally:
+        F.set_conv_policy("fp32")
+        F.set_wgrad_policy("fp32")
+    lib = native.load_library()
+    assert lib.pcs_conv_x3_applies(96, 96, 27) == 1 and lib.pcs_conv_x3_applies(56, 448, 27) == 1
+    assert lib.pcs_conv_x3_applies(4, 32, 27) == 0 and lib.pcs_conv_x3_applies(96, 16, 27) == 0 and lib.pcs_conv_x3_applies(100, 64, 27) == 0
+    assert lib.pcs_conv_x3_column_tiles(96) == 6 and lib.pcs_conv_x3_column_tiles(256) == 4 and lib.pcs_conv_x3_column_tiles(32) == 2
+    assert lib.pcs_conv_prepared_weights_x3_bytes(27, 96, 96) == 3 * 27 * 6 * 3 * 1024
