@@ -17,7 +17,10 @@
 //   * B fragments are SINGLE-buffered and rolling: the fragments of a pair of 16-column tiles are re-loaded for the next step
 //     right after that pair's 6 R MFMAs each have been issued -- with six MFMAs per product the rest of the step (>= 1000
 //     cycles) covers the L2 latency, and three planes of B double-buffered would not fit the registers;
-//   * column tiles are at most 96 wide: >= 112 output columns run as 64-column tiles (as the fp32 kernel does).
+//   * column tiles are at most 96 wide: >= 112 output columns run as 64-column tiles (as the fp32 kernel does);
+//   * groups hold R = 4 row blocks at 64 columns, 3 at 96, 2 at 32: the kernel is bound by the vector-memory address path
+//     (TA 78-87 % busy, MFMA pipe 29-37 %; without the MFMAs the launch takes the same time), a column tile costs 2 A loads
+//     + 3 N / R weight-fragment loads per row block and step, and R is what 256 registers allow (profiles/round3_convx.md).
 #include "conv_common.h"
 
 #ifndef PCS_ABLATEX
