@@ -310,30 +310,86 @@ def _cpu_baseline_worker():
     cores = CPU_BASELINE_THREADS if kind == "reference" else 1
     print(json.dumps({"value": round(1.0 / (fwd + bwd), 5), "unit": "frames/s", "cores": cores, "kind": kind,
                       "seconds_per_frame": round(fwd + bwd, 1),
-                      "sample": "ONE full frame of the bench workload (seed 0, %d rays, %d voxels), MinkUNet-34 cr1.0 "
-                                "fwd + loss + bwd measured once after a 500-ray warm-up: fwd %.1f s + bwd %.1f s, %d "
-                                "OpenMP/torch threads; no extrapolation (devoxelize backward = the restatement, the "
-                                "reference's CPU twin of it is broken)" % (n_rays, n_vox, fwd, bwd, CPU_BASELINE_THREADS)}),
+                      "sample": "n=1: one full frame (%d rays, %d voxels) MinkUNet-34 fwd %.0f s + bwd %.0f s after a 500-ray warm-up, no extrapolation"
+                                % (n_rays, n_vox, fwd, bwd)}),
           flush=True)
 
 
-def cpu_baseline():
+def _cpu_pytorch_worker():
+    """Runs in a subprocess: BASELINE config 1 -- the package's pure-PyTorch CPU path (openpcseg_amd/cpu_fallback.py: gather /
+    index_add_ / searchsorted forms of every op, TS:torchsparse/nn/functional/conv.py:67-79 semantics) under the reference's own
+    SPVCNN source (point branch + voxelize / devoxelize; the fused MinkUNet-18 workload where the reference sources are not
+    staged), one 2 000-point synthetic scan, fwd + loss + bwd, one warm-up + the median of three runs."""
+    import statistics
+    torch.set_num_threads(CPU_BASELINE_THREADS)
+    from openpcseg_amd import cpu_fallback
+    cpu_fallback.install()
+    torch.Tensor.cuda = lambda self, *a, **k: self   # the reference's model files call .cuda() on their targets (minkunet.py:425)
+    b = make_batch([0], n_points=2000)
+    model, what = None, "fused MinkUNet-18 workload"
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import fullsize as fs
+        import make_golden as mg
+        import openpcseg_amd
+        openpcseg_amd.install_reference_aliases()
+        dotted, cls = fs.MODEL_PATH["config3"]
+        model = getattr(mg.import_reference_model(dotted), cls)(mg._AttrDict(fs.MODEL_CFG["config3"]), 20)
+        what = "the reference's SPVCNN mk18 cr1.0 source"
+    except Exception:
+        from openpcseg_amd.workloads.minkunet import MK18_LAYERS
+        model = MinkUNet(num_class=20, num_layer=MK18_LAYERS, cr=1.0)
+    torch.manual_seed(0)
+    model.train()
+
+    def run():
+        batch = {"lidar": SparseTensor(b["lidar"].F, b["lidar"].C), "targets": SparseTensor(b["targets"].F, b["targets"].C),
+                 "offset": None}
+        t0 = time.perf_counter()
+        out = model(batch)
+        out = out[0] if isinstance(out, tuple) else out
+        out["loss"].backward()
+        model.zero_grad(set_to_none=True)
+        return time.perf_counter() - t0
+    run()
+    ts = [run() for _ in range(3)]
+    med = statistics.median(ts)
+    print(json.dumps({"value": round(1.0 / med, 4), "unit": "frames/s", "cores": CPU_BASELINE_THREADS, "kind": "pytorch",
+                      "seconds_per_frame": round(med, 3),
+                      "sample": "config 1: %s on the pure-PyTorch CPU path, one 2000-pt scan (%d voxels), fwd+bwd, median of 3 after 1 warm-up"
+                                % (what, b["lidar"].C.shape[0])}), flush=True)
+
+
+def _run_worker(flag, timeout_s):
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(CPU_BASELINE_THREADS), MKL_NUM_THREADS=str(CPU_BASELINE_THREADS),
                HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "1"],
-                           env=env, capture_output=True, text=True, timeout=CPU_BASELINE_TIMEOUT_S)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), flag, "1"], env=env, capture_output=True, text=True,
+                           timeout=timeout_s)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if line:
             return json.loads(line[-1])
-        return {"value": None, "unit": "frames/s", "cores": CPU_BASELINE_THREADS, "kind": "reference",
-                "sample": "cpu baseline worker failed: " + (r.stderr.strip().splitlines() or ["?"])[-1][:200]}
+        return {"value": None, "sample": "worker failed: " + (r.stderr.strip().splitlines() or ["?"])[-1][:160]}
     except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "frames/s", "cores": CPU_BASELINE_THREADS, "kind": "reference",
-                "sample": "cpu baseline exceeded the %d s cap on this host" % CPU_BASELINE_TIMEOUT_S}
+        return {"value": None, "sample": "worker exceeded the %d s cap on this host" % timeout_s}
+
+
+def cpu_baseline(compact=True):
+    """`cpu_baseline` of the bench line: the reference's compiled CPU backend on one full frame of the workload, and beside it
+    (`pytorch`) BASELINE config 1 on the package's pure-PyTorch CPU path."""
+    ref = _run_worker("--cpu-baseline-worker", CPU_BASELINE_TIMEOUT_S)
+    ref.setdefault("unit", "frames/s")
+    ref.setdefault("cores", CPU_BASELINE_THREADS)
+    ref.setdefault("kind", "reference")
+    pt = _run_worker("--cpu-pytorch-worker", 300)
+    if compact:
+        ref.pop("sample_long", None)
+        pt = {k: pt.get(k) for k in ("value", "seconds_per_frame", "sample") if k in pt}
+    ref["pytorch"] = pt
+    return ref
 
 
 def preheat(step, distributed, dev, window=10, max_windows=40):
@@ -426,6 +482,24 @@ def comm_overlap_summary(events):
             "first_rccl_to_last_conv_end_ms": (None if last_conv_end is None else round((last_conv_end - first_comm) / 1e3, 3))}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, exactly as the driver
+    would (R:dist_train.sh:17-19 -> torch.distributed.launch; one process per GPU, rendezvous on 127.0.0.1), and hand
+    the exit code on. Under a launcher (WORLD_SIZE set) this is a no-op; main() then checks WORLD_SIZE == --gpus."""
+    if "WORLD_SIZE" in os.environ or args.gpus <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -437,18 +511,39 @@ def main():
                     help="mixed precision like the reference's --amp (second bench line; the headline metric is fp32)")
     ap.add_argument("--no-amp-line", action="store_true", help="skip the secondary bf16 record of the default run")
     ap.add_argument("--no-split-line", action="store_true", help="skip the fp32_bf16x3 record (split-kernel convolutions) of the default run")
-    ap.add_argument("--wgrad", choices=["fp32", "bf16x3"], default="bf16x3",
+    ap.add_argument("--wgrad", choices=["fp32", "bf16x3"], default="fp32",
                     help="fp32 weight gradient of the >= 96-channel convolutions: fp32 MFMA, or fp32 operands as three bf16 planes "
                          "on the 16-bit MFMAs (fp32-grade: six plane products, error vs float64 <= 2x the fp32 MFMA path's)")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-pytorch-worker", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--models", default="auto",
+                    help="secondary `models` record: comma list of {minkunet18,spvcnn18,cylinder,rpvnet34,minkunet34}[:reference|workload], "
+                         "'auto' (N = 1 default run: the reference's four segmentor sources unmodified on the HIP backend + the fused "
+                         "MinkUNet-18 workload) or 'none'")
+    ap.add_argument("--verbose-json", action="store_true", help="print the long records (notes, clocks) instead of the compact line")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         _cpu_baseline_worker()
         return
+    if args.cpu_pytorch_worker:
+        _cpu_pytorch_worker()
+        return
+    self_launch(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to print a line for "
+                         "another job size" % (args.gpus, world))
+    if os.environ.get("PCS_BENCH_LAUNCH_CHECK") == "1":  # test rig (no GPU needed): the process group only
+        dist.init_process_group(backend="gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"n_gpus": dist.get_world_size(), "ranks_seen": int(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
     # PCS_BENCH_FORCE_DIST=1 (test rig): the distributed code path (process group, DDP, sync BatchNorm, barrier,
     # max-over-ranks) even for one rank, so that it runs over RCCL on a single-GPU box
     distributed = world > 1 or os.environ.get("PCS_BENCH_FORCE_DIST") == "1"
@@ -471,11 +566,11 @@ def main():
     n_vox = batch["lidar"].C.shape[0]
     be = native.backend()
     from openpcseg_amd import functional as pcsF
-    pcsF.set_wgrad_policy(args.wgrad)
 
-    def measure(amp, conv="fp32"):
+    def measure(amp, conv="fp32", wgrad="fp32"):
         """One bench line: fresh model / optimizer (same seed), preheat, W warm-up steps, K timed steps."""
         pcsF.set_conv_policy(conv)
+        pcsF.set_wgrad_policy(wgrad)
         torch.manual_seed(0)
         model = MinkUNet(num_class=20, num_layer=MK34_LAYERS, cr=1.0, dist=distributed).to(dev).train()
         if distributed:
@@ -537,6 +632,7 @@ def main():
             dt = float(tmax.item())
         comm = comm_profile(step, rank) if distributed and not one_dev else None
         pcsF.set_conv_policy("fp32")
+        pcsF.set_wgrad_policy("fp32")
         frames = args.frames_per_gpu * world * args.steps
         return {"value": round(frames / dt, 3), "ms_per_step": round(dt / args.steps * 1e3, 2),
                 "loss": round(float(loss.detach()), 4), "roofline": roof, "comm": comm}
@@ -548,45 +644,62 @@ def main():
                                                    "wgrad / statistics)" % amp))
 
     amp = None if args.amp == "off" else args.amp
-    head = measure(amp)
+    # headline: fp32 storage and fp32 MFMA arithmetic throughout (convolutions, weight gradient) unless --wgrad says otherwise
+    head = measure(amp, wgrad=args.wgrad if amp is None else "fp32")
     # the reference trains under --amp (R:dist_train.sh:18): the default run carries the bf16 step as a secondary record
     second = measure("bf16") if amp is None and not args.no_amp_line else None
-    # third record: the fp32 step with forward / input-gradient convolutions on the three-plane split kernel (fp32 in and out,
-    # fp32-grade arithmetic on the bf16 MFMAs; opt-in, never the headline value)
-    third = measure(None, conv="bf16x3") if amp is None and not args.no_split_line else None
+    # third record: the fp32 step with BOTH fp32-grade split policies (forward / input-gradient convolutions and the weight gradient
+    # of the wide layers with fp32 operands as three bf16 planes on the 16-bit MFMAs); opt-in arithmetic, never the headline value
+    third = measure(None, conv="bf16x3", wgrad="bf16x3") if amp is None and not args.no_split_line else None
+    models = None
+    if world == 1 and args.models != "none" and (args.models != "auto" or amp is None):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        try:
+            import modelbench
+            models = modelbench.run(args.models, dev, steps=min(args.steps, 3), warmup=min(args.warmup, 2))
+        except Exception as e:  # e.g. the reference sources are not staged on this box: the record says so
+            models = {"error": (type(e).__name__ + ": " + str(e))[:160]}
     if rank == 0:
+        def roof_compact(r):
+            if r is None:
+                return None
+            keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_us", "mfma_tflops")
+            out = {k: r[k] for k in keep if k in r}
+            out["kernel"] = r["kernel"].split(" (")[0]
+            clk = (r.get("clock") or {}).get("sclk_mhz_mean")
+            if clk:
+                out["sclk_mhz"] = clk
+            return out
+        pick = (lambda r: r) if args.verbose_json else roof_compact
         res = {
             "metric": "LiDAR frames/sec training MinkUNet-34 SemanticKITTI",
             "value": head["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": amp or "f32", "data": "synthetic",
-            "config": {"workload": workload(amp), "frames_per_gpu": args.frames_per_gpu,
-                       "global_batch": args.frames_per_gpu * world, "voxels_per_gpu_batch": n_vox,
-                       "parallelism": "dp%d" % world, "loss": head["loss"],
-                       "wgrad": ("fp32 MFMA (wgrad2_kernel)" if args.wgrad == "fp32" or amp is not None else
-                                 "bf16x3 on the >= 96-channel layers: fp32 operands split into three bf16 planes, six plane "
-                                 "products accumulated in fp32 on the 16-bit MFMAs (fp32-grade, tested against float64); fp32 MFMA elsewhere")},
-            "roofline": head["roofline"],
+            "config": {"workload": "MinkUNet-34 cr1.0 train step, %d x 120k-pt synthetic SemanticKITTI-shape scans per GPU, 0.05 m voxels, %s"
+                                   % (args.frames_per_gpu, "fp32" if amp is None else "autocast " + amp),
+                       "global_batch": args.frames_per_gpu * world, "voxels_per_gpu_batch": n_vox, "parallelism": "dp%d" % world,
+                       "wgrad": "fp32" if amp is not None else args.wgrad, "notes": "profiles/bench_notes.json"},
+            "roofline": pick(head["roofline"]),
         }
         if head["comm"] is not None:
             res["comm"] = head["comm"]
         if second is not None:
-            res["amp_bf16"] = {"value": second["value"], "unit": "frames/s", "ms_per_step": second["ms_per_step"],
-                               "dtype": "bf16", "steps": args.steps, "warmup": args.warmup, "workload": workload("bf16"),
-                               "loss": second["loss"], "roofline": second["roofline"]}
+            res["amp_bf16"] = {"value": second["value"], "ms_per_step": second["ms_per_step"], "dtype": "bf16",
+                               "roofline": pick(second["roofline"])}
             if second["comm"] is not None:
                 res["amp_bf16"]["comm"] = second["comm"]
         if third is not None:
-            res["fp32_bf16x3"] = {"value": third["value"], "unit": "frames/s", "ms_per_step": third["ms_per_step"], "dtype": "f32",
-                                  "steps": args.steps, "warmup": args.warmup, "loss": third["loss"],
-                                  "workload": workload(None) + "; forward and input-gradient convolutions with fp32 operands "
-                                              "split into three bf16 planes, six plane products accumulated in fp32 "
-                                              "(conv_os5x_kernel: fp32-grade, not bit-identical to fp32 FMA chains); weight "
-                                              "gradient as in the headline line",
-                                  "roofline": third["roofline"]}
+            r3 = third["roofline"] or {}
+            res["fp32_bf16x3"] = {"value": third["value"], "ms_per_step": third["ms_per_step"], "dtype": "f32",
+                                  "conv_tflops": r3.get("achieved"), "conv_frac_of_bf16_peak_over_6": r3.get("frac")}
+            if args.verbose_json:
+                res["fp32_bf16x3"]["roofline"] = third["roofline"]
+        if models is not None:
+            res["models"] = models
         if world == 1 and not args.no_cpu_baseline and amp is None:
-            res["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(res), flush=True)
+            res["cpu_baseline"] = cpu_baseline(compact=not args.verbose_json)
+        print(json.dumps(res, separators=(",", ":")), flush=True)
     if distributed:
         dist.destroy_process_group()
 

@@ -34,7 +34,7 @@ extern "C" {
 #define PCS_ELAUNCH (-3)  /* hipLaunch / hipMemsetAsync failed (pcs_last_error has text) */
 #define PCS_EUNSUPPORTED (-4)
 
-#define PCS_ABI_VERSION 5
+#define PCS_ABI_VERSION 6
 
 int pcs_abi_version(void);
 const char *pcs_last_error(void);
@@ -405,6 +405,14 @@ int pcs_conv_gather_gemm_f32_bf16x3(const float *src, int64_t n_src, int32_t cin
  *   wgrad   : pcs_conv_wgrad_f32 with half operands; accumulated and returned in fp32 (gW, ws as in _f32).
  */
 int pcs_conv_h_applies(int32_t cin, int32_t cout, int32_t K);
+/* The half convolution has two kernels behind pcs_conv_gather_gemm_h: conv_os5h_kernel (row-block groups per wave, ticket
+ * commit) and conv_ring6h_kernel (csrc/conv_ring6h.hip: the waves of a workgroup split the tile's COLUMNS; every weight
+ * slab enters the CU once per tile, gathered rows once per column tile through an LDS ring filled by LDS-DMA).
+ *   pcs_conv_ring_enable : mode 0 = never, 1 = wherever it applies, -1 = the library's per-shape policy (default; the
+ *                          environment variable PCS_CONVH_RING presets it). Returns the previous mode.
+ *   pcs_conv_ring_applies: 1 when pcs_conv_gather_gemm_h would run the ring kernel for this shape and tile height now. */
+int32_t pcs_conv_ring_enable(int32_t mode);
+int32_t pcs_conv_ring_applies(int32_t cin, int32_t cout, int32_t K, int32_t tile_rows);
 size_t pcs_conv_prepared_weights_bytes(int32_t K, int32_t contraction, int32_t columns);
 int pcs_conv_prepare_weights_h(const float *W, int32_t K, int32_t A, int32_t B, int32_t transpose, int32_t dtype,
                                void *Wp, void *stream);

@@ -4,7 +4,7 @@
 // and conv_block.hip (everything else); the weight gradient in conv_wgrad.hip.
 #include <math.h>
 
-#include "conv_common.h"
+#include "conv_half.h"
 
 using namespace pcs;
 
@@ -50,7 +50,7 @@ extern "C" int pcs_transpose_kab_f32(const float *src, int32_t K, int32_t A, int
 
 // Bumped whenever a fused-conv kernel, its launch shape picker or its epilogue changes: measurements keyed to kernels
 // (profiles/*_conv_traffic.json) carry the revision they were taken on and bench.py refuses a stale one.
-extern "C" const char *pcs_conv_kernel_revision(void) { return "r3.0-wave5+tail"; }
+extern "C" const char *pcs_conv_kernel_revision(void) { return "r4.0-ring6h"; }
 
 extern "C" int32_t pcs_conv_tile_rows(int32_t cin, int32_t cout) {
   (void)cin;
@@ -79,6 +79,23 @@ extern "C" int32_t pcs_conv_pick_tile_rows_dt(int64_t n_dst, int64_t n_pairs, in
   if (fixed > 0) return fixed;
   const double ppr = (double)n_pairs / (double)n_dst;
   const int nctt = conv_nctt(cout);
+  if (dtype != 0 && conv_ring_max_rows(cin, cout, K) > 0) {
+    // ring kernel (conv_ring6h.hip): one workgroup per CU, every weight slab enters the CU once per tile -- the tallest tile the
+    // LDS holds beside the operand ring amortises it best; below a few rounds of workgroups a shorter tile that fills the
+    // last round. Cost of a tile: its pairs + per offset the padding of half a row block and the weight slab (~24 rows' worth).
+    static const int ring_fixed = getenv("PCS_CONV_RING_TILE") ? atoi(getenv("PCS_CONV_RING_TILE")) : 0;
+    const int tmax = conv_ring_max_rows(cin, cout, K);
+    if (ring_fixed >= 32 && ring_fixed <= tmax && ring_fixed % 16 == 0) return ring_fixed;
+    const int64_t ncol = ceil_div(cout, 16 * nctt);
+    int best = tmax;
+    double best_cost = 0;
+    for (int T = tmax; T >= 96 && T >= tmax / 2; T -= 16) {
+      const double per_cu = (double)(ceil_div(n_dst, T) * ncol) / (double)device_cus();
+      const double c = 0.5 * (ceil(per_cu) + per_cu) * (T * ppr + 24.0 * K);
+      if (best_cost == 0 || c < best_cost * 0.98) { best = T; best_cost = c; }
+    }
+    return best;
+  }
   if (dtype != 0) {
     // 16-bit MFMA kernels: bound by the operand stream and, on the sparse levels, by the serial commit chain of a
     // workgroup -- two (or more) 4-wave workgroups per CU beat one tall 8-wave workgroup except on the >= 256-channel
@@ -149,7 +166,9 @@ extern "C" int32_t pcs_conv_emits_bn_partials(int32_t cin, int32_t cout, int32_t
     }
   } else {
     if (!convh_applies(cin, cout, K)) return 0;
-    nt = 2 * conv5_lds_est(tile_rows, nctt) > 160 * 1024 ? 512 : 256;
+    RingShape rs;
+    nt = conv_ring_applies(cin, cout, K, tile_rows, &rs) ? 64 * rs.nwaves()
+                                                         : (2 * conv5_lds_est(tile_rows, nctt) > 160 * 1024 ? 512 : 256);
   }
   return conv_stats_fit(tile_rows, 16 * nctt, nt) ? 1 : 0;
 }

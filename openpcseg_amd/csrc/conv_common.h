@@ -20,7 +20,7 @@
 #ifndef PCS_COMMIT_ATOMIC
 #define PCS_COMMIT_ATOMIC 0  /* wave5 / wave5h: 1 = commit with ds_add_f32 in ticket order. Measured in round 3 and left off: the LDS
                                 float atomic runs at ~1 lane per 4 clocks on gfx950 -- every shape 2-3x slower, fp32 and bf16 alike
-                                (profiles/round3_commit_ab.md). 0 = read-add-write under the ticket. */
+                                (profiles/round3_commit_ab.txt). 0 = read-add-write under the ticket. */
 #endif
 #ifndef PCS_COMMIT_NOWAIT
 #define PCS_COMMIT_NOWAIT 1  /* hand the ticket on with a bare ds_write_b32 behind the tile writes instead of waiting for their completion
@@ -76,11 +76,11 @@ __device__ __forceinline__ void lds_add(float *p, float v) {
   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-constexpr size_t kMaxDynLds = 160 * 1024 - 256;
+constexpr size_t kMaxDynLds = 160 * 1024 - 256;  // per-workgroup LDS ceiling of a gfx950 CU, minus the static part
 // sink rows below the accumulator tile of the wave5 kernels (atomic commit: one per lane group) and the LDS estimate
 // every launch-shape decision shares (tile + offset lists + slack)
 constexpr int kConvSinkRows = PCS_COMMIT_ATOMIC ? 4 : 1;
-inline size_t conv5_lds_est(int tile_rows, int nctt) { return (size_t)((tile_rows + kConvSinkRows) * (16 * nctt + 4)) * 4 + 1024; }  // per-workgroup LDS ceiling of a gfx950 CU, minus the static part
+inline size_t conv5_lds_est(int tile_rows, int nctt) { return (size_t)((tile_rows + kConvSinkRows) * (16 * nctt + 4)) * 4 + 1024; }
 
 // 16-column MFMA tiles per column tile of the wave kernels: 1, 2, 3, 4, 6 or 8. Up to 128 output columns are one
 // column tile; wider outputs take the width in {8, 6, 4} that pads the fewest columns (ties: the widest) -- 256 -> 8,

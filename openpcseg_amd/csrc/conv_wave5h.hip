@@ -18,7 +18,7 @@
 // the host layer and take the fp32 kernels. cin % 32 != 0 (56, 112, 168, 336 of RPVNet cr 1.75 ...) runs the TAIL
 // instance: the last step holds 8 / 16 / 24 channels, its out-of-range lane groups read a clamped in-row address
 // and are zeroed, and the prepared weights are zero-padded to the full step.
-#include "conv_common.h"
+#include "conv_half.h"
 
 using namespace pcs;
 
@@ -28,32 +28,6 @@ namespace {
 __device__ long long *g_convh_trace;   // [block][wave][8], as conv_wave5.hip: t_entry, t_start, t_end, loop, ticket, commit, groups, t_exit
 constexpr int kTraceBlocksH = 8192;
 #endif
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ f32x4 mfma_h(Bf16, const uint4 &a, const uint4 &b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 mfma_h(Fp16, const uint4 &a, const uint4 &b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-// local column (inside a CT-wide column tile) that lane n of 16-column tile tl feeds -- the interleave the commit and
-// the epilogue of the wave kernels assume (quads of 4 tiles: 64 q + 4 n + f; a pair: + 2 n + f; a single: + n)
-__host__ __device__ inline int h_local_col(int nctt, int tl, int n) {
-#if PCS_COMMIT_ATOMIC
-  // atomic commit (one ds_add_f32 per lane and element): tile tl owns the 16 CONSECUTIVE columns 16 tl .. 16 tl + 15, so
-  // the 16 lanes of a row hit 16 consecutive LDS banks (the 4-interleave put every lane on banks = f mod 4: 4-way
-  // conflicts). The fragment order of the prepared weights makes any column assignment free on the operand side.
-  (void)nctt;
-  return 16 * tl + n;
-#endif
-  const int n4 = nctt / 4, n2 = (nctt % 4) / 2;
-  if (tl < 4 * n4) return 64 * (tl / 4) + 4 * n + (tl % 4);
-  if (tl < 4 * n4 + 2 * n2) return 64 * n4 + 2 * n + (tl - 4 * n4);
-  return 64 * n4 + 32 * n2 + n;
-}
 
 // Wp block (k, global 16-column tile gt, step s) = 64 lanes x 8 halfs; lane 16 g + n, element j =
 //   Wmath[k][32 s + 8 g + j][column(gt, n)],  Wmath[k][c][col] = transpose ? W[k][col][c] : W[k][c][col]
@@ -86,20 +60,6 @@ __global__ void __launch_bounds__(256) prepare_weights_kernel(const float *__res
     Wp[i] = o;
   }
 }
-
-struct ConvArgsH {
-  const char *src;    // (n_src, cin) halfs
-  const char *Wp;     // prepared weights, fragment order
-  const float *bias;  // fp32, may be NULL
-  uint16_t *dst;      // (n_dst, cout) halfs
-  const int32_t *pairs;
-  const int32_t *seg;
-  int64_t n_dst;
-  int64_t ntiles;
-  int cin, cout, K, src_col, ncoltiles, xcd_remap, tile_rows, nt16, ns;
-  double *stats;  // optional [ntiles][2][cout], as ConvArgs::stats (over the ROUNDED values stored)
-  const int32_t *order;  // optional [ntiles]: workgroup slot -> row tile (heaviest first), as ConvArgs::order
-};
 
 template <int NCTT, int NW_, int R_>
 struct Conv5hCfg {
@@ -557,7 +517,7 @@ int launch_conv5h(const ConvArgsH &a, hipStream_t st) {
   return check_launch("pcs_conv_gather_gemm_h(wave5h)");
 }
 
-// row blocks per group of the half kernel per column-tile width (picked from profiles/round3_convh_group_rows.md)
+// row blocks per group of the half kernel per column-tile width (picked from profiles/round3_convh_group_rows.txt)
 inline int convh_group_rows(int nctt) {
   (void)nctt;
   return 2;
@@ -655,5 +615,9 @@ extern "C" int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t ci
   const int nctt = conv_nctt(cout);
   a.nt16 = (int)ceil_div(cout, 16 * nctt) * nctt;
   a.ns = (int)ceil_div(cin, 32);
+  a.ring_bt_cap = 0; a.ring_acc_off = 0;
+  // 96 / 128-column tiles of >= 64-channel layers whose tile fits beside the operand ring: the column-parallel ring kernel
+  // (conv_ring6h.hip: every weight slab enters the CU once per tile, gathered rows once per column tile)
+  if (conv_ring_applies(cin, cout, K, tile_rows, nullptr)) return launch_conv_ring6h(a, dtype, as_stream(stream));
   return dtype == 1 ? launch_h<Bf16>(a, as_stream(stream)) : launch_h<Fp16>(a, as_stream(stream));
 }

@@ -43,7 +43,11 @@ __device__ __forceinline__ f32x4 mfma_x(const uint4 &a, const uint4 &b, f32x4 c)
 __device__ __forceinline__ void split3(float x, float y, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
   const x_f32x2 v = {x, y};
   const x_bf16x2 h = __builtin_convertvector(v, x_bf16x2);
-  const x_f32x2 r1 = v - __builtin_convertvector(h, x_f32x2);
+  x_f32x2 r1 = v - __builtin_convertvector(h, x_f32x2);
+  // +-Inf, and finite values above the bf16 maximum that round to Inf: hi carries the Inf and the lower planes are zero
+  // (Inf - Inf would make them NaN and turn an Inf result of the fp32 kernel into NaN here); NaN stays NaN through hi
+  if (__builtin_isinf((float)h.x)) r1.x = 0.f;
+  if (__builtin_isinf((float)h.y)) r1.y = 0.f;
   const x_bf16x2 m = __builtin_convertvector(r1, x_bf16x2);
   const x_f32x2 r2 = r1 - __builtin_convertvector(m, x_f32x2);
   const x_bf16x2 l = __builtin_convertvector(r2, x_bf16x2);
@@ -396,7 +400,15 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5x_kernel(ConvArgsX a) {
         asm volatile("" ::: "memory");
       }
     }
+#if PCS_COMMIT_NOWAIT
+    // as conv_wave5.hip: the ticket store stays behind the tile writes in program order and the LDS executes one wave's
+    // instructions in order (the hardware assumption is stated once); PCS_COMMIT_NOWAIT=0 is the
+    // fenced form, bit-identical (tests/test_dense_parity.py::test_commit_variants_bit_identical on a variant library)
     if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(commit_lds), "v"(grp + 1) : "memory");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) __hip_atomic_store(commit, grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
     __builtin_amdgcn_s_setprio(0);
     cur = nxt;
     i = in;

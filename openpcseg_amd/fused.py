@@ -41,9 +41,12 @@ def _stats_group():
     import os
     if os.environ.get("PCS_BN_GROUP", "1") == "0":
         return None
-    # keyed on the identity of the default group: destroy_process_group() + re-init must not hand back a dead group
-    key = id(dist.distributed_c10d._get_default_group()), dist.get_world_size(), dist.get_backend()
-    g = _STATS_GROUP.get(key)
+    # bound to the default group OBJECT (held in the cache entry and compared with `is`: after destroy_process_group() +
+    # re-init CPython may hand the new group the old one's address, so an id() key could return a dead communicator)
+    default = dist.distributed_c10d._get_default_group()
+    key = (dist.get_world_size(), dist.get_backend())
+    hit = _STATS_GROUP.get(key)
+    g = hit[1] if hit is not None and hit[0] is default else None
     if g is None:
         _STATS_GROUP.clear()
         kw = {}
@@ -59,7 +62,7 @@ def _stats_group():
                 g = dist.new_group(backend=dist.get_backend())
             except Exception:
                 g = False
-        _STATS_GROUP[key] = g
+        _STATS_GROUP[key] = (default, g)
     return g or None
 
 

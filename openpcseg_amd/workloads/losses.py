@@ -56,8 +56,11 @@ def lovasz_softmax(probas, labels, ignore=None):
     else:
         # presence counts over the VALID points only: an out-of-range ignore label (255, -100, -1) must not be counted
         # into a clamped class (it would make that class "present" with no foreground point and add a max(err) term)
-        valid = labels != ignore
-        cnt = torch.bincount(labels.clamp(0, nc - 1), weights=valid.to(torch.float32), minlength=nc)
+        # (integer counting into an extra bin: a float-weighted bincount is a non-deterministic CUDA op). Labels outside
+        # [0, nc) that are NOT the ignore label (a negative label, 255 with ignore = 0) are invalid too: neither counted
+        # nor allowed an error term.
+        valid = (labels != ignore) & (labels >= 0) & (labels < nc)
+        cnt = torch.bincount(torch.where(valid, labels, torch.full_like(labels, nc)), minlength=nc + 1)[:nc]
     cls = (cnt > 0).nonzero().squeeze(1)  # one host sync
     if cls.numel() == 0:
         return probas.sum() * 0.0

@@ -441,3 +441,102 @@ def test_half_conv_epilogue_bn_statistics(hip, levels, dtype):
     yd = y.double()
     assert torch.allclose(got[0][:96], yd.sum(0), rtol=0, atol=1e-6 * float(yd.abs().sum(0).max()))
     assert torch.allclose(got[0][96:192], (yd * yd).sum(0), rtol=1e-6)
+
+
+def test_conv_x3_nonfinite_inputs_follow_the_fp32_kernel(hip, levels):
+    """+-Inf features (and finite ones above the bf16 maximum, whose high plane rounds to Inf) give Inf where the fp32
+    MFMA kernel gives Inf / a huge finite value -- never NaN from Inf - Inf in the lower planes (split3); NaN in, NaN out."""
+    entry, nbmaps, nbsizes, n = level_map(levels, 4)
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=(n, 64)).astype(np.float32)
+    w = np.abs(rng.normal(size=(27, 64, 64)) / 40).astype(np.float32) + 1e-3   # positive weights: Inf * w stays +-Inf
+    x[5, 3], x[900, 10], x[2000, 7] = np.inf, -np.inf, 3.4e38
+    x[3000, 1] = np.nan
+    dx, dw = t(x), t(w)
+    y32 = hip.conv_gather_gemm(dx, dw, entry.fwd)
+    y3 = hip.conv_gather_gemm_x3(dx, hip.prepare_weights_x3(dw, transpose=False), 27, 64, entry.fwd)
+    assert torch.equal(torch.isnan(y3), torch.isnan(y32))
+    big32 = torch.isinf(y32) | (y32.abs() > 1e37)
+    assert torch.equal(torch.isinf(y3) | (y3.abs() > 1e37), big32)
+    assert torch.equal(torch.sign(y3[big32]), torch.sign(y32[big32]))
+    ok = ~(big32 | torch.isnan(y32))
+    assert float((y3[ok] - y32[ok]).abs().max()) <= 2e-5 * float(y32[ok].abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("stride,cin,cout,tile", [(1, 96, 96, None), (1, 96, 96, 48), (2, 128, 96, 304), (4, 64, 128, None),
+                                                  (4, 192, 128, 208), (8, 256, 256, 80), (8, 384, 256, None), (8, 512, 96, None)])
+def test_ring_conv_forward_dense_map(hip, levels, dtype, stride, cin, cout, tile):
+    """conv_ring6h_kernel (column-parallel waves, gathered rows through the LDS ring) on the shapes it serves: one to four
+    32-channel steps per weight chunk, one to four chunks, 96 / 128-column tiles, partial last tiles, the tallest and very
+    short tiles, with and without the tile order; against the oracle on the same half-rounded operands, bit-reproducible,
+    and bit-identical to itself under the heaviest-first order."""
+    prev = hip.lib.pcs_conv_ring_enable(1)   # the kernel under test, whatever the library's per-shape policy says
+    try:
+        _ring_case(hip, levels, dtype, stride, cin, cout, tile)
+    finally:
+        hip.lib.pcs_conv_ring_enable(prev)
+
+
+def _ring_case(hip, levels, dtype, stride, cin, cout, tile):
+    entry, nbmaps, nbsizes, n = level_map(levels, stride)
+    assert hip.lib.pcs_conv_ring_applies(cin, cout, 27, tile or hip.tile_rows(cin, cout, entry.fwd, hip._HALF[dtype])) == 1
+    rng = np.random.default_rng(stride * 100000 + cin * 100 + cout + 17)
+    x = _round_half(rng.normal(size=(n, cin)).astype(np.float32), dtype)
+    w = _round_half((rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32), dtype)
+    bias = rng.normal(size=cout).astype(np.float32)
+    wp = hip.prepare_weights_h(t(w), dtype, transpose=False)
+    dx = t(x).to(dtype)
+    y = hip.conv_gather_gemm_h(dx, wp, 27, cout, entry.fwd, tile_rows=tile, ordered=False)
+    close_half(y, orc.conv_fwd(x, w, nbmaps, nbsizes, (n, n)), dtype)
+    assert torch.equal(y, hip.conv_gather_gemm_h(dx, wp, 27, cout, entry.fwd, tile_rows=tile, ordered="force"))
+    got = []
+    yb = hip.conv_gather_gemm_h(dx, wp, 27, cout, entry.fwd, bias=t(bias), tile_rows=tile, bn_sums=got)
+    close_half(yb, orc.conv_fwd(x, w, nbmaps, nbsizes, (n, n)) + bias[None, :], dtype)
+    if got:   # BatchNorm partials of the write-back: the statistics pass over the stored values
+        ref = hip.bn_stats(yb)
+        assert torch.allclose(got[0], ref, rtol=1e-9, atol=1e-6 * float(ref.abs().max()))
+
+
+def test_commit_variants_bit_identical(hip, levels):
+    """PCS_COMMIT_NOWAIT=0 / PCS_COMMIT_PHASED=0 (the fenced ticket hand-over and the compiler-interleaved commit kept behind
+    macros in conv_wave5.hip, conv_wave5h.hip and conv_wave5x.hip) produce the same bits as the default build: a variant
+    library is built here (hipcc is on the GPU box too) and both libraries run the same launches in subprocesses."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["bash", os.path.join(root, "tools", "build_variant_lib.sh"), "fenced", "-DPCS_COMMIT_NOWAIT=0",
+                        "-DPCS_COMMIT_PHASED=0"], capture_output=True, text=True, timeout=900)
+    lib = os.path.join(root, "openpcseg_amd", "lib", "dbg", "fenced.so")
+    if r.returncode != 0 or not os.path.exists(lib):
+        pytest.skip("variant library did not build here: " + r.stderr[-300:])
+    code = r"""
+import hashlib, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from openpcseg_amd import functional as F, native
+from openpcseg_amd.workloads.synthetic import make_batch
+be = native.backend()
+c = make_batch([0], n_points=30000)["lidar"].C.cuda()
+c = c[torch.argsort(F.sphash(c))].contiguous()
+e = F.build_kernel_map(c, c, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+torch.manual_seed(0)
+h = hashlib.sha256()
+for cin, cout in [(64, 64), (96, 96), (128, 96), (32, 32)]:
+    x = torch.randn(c.shape[0], cin, device="cuda"); w = torch.randn(27, cin, cout, device="cuda") * 0.05
+    h.update(be.conv_gather_gemm(x, w, e.fwd).cpu().numpy().tobytes())
+    if cin >= 64:
+        h.update(be.conv_gather_gemm_x3(x, be.prepare_weights_x3(w, transpose=False), 27, cout, e.fwd).cpu().numpy().tobytes())
+        xb = x.bfloat16()
+        h.update(be.conv_gather_gemm_h(xb, be.prepare_weights_h(w, torch.bfloat16, transpose=False), 27, cout, e.fwd).float().cpu().numpy().tobytes())
+print("HASH", h.hexdigest())
+""" % root
+    out = []
+    for extra in ({}, {"PCS_LIB_PATH": lib}):
+        env = dict(os.environ, PCS_CONVH_RING="0", **extra)   # the half launches on the ticket kernel the macros belong to
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-800:]
+        out.append([l for l in p.stdout.splitlines() if l.startswith("HASH")][-1])
+    os.remove(lib)
+    assert out[0] == out[1]

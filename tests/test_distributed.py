@@ -270,3 +270,22 @@ def test_bench_two_ranks_over_rccl():
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["value"] > 0
     assert res["comm"]["rccl_kernels"] > 0 and res["comm"]["first_rccl_kernel_before_last_conv_ends"], res["comm"]
     assert res["amp_bf16"]["value"] > 0
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks (torch.distributed.run on 127.0.0.1, as
+    R:dist_train.sh:17-19 does) and the line it prints says n_gpus = 2; under a launcher whose WORLD_SIZE disagrees with
+    --gpus it refuses. PCS_BENCH_LAUNCH_CHECK=1: the process group only (gloo), no GPU needed."""
+    import json
+    import subprocess
+    env = dict(os.environ, PCS_BENCH_LAUNCH_CHECK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"n_gpus": 2, "ranks_seen": 2}
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "refusing" in (bad.stderr + bad.stdout)

@@ -44,6 +44,10 @@ class _Env:
             from openpcseg_amd import native
             monkeypatch.setattr(native, "_BACKEND", OracleBackend())
             monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+        elif kind == "torchcpu":  # BASELINE config 1: the package's own pure-PyTorch CPU path (explicit opt-in)
+            from openpcseg_amd import cpu_fallback, native
+            monkeypatch.setattr(native, "_BACKEND", cpu_fallback.TorchCpuBackend())
+            monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
         else:
             from openpcseg_amd import native
             assert isinstance(native.backend(), native.HipBackend)
@@ -60,6 +64,11 @@ def env_oracle(monkeypatch):
 @pytest.fixture()
 def env_hip(monkeypatch, hip):
     return _Env("hip", monkeypatch)
+
+
+@pytest.fixture()
+def env_torchcpu(monkeypatch):
+    return _Env("torchcpu", monkeypatch)
 
 
 def _load(dotted):
@@ -191,6 +200,17 @@ def test_reference_cylinder_on_our_api(gold, env_oracle):
 
 def test_reference_rpvnet_on_our_api(gold, env_oracle):
     _run_rpvnet(env_oracle, gold)
+
+
+# ---- BASELINE config 1: pure-PyTorch CPU path (openpcseg_amd/cpu_fallback.py), world_size 1, no GPU ----------------------------
+def test_config1_reference_spvcnn_on_the_pytorch_cpu_path(gold, env_torchcpu):
+    """SPVCNN (point branch + initial_voxelize / point_to_voxel / voxel_to_point) on the 2 000-point synthetic scan, every sparse op
+    through the torch gather / index_add_ / searchsorted path: the reference's logits and loss, forward + backward."""
+    _run_spvcnn(env_torchcpu, gold)
+
+
+def test_config1_reference_minkunet_on_the_pytorch_cpu_path(golden_e2e, env_torchcpu):
+    _run_minkunet(env_torchcpu, golden_e2e)
 
 
 # ---- HIP backend (the parity claim; runs on the MI355X box from the staged reference sources) ---------------------
