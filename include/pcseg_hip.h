@@ -405,14 +405,17 @@ int pcs_conv_gather_gemm_f32_bf16x3(const float *src, int64_t n_src, int32_t cin
  *   wgrad   : pcs_conv_wgrad_f32 with half operands; accumulated and returned in fp32 (gW, ws as in _f32).
  */
 int pcs_conv_h_applies(int32_t cin, int32_t cout, int32_t K);
-/* The half convolution has two kernels behind pcs_conv_gather_gemm_h: conv_os5h_kernel (row-block groups per wave, ticket
- * commit) and conv_ring6h_kernel (csrc/conv_ring6h.hip: the waves of a workgroup split the tile's COLUMNS; every weight
- * slab enters the CU once per tile, gathered rows once per column tile through an LDS ring filled by LDS-DMA).
- *   pcs_conv_ring_enable : mode 0 = never, 1 = wherever it applies, -1 = the library's per-shape policy (default; the
- *                          environment variable PCS_CONVH_RING presets it). Returns the previous mode.
- *   pcs_conv_ring_applies: 1 when pcs_conv_gather_gemm_h would run the ring kernel for this shape and tile height now. */
-int32_t pcs_conv_ring_enable(int32_t mode);
-int32_t pcs_conv_ring_applies(int32_t cin, int32_t cout, int32_t K, int32_t tile_rows);
+/* The fused convolution has two kernel structures behind pcs_conv_gather_gemm_f32 / pcs_conv_gather_gemm_h: the
+ * wave-autonomous ones (conv_os5_kernel / conv_os5h_kernel: row-block groups per wave, ticket commit) and the ring ones
+ * (csrc/conv_ring6f.hip, conv_ring6h.hip: the waves of a workgroup split the tile's COLUMNS; gathered rows enter the CU once
+ * per column tile through an LDS ring filled by LDS-DMA, every weight slab once per tile; no ticket).
+ *   pcs_conv_ring_enable : kind 0 = the fp32 kernel, 1 = the half kernels; mode 0 = never, 1 = wherever it applies,
+ *                          -1 = the library's per-shape policy (default; the environment variables PCS_CONV_RINGF /
+ *                          PCS_CONVH_RING preset it). Returns the previous mode.
+ *   pcs_conv_ring_applies: 1 when the entry point would run the ring kernel for this shape and tile height now
+ *                          (dtype 0 fp32, 1 / 2 bf16 / fp16). */
+int32_t pcs_conv_ring_enable(int32_t kind, int32_t mode);
+int32_t pcs_conv_ring_applies(int32_t cin, int32_t cout, int32_t K, int32_t tile_rows, int32_t dtype);
 size_t pcs_conv_prepared_weights_bytes(int32_t K, int32_t contraction, int32_t columns);
 int pcs_conv_prepare_weights_h(const float *W, int32_t K, int32_t A, int32_t B, int32_t transpose, int32_t dtype,
                                void *Wp, void *stream);

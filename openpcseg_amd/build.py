@@ -20,7 +20,8 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-
 # into v_pk_add_f32 at the price of two register moves each, inside the one serial chain of a workgroup
 EXTRA_FLAGS = {"conv_wave5.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"],
                "conv_wave5h.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"],
-               "conv_ring6h.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"]}
+               "conv_ring6h.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"],
+               "conv_ring6f.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"]}
 
 
 def sources():

@@ -52,6 +52,7 @@ struct ConvArgs {
   int cin, cout, K, src_col, ncoltiles, xcd_remap, tile_rows;
   double *stats;  // optional [ntiles][2][cout]: per-tile column sums / sums of squares of the rows written (BatchNorm)
   const int32_t *order;  // optional [ntiles]: workgroup slot -> row tile (heaviest first), nullptr = row order
+  int ring_acc_off = 0;  // ring kernel (conv_ring6f.hip): byte offset of the accumulator tile in LDS
 };
 
 // storage-format tags of the half-precision kernels (features / prepared weights / outputs)

@@ -21,37 +21,15 @@
 //     atomics, bit-reproducible; the commit of a row block is issued behind the MFMAs of the next one.
 // The tile is as tall as the LDS allows beside the ring (one workgroup per CU: W is amortised over more rows);
 // epilogue, BatchNorm partials, prepared-weight format, tile order and XCD mapping are shared with conv_wave5h.hip.
-#include "conv_half.h"
+#include "conv_ring.h"
 
 using namespace pcs;
 
 namespace {
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef unsigned v4u __attribute__((ext_vector_type(4)));  // native vectors: the HIP uint4 / float2 structs do not load across address spaces
-#define PCS_LDS(T) __attribute__((address_space(3))) T
-
-// LDS-DMA, 16 / 4 bytes per lane: lane l's bytes land at lds_dst + l * {16, 4}. M0 carries the (wave-uniform) LDS address
-// and is written in the same statement that reads it; hipcc neither counts nor waits for these loads (the loader wave
-// counts its own vmcnt).
-__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void glds4(const void *gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-// workgroup barrier without the fence of __syncthreads() (which would drain the loader's DMA queue and every compute wave's
-// weight prefetch): the compiler may not move memory operations across it, the hardware orders nothing but arrival
-__device__ __forceinline__ void ring_barrier() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
+typedef ring_v2f v2f;
+typedef ring_v4i v4i;
+typedef ring_v4u v4u;
 
 template <int NCTT_, int NC_, int KC_>
 struct RingCfg {
@@ -433,12 +411,3 @@ int launch_conv_ring6h(const ConvArgsH &a0, int dtype, hipStream_t st) {
 
 }  // namespace pcs
 
-extern "C" int32_t pcs_conv_ring_enable(int32_t mode) {
-  const int prev = pcs::conv_ring_mode();
-  pcs::conv_ring_mode() = mode > 0 ? 1 : (mode < 0 ? -1 : 0);
-  return prev;
-}
-
-extern "C" int32_t pcs_conv_ring_applies(int32_t cin, int32_t cout, int32_t K, int32_t tile_rows) {
-  return pcs::conv_ring_applies(cin, cout, K, tile_rows, nullptr) ? 1 : 0;
-}

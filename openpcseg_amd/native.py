@@ -78,8 +78,8 @@ SIGNATURES = {
     "pcs_quantize_flags": (c_int32, [_P, c_int64, _P, _P]),
     "pcs_quantize_emit": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "pcs_conv_h_applies": (c_int32, [c_int32, c_int32, c_int32]),
-    "pcs_conv_ring_enable": (c_int32, [c_int32]),
-    "pcs_conv_ring_applies": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    "pcs_conv_ring_enable": (c_int32, [c_int32, c_int32]),
+    "pcs_conv_ring_applies": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "pcs_conv_prepared_weights_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "pcs_conv_prepare_weights_h": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_conv_gather_gemm_h": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32, _P, c_int32, c_int64,

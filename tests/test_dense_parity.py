@@ -471,16 +471,16 @@ def test_ring_conv_forward_dense_map(hip, levels, dtype, stride, cin, cout, tile
     32-channel steps per weight chunk, one to four chunks, 96 / 128-column tiles, partial last tiles, the tallest and very
     short tiles, with and without the tile order; against the oracle on the same half-rounded operands, bit-reproducible,
     and bit-identical to itself under the heaviest-first order."""
-    prev = hip.lib.pcs_conv_ring_enable(1)   # the kernel under test, whatever the library's per-shape policy says
+    prev = hip.lib.pcs_conv_ring_enable(1, 1)   # the kernel under test, whatever the library's per-shape policy says
     try:
         _ring_case(hip, levels, dtype, stride, cin, cout, tile)
     finally:
-        hip.lib.pcs_conv_ring_enable(prev)
+        hip.lib.pcs_conv_ring_enable(1, prev)
 
 
 def _ring_case(hip, levels, dtype, stride, cin, cout, tile):
     entry, nbmaps, nbsizes, n = level_map(levels, stride)
-    assert hip.lib.pcs_conv_ring_applies(cin, cout, 27, tile or hip.tile_rows(cin, cout, entry.fwd, hip._HALF[dtype])) == 1
+    assert hip.lib.pcs_conv_ring_applies(cin, cout, 27, tile or hip.tile_rows(cin, cout, entry.fwd, hip._HALF[dtype]), hip._HALF[dtype]) == 1
     rng = np.random.default_rng(stride * 100000 + cin * 100 + cout + 17)
     x = _round_half(rng.normal(size=(n, cin)).astype(np.float32), dtype)
     w = _round_half((rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32), dtype)
@@ -540,3 +540,39 @@ print("HASH", h.hexdigest())
         out.append([l for l in p.stdout.splitlines() if l.startswith("HASH")][-1])
     os.remove(lib)
     assert out[0] == out[1]
+
+
+@pytest.mark.parametrize("stride,cin,cout,tile", [(1, 96, 96, None), (1, 32, 64, None), (1, 96, 96, 48), (2, 128, 96, 304), (4, 64, 128, None),
+                                                  (4, 192, 128, 208), (4, 64, 64, 384), (8, 256, 256, 80), (8, 384, 256, None),
+                                                  (8, 160, 192, None)])
+def test_ring_conv_f32_forward_dense_map(hip, levels, stride, cin, cout, tile):
+    """conv_ring6f_kernel (fp32 MFMA, column-parallel waves, gathered rows through the LDS ring) against the scalar oracle: one
+    and two 32-channel steps per weight chunk, one to six chunks, 64 / 96 / 128-column tiles in one to three column tiles, the
+    tallest and very short tiles; bit-reproducible, independent of the tile order, BatchNorm partials of the write-back."""
+    prev = hip.lib.pcs_conv_ring_enable(0, 1)
+    try:
+        entry, nbmaps, nbsizes, n = level_map(levels, stride)
+        assert hip.lib.pcs_conv_ring_applies(cin, cout, 27, tile or hip.tile_rows(cin, cout, entry.fwd), 0) == 1
+        rng = np.random.default_rng(stride * 100000 + cin * 100 + cout + 23)
+        x = rng.normal(size=(n, cin)).astype(np.float32)
+        w = (rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32)
+        bias = rng.normal(size=cout).astype(np.float32)
+        dx, dw = t(x), t(w)
+        y = hip.conv_gather_gemm(dx, dw, entry.fwd, tile_rows=tile, ordered=False)
+        ref = orc.conv_fwd(x, w, nbmaps, nbsizes, (n, n))
+        close(y, ref, 2e-5)
+        assert torch.equal(y, hip.conv_gather_gemm(dx, dw, entry.fwd, tile_rows=tile, ordered="force"))
+        got = []
+        yb = hip.conv_gather_gemm(dx, dw, entry.fwd, bias=t(bias), tile_rows=tile, bn_sums=got)
+        close(yb, ref + bias[None, :], 2e-5)
+        if got:
+            st = hip.bn_stats(yb)
+            assert torch.allclose(got[0], st, rtol=1e-9, atol=1e-6 * float(st.abs().max()))
+        # dgrad = the same kernel on the input-sorted map with per-offset transposed weights
+        gy = rng.normal(size=(n, cout)).astype(np.float32)
+        ogx, _ = orc.conv_bwd(x, gy, w, nbmaps, nbsizes)
+        if hip.lib.pcs_conv_ring_applies(cout, cin, 27, hip.tile_rows(cout, cin, entry.rev), 0):
+            gx = hip.conv_gather_gemm(t(gy), hip.transpose_weights(dw), entry.rev)
+            close(gx, ogx, 2e-5)
+    finally:
+        hip.lib.pcs_conv_ring_enable(0, prev)

@@ -10,7 +10,7 @@ name=$1; shift
 python -m openpcseg_amd.build > /dev/null
 mkdir -p $ROOT/openpcseg_amd/lib/dbg /tmp/pcsvar_$name
 for f in $ROOT/openpcseg_amd/csrc/conv*.hip; do
-  extra=""; case $(basename $f) in conv_wave5*.hip) extra="-fno-slp-vectorize";; esac  # as openpcseg_amd/build.py EXTRA_FLAGS
+  extra=""; case $(basename $f) in conv_wave5*.hip|conv_ring6*.hip) extra="-fno-slp-vectorize";; esac  # as openpcseg_amd/build.py EXTRA_FLAGS
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics -fPIC -Wno-unused-value -Wno-array-bounds $extra "$@" \
     -c $f -o /tmp/pcsvar_$name/$(basename $f).o &
 done

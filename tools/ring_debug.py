@@ -18,12 +18,34 @@ def main():
     npts = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
     dev = torch.device("cuda:0")
     be = native.backend()
-    be.lib.pcs_conv_ring_enable(1)
+    be.lib.pcs_conv_ring_enable(1, 1)
     coords = make_batch([0, 1], n_points=npts)["lidar"].C.to(dev)
     coords = coords[torch.argsort(F.sphash(coords))].contiguous()
     entry = F.build_kernel_map(coords, coords, (3, 3, 3), (1, 1, 1), (1, 1, 1))
     n = coords.shape[0]
     print("n=%d pairs=%d" % (n, entry.fwd.num_pairs), flush=True)
+    be.lib.pcs_conv_ring_enable(0, 1)
+    for cin, cout, tile in [(64, 128, None), (32, 64, None), (96, 96, None), (128, 96, 48), (256, 256, None), (64, 64, 96)]:  # fp32 ring vs the wave kernel
+        torch.manual_seed(cin * 5 + cout)
+        x = torch.randn(n, cin, device=dev)
+        w = torch.randn(27, cin, cout, device=dev) * 0.05
+        assert be.lib.pcs_conv_ring_applies(cin, cout, 27, tile or be.tile_rows(cin, cout, entry.fwd), 0) == 1
+        y = be.conv_gather_gemm(x, w, entry.fwd, tile_rows=tile)
+        be.lib.pcs_conv_ring_enable(0, 0)
+        ref = be.conv_gather_gemm(x, w, entry.fwd)
+        be.lib.pcs_conv_ring_enable(0, 1)
+        torch.cuda.synchronize()
+        d = (y - ref).abs()
+        bad = d > 2e-5 * ref.abs().max()
+        t = tile or be.tile_rows(cin, cout, entry.fwd)
+        print("f32 %d->%d tile=%d max_err=%.3e (ref max %.2f) bad=%d of %d" % (cin, cout, t, float(d.max()), float(ref.abs().max()),
+                                                                          int(bad.sum()), bad.numel()), flush=True)
+        if bad.any():
+            b = bad.cpu().numpy()
+            rows, cols = np.nonzero(b)
+            print("  bad rows: %d distinct; by row tile %s; by 16-column tile %s" % (len(set(rows.tolist())), np.bincount(rows // t)[:12].tolist(),
+                                                                                    np.bincount(cols // 16, minlength=cout // 16).tolist()))
+    be.lib.pcs_conv_ring_enable(0, -1)
     for cin, cout, tile in [(128, 128, 64), (128, 128, None), (96, 96, None), (64, 128, None), (256, 128, None), (192, 96, 96),
                             (384, 256, None), (128, 96, 48)]:
         torch.manual_seed(cin * 7 + cout)
