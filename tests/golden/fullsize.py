@@ -35,7 +35,12 @@ MODEL_CFG = {
                     PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96], cr=1.75, DROPOUT_P=0.0, LABEL_SMOOTHING=0.0,
                     IF_DIST=True),
 }
-MODEL_PATH = {"config2": ("pcseg.model.segmentor.voxel.minkunet.minkunet", "MinkUNet"),
+# config 2 on a TWO-frame batch (seeds 0 and 4): batch-level BatchNorm statistics, loss and gradients over frames that never
+# share a voxel (the batch index is part of every hashed coordinate) -- what the one-frame fixtures cannot pin
+MODEL_CFG["config2x2"] = MODEL_CFG["config2"]
+BATCH_SEEDS = {"config2x2": [0, 4]}
+MODEL_PATH = {"config2x2": ("pcseg.model.segmentor.voxel.minkunet.minkunet", "MinkUNet"),
+              "config2": ("pcseg.model.segmentor.voxel.minkunet.minkunet", "MinkUNet"),
               "config3": ("pcseg.model.segmentor.fusion.spvcnn.spvcnn", "SPVCNN"),
               "config4": ("pcseg.model.segmentor.voxel.cylinder3d.cylinder_ts", "Cylinder_TS"),
               "config5": ("pcseg.model.segmentor.fusion.rpvnet.rpvnet", "RPVNet")}
@@ -105,6 +110,11 @@ def cylinder_frame(seed, n_points=None):
 
 
 def build_inputs(cfg_name, SparseTensor, n_points=None):
+    if cfg_name in BATCH_SEEDS:
+        from openpcseg_amd.workloads.synthetic import make_batch
+        b = make_batch(BATCH_SEEDS[cfg_name], n_points=n_points)
+        return {"lidar": SparseTensor(b["lidar"].feats, b["lidar"].coords), "targets": SparseTensor(b["targets"].feats, b["lidar"].coords),
+                "offset": None}
     seed = FRAME_SEED[cfg_name]
     if cfg_name == "config4":
         return cylinder_frame(seed, n_points)
@@ -167,7 +177,7 @@ def run_train_step(cfg_name, model, batch):
     loss = ret["loss"]
     model.zero_grad(set_to_none=True)
     loss.backward()
-    return cap["logits"].detach().cpu().numpy(), float(loss.detach())
+    return cap["logits"].detach().float().cpu().numpy(), float(loss.detach())
 
 
 # ---- fingerprints -----------------------------------------------------------------------------------------------------

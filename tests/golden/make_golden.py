@@ -327,7 +327,7 @@ def rpvnet_inputs(seed=5, n_points=2000, h=64, w=512):
     return batch
 
 
-def run_reference_rpvnet():
+def run_reference_rpvnet(tag="rpv", in_dim=4, num_class=20, label_smoothing=0.1, seed=5):
     """RPVNet (config 5). range_lib has no CPU build in the reference: its two ops are served here by the
     restatement of RL:range_utils/src/*.cu (oracle.map_count / denselize_fwd); everything else is the reference."""
     fn = install_range_stub()
@@ -338,19 +338,24 @@ def run_reference_rpvnet():
     # initialised nn.SyncBatchNorm computes plain batch statistics (torch/nn/modules/batchnorm.py need_sync), so the
     # logits stay O(10) and an absolute bound means something. The range image is 16 x 128 so that 2000 rays fill it
     # (batch statistics over a mostly empty image blow the activations up).
-    cfg = _cfg(NAME="RPVNet", IN_FEATURE_DIM=4, BLOCK="ResBlock", NUM_LAYER=[2] * 8,
-               PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96], cr=0.25, LABEL_SMOOTHING=0.1)
+    cfg = _cfg(NAME="RPVNet", IN_FEATURE_DIM=in_dim, BLOCK="ResBlock", NUM_LAYER=[2] * 8,
+               PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96], cr=0.25, LABEL_SMOOTHING=label_smoothing)
     cfg["IF_DIST"] = True
     torch.manual_seed(0)
-    model = mod.RPVNet(cfg, 20)
+    model = mod.RPVNet(cfg, num_class)
     seeded_state(model)
     model.train()
     import fullsize
     fullsize.freeze_dropout(model)  # the range branch's hard-coded Dropout2d(0.2): random masks are not reproducible
-    batch = rpvnet_inputs(h=16, w=128)
-    keep = {"rpv_feats": batch["lidar"].feats.numpy().copy(), "rpv_coords": batch["lidar"].coords.numpy().copy(),
-            "rpv_labels": batch["targets"].feats.numpy().copy(), "rpv_range_image": batch["range_image"].numpy().copy(),
-            "rpv_range_pxpy": batch["range_pxpy"].numpy().copy()}
+    batch = rpvnet_inputs(seed=seed, h=16, w=128)
+    if in_dim == 5:  # Waymo's fifth point feature (elongation): a deterministic function of the point, as tests/golden/fullsize.py
+        f = batch["lidar"].feats
+        batch["lidar"].feats = torch.cat([f, torch.frac(f[:, :1] * 0.37 + f[:, 3:4] * 1.9).abs()], dim=1).contiguous()
+    if num_class > 20:  # use the whole label range of the head
+        batch["targets"].feats = (batch["targets"].feats + (batch["lidar"].coords[:, 0] % 2) * (num_class - 20)).long() % num_class
+    keep = {tag + "_feats": batch["lidar"].feats.numpy().copy(), tag + "_coords": batch["lidar"].coords.numpy().copy(),
+            tag + "_labels": batch["targets"].feats.numpy().copy(), tag + "_range_image": batch["range_image"].numpy().copy(),
+            tag + "_range_pxpy": batch["range_pxpy"].numpy().copy()}
     cap = {}
     model.classifier.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", o.detach().clone()))
     orig = torch.Tensor.cuda
@@ -359,8 +364,8 @@ def run_reference_rpvnet():
         ret, _, _ = model(batch)
     finally:
         torch.Tensor.cuda = orig
-    keep["rpv_logits"] = cap["logits"].numpy()
-    keep["rpv_loss"] = np.array(float(ret["loss"].detach()))
+    keep[tag + "_logits"] = cap["logits"].numpy()
+    keep[tag + "_loss"] = np.array(float(ret["loss"].detach()))
     return keep
 
 
@@ -417,6 +422,8 @@ def main_models():
     g.update(run_reference_spvcnn())
     g.update(run_reference_cylinder())
     g.update(run_reference_rpvnet())
+    # the Waymo head: 23 classes, 5 point features, no label smoothing (R:tools/cfgs/fusion/waymo/rpvnet_mk18_cr10.yaml:13-23)
+    g.update(run_reference_rpvnet(tag="rpw", in_dim=5, num_class=23, label_smoothing=0.0, seed=6))
     np.savez_compressed(os.path.join(OUT, "models_e2e_golden.npz"), **g)
     print("wrote models_e2e_golden.npz:", {k: v.shape for k, v in g.items() if "logits" in k})
 
@@ -457,6 +464,18 @@ def main_full(cfg_name):
     def devox_bwd(gout, idx, w, n):
         return torch.from_numpy(orc.devoxelize_bwd(gout.contiguous().numpy(), idx.numpy(), w.numpy(), int(n)))
     backend.devoxelize_backward_cpu = devox_bwd
+    if cfg_name in fs.BATCH_SEEDS:
+        # multi-frame batch: the reference's CPU kernel_hash reads the batch index of row 0 for every row (hash_cpu.cpp:29;
+        # its CUDA twin hash_cuda.cu:42-46 is right) -- called per frame here, which restates the CUDA semantics
+        kh_one = backend.kernel_hash_cpu
+
+        def kernel_hash_per_frame(idx, offsets):
+            out = torch.empty((offsets.shape[0], idx.shape[0]), dtype=torch.long)
+            for b in idx[:, 3].unique().tolist():
+                sel = (idx[:, 3] == b).nonzero().squeeze(1)
+                out[:, sel] = kh_one(idx[sel].contiguous(), offsets)
+            return out
+        backend.kernel_hash_cpu = kernel_hash_per_frame
     install_scatter_stub()
     rnf = install_range_stub()
     dotted, cls = fs.MODEL_PATH[cfg_name]
@@ -528,7 +547,7 @@ def main_cylinder():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cylinder":
         main_cylinder()
-    elif len(sys.argv) > 1 and sys.argv[1] in ("config2", "config3", "config4", "config5"):
+    elif len(sys.argv) > 1 and sys.argv[1] in ("config2", "config3", "config4", "config5", "config2x2"):
         main_full(sys.argv[1])
     elif len(sys.argv) > 1 and sys.argv[1] == "models":
         main_models()

@@ -153,7 +153,7 @@ def _run_cylinder(env, gold):
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
-def _run_rpvnet(env, gold):
+def _run_rpvnet(env, gold, tag="rpv", in_dim=4, num_class=20, label_smoothing=0.1):
     """Config 5 (range-point-voxel fusion): adds range_utils.map_count / denselize (K13/K14) to the surface.
     TRAIN mode with the shipped IF_DIST=True variant (the reference's IF_DIST=False RPVNet is broken, rpvnet.py:574;
     without a process group nn.SyncBatchNorm computes plain batch statistics): logits are O(10), the bound is the
@@ -162,25 +162,26 @@ def _run_rpvnet(env, gold):
     from seeded import seeded_state
     mg, mod = _load("pcseg.model.segmentor.fusion.rpvnet.rpvnet")
     mod.rnf = sys.modules["range_utils.nn.functional"]
-    cfg = mg._cfg(NAME="RPVNet", IN_FEATURE_DIM=4, BLOCK="ResBlock", NUM_LAYER=[2] * 8,
-                  PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96], cr=0.25, LABEL_SMOOTHING=0.1)
+    cfg = mg._cfg(NAME="RPVNet", IN_FEATURE_DIM=in_dim, BLOCK="ResBlock", NUM_LAYER=[2] * 8,
+                  PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96], cr=0.25, LABEL_SMOOTHING=label_smoothing)
     cfg["IF_DIST"] = True
-    model = mod.RPVNet(cfg, 20)
+    model = mod.RPVNet(cfg, num_class)
     seeded_state(model)
     model.to(env.dev).train()
     import fullsize
     fullsize.freeze_dropout(model)  # as the fixture: the range branch's Dropout2d(0.2) masks are not reproducible
-    coords = env.t(gold["rpv_coords"])
-    batch = {"lidar": SparseTensor(env.t(gold["rpv_feats"]), coords),
-             "targets": SparseTensor(env.t(gold["rpv_labels"]), coords), "offset": None,
-             "range_image": env.t(gold["rpv_range_image"]), "range_pxpy": env.t(gold["rpv_range_pxpy"])}
+    coords = env.t(gold[tag + "_coords"])
+    batch = {"lidar": SparseTensor(env.t(gold[tag + "_feats"]), coords),
+             "targets": SparseTensor(env.t(gold[tag + "_labels"]), coords), "offset": None,
+             "range_image": env.t(gold[tag + "_range_image"]), "range_pxpy": env.t(gold[tag + "_range_pxpy"])}
     cap = {}
     model.classifier.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", o.detach()))
     ret, _, _ = model(batch)
-    ref = gold["rpv_logits"]
+    ref = gold[tag + "_logits"]
+    assert ref.shape[1] == num_class and _np(cap["logits"]).shape == ref.shape
     assert np.abs(ref).max() < 100.0  # the fixture itself must be in the regime where an absolute bound is meaningful
     assert np.abs(_np(cap["logits"]) - ref).max() < 1e-3
-    assert abs(float(ret["loss"].detach()) - float(gold["rpv_loss"])) < 1e-3
+    assert abs(float(ret["loss"].detach()) - float(gold[tag + "_loss"])) < 1e-3
     ret["loss"].backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
@@ -200,6 +201,14 @@ def test_reference_cylinder_on_our_api(gold, env_oracle):
 
 def test_reference_rpvnet_on_our_api(gold, env_oracle):
     _run_rpvnet(env_oracle, gold)
+
+
+WAYMO = dict(tag="rpw", in_dim=5, num_class=23, label_smoothing=0.0)  # R:tools/cfgs/fusion/waymo/rpvnet_mk18_cr10.yaml:13-23
+
+
+def test_reference_rpvnet_waymo_head_on_our_api(gold, env_oracle):
+    """BASELINE config 5 says Waymo Open: 23 classes, 5 point features (elongation), no label smoothing."""
+    _run_rpvnet(env_oracle, gold, **WAYMO)
 
 
 # ---- BASELINE config 1: pure-PyTorch CPU path (openpcseg_amd/cpu_fallback.py), world_size 1, no GPU ----------------------------
@@ -232,6 +241,11 @@ def test_reference_cylinder_on_hip(gold, env_hip):
 @pytest.mark.gpu
 def test_reference_rpvnet_on_hip(gold, env_hip):
     _run_rpvnet(env_hip, gold)
+
+
+@pytest.mark.gpu
+def test_reference_rpvnet_waymo_head_on_hip(gold, env_hip):
+    _run_rpvnet(env_hip, gold, **WAYMO)
 
 
 # BASELINE configs 2-5 at FULL size (logits AND gradients): tests/test_fullsize_parity.py
