@@ -45,7 +45,8 @@ __device__ __forceinline__ void split3(float x, float y, uint32_t &hi, uint32_t 
   const x_bf16x2 h = __builtin_convertvector(v, x_bf16x2);
   x_f32x2 r1 = v - __builtin_convertvector(h, x_f32x2);
   // +-Inf, and finite values above the bf16 maximum that round to Inf: hi carries the Inf and the lower planes are zero
-  // (Inf - Inf would make them NaN and turn an Inf result of the fp32 kernel into NaN here); NaN stays NaN through hi
+  // (Inf - Inf would make them NaN). The products of that Inf with the signed lower planes of the other operand can still
+  // sum to NaN: an output the fp32 kernel makes Inf is non-finite here, Inf or NaN. NaN stays NaN through hi.
   if (__builtin_isinf((float)h.x)) r1.x = 0.f;
   if (__builtin_isinf((float)h.y)) r1.y = 0.f;
   const x_bf16x2 m = __builtin_convertvector(r1, x_bf16x2);

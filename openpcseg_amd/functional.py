@@ -351,7 +351,30 @@ class _PointwiseConv(Function):
         return gin, gw, None
 
 
+def _channel_padding(feats, weight):
+    """(pad_in, pad_out) that bring a layer whose channel counts are not 16-byte granular onto the MFMA kernels, else (0, 0).
+    The cr 1.6 model-zoo configs (R:tools/cfgs/voxel/waymo/minkunet_mk34_cr16.yaml:20, R:tools/cfgs/fusion/*/spvcnn_mk34_cr16.yaml:
+    51 / 102 / 153 / 204 / 409 channels) would otherwise run every layer on the generic kernels (conv_os4_kernel / conv_block:
+    5-25 TFLOP/s) in fp32 even under autocast. Zero channels change nothing: padded input columns meet zero weight rows, padded
+    output columns are cut off again; autograd differentiates the pad and the slice (gradients of the padding are dropped)."""
+    if not feats.is_cuda or weight.dim() != 3 or weight.shape[0] > 32:
+        return 0, 0
+    k, cin, cout = weight.shape
+    q = 8 if _amp_dtype(feats) is not None else 4   # 16 bytes of a row
+    pin, pout = (-cin) % q, (-cout) % q
+    if (pin == 0 and pout == 0) or cin + pin < 32:
+        return 0, 0
+    return pin, pout
+
+
 def _sparse_conv(feats, weight, entry, transposed, bn_stats):
+    pin, pout = _channel_padding(feats, weight)
+    if pin or pout:
+        cout = weight.shape[2]
+        feats = torch.nn.functional.pad(feats, (0, pin)) if pin else feats
+        weight = torch.nn.functional.pad(weight, (0, pout, 0, pin))
+        out = _SparseConv.apply(feats, weight, entry, transposed)
+        return (out[:, :cout].contiguous() if pout else out), None   # the epilogue statistics would cover the padded columns: not used
     if not bn_stats:
         return _SparseConv.apply(feats, weight, entry, transposed), None
     out, sums = _SparseConv.apply(feats, weight, entry, transposed, True)

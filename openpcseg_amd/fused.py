@@ -151,6 +151,10 @@ class FusedBatchNorm(nn.Module):
         x = input.feats
         r = residual.feats if isinstance(residual, SparseTensor) else residual
         tail = cat_with.feats if isinstance(cat_with, SparseTensor) else cat_with
+        if tail is not None and (x.shape[1] % 4 or tail.shape[1] % 4 or tail.shape[0] != x.shape[0]):
+            # the concat-fused apply pass moves 16-byte pieces: other widths (the cr 1.6 configs: 409 + 204 ...) concatenate with torch
+            y = self.forward(input, residual=residual, relu=relu)
+            return input._like(torch.cat([y.feats, tail.to(y.feats.dtype)], dim=1))
         if self.training:
             if not self.counted_by_parent:  # a model may bump all its counters with one _foreach_add_ per step
                 self.num_batches_tracked += 1

@@ -37,15 +37,17 @@ class ScatterMaxResult:
 class _ScatterMax(Function):
     @staticmethod
     def forward(ctx, src, index, dim_size):
-        out, arg = native.backend().scatter_max_fwd(src.contiguous(), index.contiguous().long(), dim_size)
-        ctx.for_backwards = (arg, src.shape[0])
+        # half inputs (the cylinder front-end under autocast): the maximum of half values is a half value, so taking it in
+        # fp32 and casting back is exact -- the same result torch_scatter's half kernel gives
+        out, arg = native.backend().scatter_max_fwd(src.float().contiguous(), index.contiguous().long(), dim_size)
+        ctx.for_backwards = (arg, src.shape[0], src.dtype)
         ctx.mark_non_differentiable(arg)
-        return out, arg
+        return out.to(src.dtype), arg
 
     @staticmethod
     def backward(ctx, grad_out, _grad_arg):
-        arg, n = ctx.for_backwards
-        return native.backend().scatter_max_bwd(grad_out.contiguous(), arg, n), None, None
+        arg, n, dtype = ctx.for_backwards
+        return native.backend().scatter_max_bwd(grad_out.float().contiguous(), arg, n).to(dtype), None, None
 
 
 def scatter_max(src, index, dim=0, out=None, dim_size=None):

@@ -148,6 +148,12 @@ def test_scatter_max_result_is_tuple_like(oracle_backend):
     assert scatter_max(src, idx, dim=0, dim_size=6)[0].shape == (6, 2)
     with pytest.raises(AssertionError):
         scatter_max(src, idx, dim=1)
+    # half inputs (the cylinder front-end under autocast): same dtype out, exact, gradient in the input's dtype
+    hsrc = src.to(torch.bfloat16).requires_grad_(True)
+    hout, harg = scatter_max(hsrc, idx, dim=0)
+    assert hout.dtype == torch.bfloat16 and hout.float().tolist() == out.tolist() and harg.tolist() == arg.tolist()
+    hout.sum().backward()
+    assert hsrc.grad.dtype == torch.bfloat16 and hsrc.grad.float().tolist() == [[0., 0.], [0., 0.], [1., 1.], [1., 1.]]
 
 
 def test_kmap_entry_reads_like_the_reference_list(golden, oracle_backend):

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-shape timing table of the fused conv / wgrad launches inside one MinkUNet-34 training
 step (HIP events on the launch stream). Usage: python tools/conv_layer_table.py [frames] [cr] [off|bf16|fp16]
+cr 1.6 = the model-zoo widths 51 / 102 / 153 / 204 / 409 (R:tools/cfgs/voxel/waymo/minkunet_mk34_cr16.yaml): the launches show the
+zero-padded shapes conv3d runs them at (52 / 104 ... in fp32, 56 / 104 ... under autocast).
 cr 1.75 on 4 frames = the voxel branch of BASELINE config 5 (RPVNet mk34 cr 1.75: widths 56/112/224/448/168, concat inputs
 672/336/224; BATCH_SIZE_PER_GPU 4, R:tools/cfgs/fusion/semantic_kitti/rpvnet_mk34_cr17_5.yaml)."""
 import collections
