@@ -34,7 +34,7 @@ extern "C" {
 #define PCS_ELAUNCH (-3)  /* hipLaunch / hipMemsetAsync failed (pcs_last_error has text) */
 #define PCS_EUNSUPPORTED (-4)
 
-#define PCS_ABI_VERSION 6
+#define PCS_ABI_VERSION 7
 
 int pcs_abi_version(void);
 const char *pcs_last_error(void);
@@ -456,6 +456,22 @@ int pcs_voxel_label_vote(const int64_t *inverse, const int64_t *labels, int64_t 
                          void *stream);
 int pcs_rows_argmax_gather_f32(const float *logits, int64_t m, int32_t c, const int64_t *inverse, int64_t n,
                                int64_t *out, void *stream);
+
+/* ---- Lovasz-softmax of the training criterion (the timed step's loss tail) -----------------
+ * lovasz_softmax(probas, labels, classes='present', per_image=False, ignore) of
+ * R:tools/utils/common/lovasz_losses.py:158-204 (+ lovasz_grad :23-35, flatten_probas :207-228) as the reference's
+ * criterion calls it (R:pcseg/loss/__init__.py:106-115), value AND gradient w.r.t. probas, every class in one radix
+ * sort instead of a sort / gather / three scans per class (csrc/lovasz.hip).
+ *   probas (n, num_class) float32 row-major, labels (n,) int64. has_ignore = 0: every label inside [0, num_class)
+ *   counts; has_ignore = 1: points labelled `ignore` (any value, also outside the class range) are dropped. Labels
+ *   outside [0, num_class) never count. loss = 1 DEVICE float (0 when no class is present); grad (n, num_class)
+ *   float32 = d loss / d probas, every element written (may be NULL: value only).
+ *   Ties between equal errors keep point order (what torch's stable descending sort gives the reference).
+ *   ws: pcs_lovasz_workspace_bytes(n, num_class, has_ignore, ignore) bytes (-1 + pcs_last_error on bad sizes;
+ *   20 B per point and class + the sort's temporaries). num_class <= 60, n * num_class < 2^32 - 1. */
+int64_t pcs_lovasz_workspace_bytes(int64_t n, int32_t num_class, int32_t has_ignore, int64_t ignore);
+int pcs_lovasz_softmax_f32(const float *probas, const int64_t *labels, int64_t n, int32_t num_class, int32_t has_ignore,
+                           int64_t ignore, float *loss, float *grad, void *ws, int64_t ws_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -98,9 +98,11 @@ SIGNATURES = {
     "pcs_cylinder_partition_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "pcs_voxel_label_vote": (c_int32, [_P, _P, c_int64, c_int64, c_int32, c_int64, _P, _P, _P, _P]),
     "pcs_rows_argmax_gather_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
+    "pcs_lovasz_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32, c_int64]),
+    "pcs_lovasz_softmax_f32": (c_int32, [_P, _P, c_int64, c_int32, c_int32, c_int64, _P, _P, _P, c_int64, _P]),
 }
 
-ABI_VERSION = 6  # include/pcseg_hip.h PCS_ABI_VERSION (6: ring kernel switch / query; 5: fp32 convolution on the bf16 MFMAs, pcs_conv_*_x3; 4: tile order)
+ABI_VERSION = 7  # include/pcseg_hip.h PCS_ABI_VERSION (7: pcs_lovasz_*; 6: ring kernel switch / query; 5: fp32 convolution on the bf16 MFMAs, pcs_conv_*_x3; 4: tile order)
 _lib = None
 
 
@@ -1026,6 +1028,26 @@ class HipBackend:
         _check(self.lib.pcs_rows_argmax_gather_f32(_ptr(logits), m, c, _ptr(inverse) if inverse is not None else None,
                                                    n, _ptr(out), _stream()), "pcs_rows_argmax_gather_f32")
         return out
+
+    # -- criterion tail ---------------------------------------------------------------------------
+    def lovasz_softmax(self, probas, labels, ignore=None, need_grad=True):
+        """-> (loss 0-dim float32, d loss / d probas (n, C) float32 or None); csrc/lovasz.hip."""
+        probas = _dev(probas, "probas", torch.float32)
+        labels = _dev(labels, "labels", torch.int64)
+        n, nc = probas.shape
+        if labels.numel() != n:
+            raise ValueError("openpcseg_amd: %d labels for %d probability rows" % (labels.numel(), n))
+        has_ignore, ign = (0, 0) if ignore is None else (1, int(ignore))
+        ws_bytes = self.lib.pcs_lovasz_workspace_bytes(n, nc, has_ignore, ign)
+        if ws_bytes < 0:
+            _check(-1, "pcs_lovasz_workspace_bytes")
+        ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=probas.device)
+        loss = torch.empty((), dtype=torch.float32, device=probas.device)
+        grad = torch.empty_like(probas) if need_grad else None
+        _check(self.lib.pcs_lovasz_softmax_f32(_ptr(probas), _ptr(labels), n, nc, has_ignore, ign, _ptr(loss),
+                                               _ptr(grad) if grad is not None else None, _ptr(ws), int(ws_bytes), _stream()),
+               "pcs_lovasz_softmax_f32")
+        return loss, grad
 
 
 _BACKEND = None

@@ -331,3 +331,42 @@ def sparse_quantize(points, voxel_size=(1, 1, 1)):
     inverse = np.empty(key.size, dtype=np.int64)
     inverse[order] = np.cumsum(head) - 1
     return c[index], index, inverse
+
+
+def lovasz_softmax(probas, labels, ignore=None):
+    """Lovasz-softmax, classes='present', per_image=False, with d loss / d probas, in float64 on the float32 inputs
+    (R:tools/utils/common/lovasz_losses.py:158-204: flatten_probas drops the ignored points :207-228, then per present
+    class errors = |fg - p_c|, descending sort, dot with lovasz_grad :23-35 of the sorted foreground; mean over the
+    classes). The sort is STABLE (ties keep point order), which is what torch's radix sort gives the reference on the
+    device. Labels outside [0, C) other than `ignore` are dropped like ignored ones (the reference would index-error
+    or silently never match them). -> (loss float, grad (n, C) float64)."""
+    p = np.asarray(probas, dtype=np.float32).astype(np.float64)
+    lab = np.asarray(labels).astype(np.int64)
+    n, nc = p.shape
+    valid = (lab >= 0) & (lab < nc)
+    if ignore is not None:
+        valid &= lab != ignore
+    grad = np.zeros((n, nc), np.float64)
+    rows = np.nonzero(valid)[0]
+    pv, lv = p[rows], lab[rows]
+    losses = []
+    for c in range(nc):
+        fg = (lv == c).astype(np.float64)
+        if fg.sum() == 0:
+            continue
+        err = np.abs(fg - pv[:, c])
+        perm = np.argsort(-err, kind="stable")
+        fgs = fg[perm]
+        gts = fgs.sum()
+        inter = gts - np.cumsum(fgs)
+        union = gts + np.cumsum(1.0 - fgs)
+        jac = 1.0 - inter / union
+        g = jac.copy()
+        g[1:] = jac[1:] - jac[:-1]
+        losses.append(float(np.dot(err[perm], g)))
+        d = np.zeros(len(rows))
+        d[perm] = g
+        grad[rows, c] = d * np.sign(pv[:, c] - fg)   # d|fg - p| / dp = sign(p - fg), 0 at a zero error
+    if not losses:
+        return 0.0, grad
+    return float(np.mean(losses)), grad / len(losses)

@@ -11,7 +11,7 @@ Known reference CPU-twin defects are worked around WITHOUT changing semantics:
   - kernel_hash_cpu uses row 0's batch index for every row (hash_cpu.cpp:29): called per batch;
   - devoxelize_backward_cpu is wrong (devoxelize_cpu.cpp:51-53): replaced by the restatement of
     devoxelize_cuda.cu:37-57 where a golden needs a backward pass (main_full).
-Usage: python tests/golden/make_golden.py [models | quantize | config2 | config3 | config4 | config5 | cylinder]
+Usage: python tests/golden/make_golden.py [models | quantize | lovasz | config2 | config3 | config4 | config5 | cylinder]
 """
 import os
 import sys
@@ -446,6 +446,49 @@ def main_quantize():
     print("wrote quantize_golden.npz:", {k: v.shape for k, v in g.items() if k.endswith("_vox")})
 
 
+def lovasz_cases():
+    """(name, probas (n, C) float32, labels (n,) int64, ignore) of the Lovasz-softmax golden: an ignored label inside
+    and outside the class range, no ignore, absent classes, saturated probabilities (exact 0 / 1 errors -> ties), two
+    valid points among ignored ones."""
+    rng = np.random.default_rng(23)
+    out = []
+    for name, n, nc, ign, hi in (("kitti", 6000, 20, 0, 20), ("ign255", 4000, 17, 255, 15), ("noign", 3000, 20, None, 20),
+                                 ("waymo", 5000, 23, 0, 23), ("tiny", 9, 5, 0, 5)):
+        z = rng.normal(size=(n, nc)).astype(np.float32) * 3
+        p = np.exp(z - z.max(1, keepdims=True))
+        p = (p / p.sum(1, keepdims=True)).astype(np.float32)
+        lab = rng.integers(0, hi, n).astype(np.int64)
+        if name == "kitti":
+            lab[lab == 7] = 3                      # an absent class
+            sat = rng.random(n) < 0.05             # saturated rows: one-hot probabilities, right and wrong
+            p[sat] = 0.0
+            p[sat, rng.integers(0, nc, int(sat.sum()))] = 1.0
+        if ign not in (None, 0):
+            lab[rng.random(n) < 0.1] = ign
+        if name == "tiny":
+            lab[:] = 0
+            lab[4], lab[7] = 3, 2   # (a single valid point breaks the reference: flatten_probas squeezes it to 1-D)
+        out.append((name, p, lab, ign))
+    return out
+
+
+def main_lovasz():
+    """lovasz_softmax(probas, labels, ignore) of the reference (tools/utils/common/lovasz_losses.py, imported by path) on
+    CPU float32, value and gradient w.r.t. probas."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_lovasz", "/root/reference/tools/utils/common/lovasz_losses.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = {}
+    for name, p, lab, ign in lovasz_cases():
+        tp = torch.from_numpy(p).requires_grad_(True)
+        loss = mod.lovasz_softmax(tp, torch.from_numpy(lab), ignore=ign)
+        grad, = torch.autograd.grad(loss, tp)
+        g[name + "_loss"], g[name + "_grad"] = np.float32(loss.item()), grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "lovasz_golden.npz"), **g)
+    print("wrote lovasz_golden.npz:", {k: float(v) for k, v in g.items() if k.endswith("_loss")})
+
+
 def main_full(cfg_name):
     """BASELINE configs 2-5 at full size (tests/golden/fullsize.py holds the shared definitions): the reference's own
     segmentor, fp32, ONE full synthetic frame (120 000 rays), TRAIN mode (batch statistics), forward + loss + backward
@@ -553,5 +596,7 @@ if __name__ == "__main__":
         main_models()
     elif len(sys.argv) > 1 and sys.argv[1] == "quantize":
         main_quantize()
+    elif len(sys.argv) > 1 and sys.argv[1] == "lovasz":
+        main_lovasz()
     else:
         main()

@@ -31,3 +31,29 @@ def seeded_state(model):
             v = 0.2 * (r - 0.5)
         sd[name] = v.to(t.dtype)
     model.load_state_dict(sd)
+
+
+def lovasz_grad_mismatch(probas, labels, ignore, ga, gb):
+    """Largest difference between two Lovasz-softmax gradients (n, C) where the function defines them: element by element
+    where a point's error is unique within its class, and as the SUM of the Jaccard weights (the gradient with the sign
+    of d|fg - p| / dp taken off) over each group of equal errors otherwise: the order inside a tie group -- saturated
+    probabilities -- is the sort implementation's, the group's total weight is not."""
+    import numpy as np
+    p = np.asarray(probas, dtype=np.float32)
+    lab = np.asarray(labels).astype(np.int64)
+    n, nc = p.shape
+    valid = (lab >= 0) & (lab < nc)
+    if ignore is not None:
+        valid &= lab != ignore
+    worst = float(np.abs(np.asarray(ga)[~valid] - np.asarray(gb)[~valid]).max()) if (~valid).any() else 0.0
+    rows = np.nonzero(valid)[0]
+    for c in range(nc):
+        fg = lab[rows] == c
+        err = np.abs(fg.astype(np.float32) - p[rows, c])
+        sgn = np.where(fg, -1.0, 1.0)
+        _, inv = np.unique(err, return_inverse=True)
+        sa = np.bincount(inv, weights=sgn * np.asarray(ga, dtype=np.float64)[rows, c])
+        sb = np.bincount(inv, weights=sgn * np.asarray(gb, dtype=np.float64)[rows, c])
+        if len(sa):
+            worst = max(worst, float(np.abs(sa - sb).max()))
+    return worst

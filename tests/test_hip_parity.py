@@ -847,3 +847,83 @@ def test_half_paths_empty_and_ragged(hip, dtype):
         hip.cylinder_partition(torch.zeros(4, 4, device=DEV), [0, -180, -4], [50, 180, 2], [1, 360, 32])   # grid < 2
     with pytest.raises(RuntimeError):
         hip.prepare_weights_h(torch.zeros(27, 5, 33, device=DEV), dtype, transpose=False)                # shape not served
+
+
+# ---- criterion tail: Lovasz-softmax in one sort ----------------------------------------------------------------------------
+def _lovasz_cases():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden import lovasz_cases
+    return lovasz_cases()
+
+
+def test_lovasz_softmax_golden_and_oracle(hip):
+    """pcs_lovasz_softmax_f32 against the reference's own lovasz_softmax (tests/golden/lovasz_golden.npz: value 2e-6,
+    gradient 2e-7 with tie groups compared by their total weight) and, element by element INCLUDING the ties, against
+    the float64 oracle with a stable sort: the kernel keeps point order inside a tie group like torch's device sort."""
+    import os
+    from seeded import lovasz_grad_mismatch
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lovasz_golden.npz"))
+    for name, p, lab, ign in _lovasz_cases():
+        loss, grad = hip.lovasz_softmax(t(p), t(lab), ign)
+        lo, go = orc.lovasz_softmax(p, lab, ign)
+        assert abs(float(loss) - float(g[name + "_loss"])) <= 2e-6, name
+        assert lovasz_grad_mismatch(p, lab, ign, grad.cpu().numpy(), g[name + "_grad"]) <= 2e-7, name
+        assert abs(float(loss) - lo) <= 1e-6 and np.abs(grad.cpu().numpy() - go).max() <= 2e-7, name
+        value_only, none = hip.lovasz_softmax(t(p), t(lab), ign, need_grad=False)
+        assert none is None and float(value_only) == float(loss)
+        again, grad2 = hip.lovasz_softmax(t(p), t(lab), ign)
+        assert float(again) == float(loss) and torch.equal(grad, grad2)   # no atomics on floats: bit-reproducible
+
+
+@pytest.mark.parametrize("n,nc,ign", [(300001, 20, 0), (1200000, 20, 0), (70000, 23, 255), (4097, 3, None), (2048, 60, 0)])
+def test_lovasz_softmax_large(hip, n, nc, ign):
+    """Bench-sized streams (1.2 M points x 19 class slots: several hundred scan blocks per class, a partial last block)
+    against the float64 oracle: loss 1e-6, gradient 2e-7 absolute; with saturated rows and an absent class."""
+    rng = np.random.default_rng(n)
+    z = (rng.normal(size=(n, nc)) * 4).astype(np.float32)
+    p = np.exp(z - z.max(1, keepdims=True))
+    p = (p / p.sum(1, keepdims=True)).astype(np.float32)
+    sat = rng.random(n) < 0.02
+    p[sat] = 0.0
+    p[sat, rng.integers(0, nc, int(sat.sum()))] = 1.0
+    lab = rng.integers(0, nc, n).astype(np.int64)
+    lab[lab == nc - 2] = 1
+    if ign is not None:
+        lab[rng.random(n) < 0.07] = ign
+    loss, grad = hip.lovasz_softmax(t(p), t(lab), ign)
+    lo, go = orc.lovasz_softmax(p, lab, ign)
+    assert abs(float(loss) - lo) <= 1e-6, (float(loss), lo)
+    assert np.abs(grad.cpu().numpy() - go).max() <= 2e-7   # (one fp32 rounding of a Jaccard value near 1, over the class count)
+
+
+def test_lovasz_softmax_edges_and_autograd(hip):
+    """No points, only ignored points, a single class; more than 60 classes refused with a message; the autograd
+    wrapper of the workload's criterion (`SegLoss`) gives the loss and logits gradient of the torch form."""
+    from openpcseg_amd.workloads.losses import SegLoss, lovasz_softmax, lovasz_softmax_device
+    loss, grad = hip.lovasz_softmax(torch.zeros((0, 20), device=DEV), torch.zeros(0, dtype=torch.long, device=DEV), 0)
+    assert float(loss) == 0.0 and grad.shape == (0, 20)
+    p = torch.full((50, 20), 0.05, device=DEV)
+    loss, grad = hip.lovasz_softmax(p, torch.zeros(50, dtype=torch.long, device=DEV), 0)
+    assert float(loss) == 0.0 and float(grad.abs().max()) == 0.0
+    loss, grad = hip.lovasz_softmax(torch.rand(10, 1, device=DEV), torch.zeros(10, dtype=torch.long, device=DEV), 0)
+    assert float(loss) == 0.0 and float(grad.abs().max()) == 0.0   # the only class is the ignored one
+    with pytest.raises(RuntimeError, match="classes"):
+        hip.lovasz_softmax(torch.rand(10, 61, device=DEV), torch.zeros(10, dtype=torch.long, device=DEV), 0)
+    torch.manual_seed(3)
+    logits = torch.randn(20000, 20, device=DEV)
+    target = torch.randint(0, 20, (20000,), device=DEV)
+    outs = []
+    for fn in (lovasz_softmax_device, lovasz_softmax):
+        x = logits.clone().requires_grad_(True)
+        val = fn(x.softmax(1), target, ignore=0)
+        gx, = torch.autograd.grad(val * 3.0, x)
+        outs.append((float(val), gx))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-6 and float((outs[0][1] - outs[1][1]).abs().max()) <= 2e-7
+    crit = SegLoss(ignore_index=0, label_smoothing=0.1)
+    x = logits.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        val = crit(x, target)
+    val.backward()
+    assert torch.isfinite(val) and torch.isfinite(x.grad).all() and x.grad.dtype == torch.float32

@@ -146,3 +146,28 @@ def test_sparse_quantize_restatement_matches_reference(case):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "quantize_golden.npz"))
     vox, idx, inv = orc.sparse_quantize(g[case + "_in"], g[case + "_vs"] if g[case + "_vs"].ndim else (float(g[case + "_vs"]),) * 3)
     assert np.array_equal(vox, g[case + "_vox"]) and np.array_equal(idx, g[case + "_idx"]) and np.array_equal(inv, g[case + "_inv"])
+
+
+def _lovasz_golden():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden import lovasz_cases
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lovasz_golden.npz"))
+    return [(name, p, lab, ign, float(g[name + "_loss"]), g[name + "_grad"]) for name, p, lab, ign in lovasz_cases()]
+
+
+def test_lovasz_restatement_matches_reference():
+    """oracle.lovasz_softmax (float64, stable sort) against the reference's lovasz_softmax run on CPU
+    (tests/golden/lovasz_golden.npz, `make_golden.py lovasz`): ignore inside / outside the class range / none, absent
+    classes, saturated probabilities; and the workload's two torch forms against the same vectors."""
+    from openpcseg_amd.workloads.losses import lovasz_softmax, lovasz_softmax_per_class
+    from seeded import lovasz_grad_mismatch
+    for name, p, lab, ign, loss, grad in _lovasz_golden():
+        lo, go = orc.lovasz_softmax(p, lab, ign)
+        assert abs(lo - loss) <= 2e-6, (name, lo, loss)
+        assert lovasz_grad_mismatch(p, lab, ign, go, grad) <= 2e-7, name   # (CPU torch.sort orders ties its own way)
+        for fn in (lovasz_softmax, lovasz_softmax_per_class):
+            tp = torch.from_numpy(p).requires_grad_(True)
+            lt = fn(tp, torch.from_numpy(lab), ignore=ign)
+            gt, = torch.autograd.grad(lt, tp)
+            assert abs(float(lt.detach()) - loss) <= 2e-6 and lovasz_grad_mismatch(p, lab, ign, gt.numpy(), grad) <= 2e-7, (name, fn.__name__)
