@@ -334,13 +334,14 @@ def sparse_quantize(points, voxel_size=(1, 1, 1)):
 
 
 def lovasz_softmax(probas, labels, ignore=None):
-    """Lovasz-softmax, classes='present', per_image=False, with d loss / d probas, in float64 on the float32 inputs
+    """Lovasz-softmax, classes='present', per_image=False, with d loss / d probas: the errors in float32 as the reference
+    forms them (their ORDER is part of the function: 1 - p rounds in float32), everything after the sort in float64
     (R:tools/utils/common/lovasz_losses.py:158-204: flatten_probas drops the ignored points :207-228, then per present
     class errors = |fg - p_c|, descending sort, dot with lovasz_grad :23-35 of the sorted foreground; mean over the
     classes). The sort is STABLE (ties keep point order), which is what torch's radix sort gives the reference on the
     device. Labels outside [0, C) other than `ignore` are dropped like ignored ones (the reference would index-error
     or silently never match them). -> (loss float, grad (n, C) float64)."""
-    p = np.asarray(probas, dtype=np.float32).astype(np.float64)
+    p = np.asarray(probas, dtype=np.float32)
     lab = np.asarray(labels).astype(np.int64)
     n, nc = p.shape
     valid = (lab >= 0) & (lab < nc)
@@ -354,7 +355,7 @@ def lovasz_softmax(probas, labels, ignore=None):
         fg = (lv == c).astype(np.float64)
         if fg.sum() == 0:
             continue
-        err = np.abs(fg - pv[:, c])
+        err = np.abs(fg.astype(np.float32) - pv[:, c]).astype(np.float64)
         perm = np.argsort(-err, kind="stable")
         fgs = fg[perm]
         gts = fgs.sum()
@@ -366,7 +367,7 @@ def lovasz_softmax(probas, labels, ignore=None):
         losses.append(float(np.dot(err[perm], g)))
         d = np.zeros(len(rows))
         d[perm] = g
-        grad[rows, c] = d * np.sign(pv[:, c] - fg)   # d|fg - p| / dp = sign(p - fg), 0 at a zero error
+        grad[rows, c] = d * np.sign(pv[:, c].astype(np.float64) - fg)   # d|fg - p| / dp = sign(p - fg), 0 at a zero error
     if not losses:
         return 0.0, grad
     return float(np.mean(losses)), grad / len(losses)

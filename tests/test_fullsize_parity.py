@@ -49,7 +49,7 @@ BOUNDS = {
     "config2/workload": (3e-4, 1e-5, 1e-4, 6e-4, 1e-3, 1e-2),        # 1.4e-4   4.1e-5 / 2.8e-4   4.8e-4 / 4.7e-3
     "config3/reference": (4e-4, 1e-5, 3e-4, 7e-4, 5e-4, 3e-3),       # 1.7e-4   1.4e-4 / 3.5e-4   2.1e-4 / 1.4e-3
     "config4/reference": (1e-3, 1e-5, 3e-3, 3.6e-2, 1.8e-2, 5.5e-2),  # 8.8e-4   1.5e-3 / 1.8e-2   8.8e-3 / 2.7e-2 (see above)
-    "config2x2/reference": (3e-4, 1e-5, 6e-4, 2.5e-3, 6e-3, 1.1e-2),  # two-frame batch: config 2's bounds (measured: profiles/round4_fullsize_parity.json)
+    "config2x2/reference": (9e-4, 1e-5, 9e-4, 4e-3, 4e-3, 1.3e-2),    # 4.5e-4   4.5e-4 / 2.0e-3   1.9e-3 / 6.7e-3 (two-frame batch, logit scale 150; r4)
     "config5/reference": (8e-4, 2e-5, 2e-4, 6e-4, 5e-4, 4e-3),       # 4.1e-4   7.8e-5 / 2.9e-4   2.3e-4 / 1.8e-3
 }
 _MEASURED = {}
@@ -214,7 +214,9 @@ def test_fullsize_workload_autocast_vs_fp32_reference(dtype, hip):
 # instances of the cr 1.75 widths), BatchNorm / point ops / the range branch follow torch's autocast rules. Bounds per point
 # relative to the RMS of the reference logits, as AMP_BOUNDS above but for a graph with fp16-unfriendly pieces this package does
 # not own (point MLPs, the SalsaNext range branch): max / rms, mean / rms, worst live parameter-gradient abs-sum, arg-max agreement.
-REF_AMP_BOUNDS = {"config3": (0.60, 0.04, 0.25, 0.95), "config5": (0.60, 0.04, 0.25, 0.95)}
+# (max err / rms, mean err / rms, gradient abs-sum rel, arg-max agreement), each <= 2x the value measured on MI355X in round 4:
+#   config3  0.187 / 0.0092 / 0.072 / 0.988      config5  0.158 / 0.0076 / 0.101 / 0.991  (profiles/round4_fullsize_parity.json)
+REF_AMP_BOUNDS = {"config3": (0.38, 0.019, 0.15, 0.975), "config5": (0.32, 0.016, 0.20, 0.982)}
 
 
 @pytest.mark.gpu
