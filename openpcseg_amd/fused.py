@@ -297,6 +297,34 @@ class FusedLinear(nn.Linear):
             hd = torch.get_autocast_dtype("cuda")
         return _SkinnyLinear.apply(x, self.weight, self.bias, self._maps, hd)
 
+    def devoxelized_part(self, col, xf, idx, wts):
+        """One term of forward(cat([devoxelize(x_i) for i], 1)) = sum_i devoxelize(x_i @ W_i^T) + b, W_i = the column
+        block [col, col + C_i) of the weight: trilinear devoxelisation is linear over the voxel features (fixed
+        per-point weights), so it commutes with the classifier -- the class scores are formed on the VOXELS (36 k /
+        329 k / 1.16 M rows of 256 / 128 / 96 channels -> num_class) and only num_class channels per point are
+        interpolated, instead of interpolating 480 channels per point and contracting them there (2.7 GB of point
+        features written, read by the classifier, and the same again as gradients in backward). Same function; the fp32
+        rounding order differs. xf (V, C_i) voxel features, idx / wts (N, 8) the points' corner map. The bias is added
+        on the points (`sum_devoxelized`): the weights of a point with missing corners do not sum to one."""
+        from . import functional as F_
+        if len(self._maps) > 8:
+            self._maps.clear()
+        cin = xf.shape[1]
+        w = self.weight[:, col:col + cin]
+        ok = (xf.is_cuda and xf.dim() == 2 and xf.dtype in (torch.float32, torch.bfloat16, torch.float16) and
+              xf.shape[0] >= 4096 and cin % 4 == 0 and self.out_features % 4 == 0)
+        if ok:
+            v = _SkinnyLinear.apply(xf, w, None, self._maps, xf.dtype if xf.dtype != torch.float32 else None)
+        else:
+            v = torch.nn.functional.linear(xf.float(), w.float())
+        return F_.spdevoxelize(v.float(), idx, wts)
+
+    def sum_devoxelized(self, terms):
+        y = terms[0]
+        for t in terms[1:]:
+            y = y + t
+        return y + self.bias if self.bias is not None else y
+
     def forward_parts(self, parts):
         """forward(torch.cat(parts, 1)) without building the concatenation (column blocks of the weight)."""
         parts = list(parts)

@@ -16,7 +16,7 @@ from .. import modules as spnn
 from ..fused import FusedBatchNorm, FusedLinear
 from ..sparse import PointTensor, cat, fapply
 from .losses import SegLoss
-from .pointvoxel import initial_voxelize, voxel_to_point
+from .pointvoxel import initial_voxelize, point_maps, voxel_to_point
 
 MK34_LAYERS = [2, 3, 4, 6, 2, 2, 2, 2]
 MK18_LAYERS = [2, 2, 2, 2, 2, 2, 2, 2]
@@ -137,6 +137,11 @@ class MinkUNet(nn.Module):
         h = _bn_act(self.stem[1], self.stem[0](x), act=self.stem[2])
         return _bn_act(self.stem[4], self.stem[3](h), act=self.stem[5])
 
+    def _dropout(self, feats, out_of_place):
+        if out_of_place:
+            return torch.nn.functional.dropout(feats, self.dropout.p, self.training, False)
+        return self.dropout(feats)
+
     def point_logits(self, x):
         """x: SparseTensor (feats (N,>=in_dim), coords (N,4) int) -> per-point logits (N, num_class)."""
         if self.training and self._bn_layers:
@@ -145,20 +150,34 @@ class MinkUNet(nn.Module):
         z = PointTensor(x.F, x.C.float())
         x0 = self._stem(initial_voxelize(z, self.pres, self.vres))
         z0 = voxel_to_point(x0, z)
+        lin = self.classifier[0]
+        # classifier(cat(devoxelize(x4), devoxelize(y2), devoxelize(y4))) with the linear map applied on the voxels first
+        # (FusedLinear.devoxelized_part: interpolation and the classifier commute); PCS_CLASSIFIER_COMMUTE=0 = the literal
+        # order. The voxel features are taken where the reference devoxelises them: BEFORE the dropout that follows (which
+        # then runs out of place: the product keeps its input for the weight gradient).
+        commute = isinstance(lin, FusedLinear) and os.environ.get("PCS_CLASSIFIER_COMMUTE", "1") != "0"
         x1 = self.stage1(x0)
         x2 = self.stage2(x1)
         x3 = self.stage3(x2)
         x4 = self.stage4(x3)
-        z1 = voxel_to_point(x4, z0)
-        x4.F = self.dropout(x4.F)
+        if commute:
+            t1 = lin.devoxelized_part(0, x4.F, *point_maps(x4, z0))
+        else:
+            z1 = voxel_to_point(x4, z0)
+        x4.F = self._dropout(x4.F, commute)
         y1 = self.up1[1](self.up1[0](x4, cat_with=x3))  # torchsparse.cat([up(x4), x3]) fused into the BN apply pass
         y2 = self.up2[1](self.up2[0](y1, cat_with=x2))
-        z2 = voxel_to_point(y2, z1)
-        y2.F = self.dropout(y2.F)
+        if commute:
+            t2 = lin.devoxelized_part(x4.F.shape[1], y2.F, *point_maps(y2, z0))
+        else:
+            z2 = voxel_to_point(y2, z1)
+        y2.F = self._dropout(y2.F, commute)
         y3 = self.up3[1](self.up3[0](y2, cat_with=x1))
         y4 = self.up4[1](self.up4[0](y3, cat_with=x0))
+        if commute:
+            t3 = lin.devoxelized_part(x4.F.shape[1] + y2.F.shape[1], y4.F, *point_maps(y4, z0))
+            return lin.sum_devoxelized([t1, t2, t3])
         z3 = voxel_to_point(y4, z2)
-        lin = self.classifier[0]
         if isinstance(lin, FusedLinear) and os.environ.get("PCS_CLASSIFIER_PARTS", "1") != "0":
             return lin.forward_parts([z1.F, z2.F, z3.F])  # Linear over [z1 | z2 | z3] without the (N, 480) concat
         return self.classifier(torch.cat([z1.F, z2.F, z3.F], dim=1))

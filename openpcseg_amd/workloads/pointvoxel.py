@@ -52,8 +52,8 @@ def initial_voxelize(z, init_res, after_res):
     return x
 
 
-def voxel_to_point(x, z, nearest=False):
-    """Trilinear devoxelisation of x at the points of z; maps cached per stride (utils.py:69-105)."""
+def point_maps(x, z, nearest=False):
+    """(idx_query (N, 8), weights (N, 8)) of the points of z in the voxels of x; cached on z per stride (utils.py:69-105)."""
     s = x.s
     if z.idx_query.get(s) is None or z.weights.get(s) is None:
         be = native.backend()
@@ -71,6 +71,13 @@ def voxel_to_point(x, z, nearest=False):
             idx_query[:, 1:] = -1
         z.idx_query[s] = idx_query
         z.weights[s] = weights
+    return z.idx_query[s], z.weights[s]
+
+
+def voxel_to_point(x, z, nearest=False):
+    """Trilinear devoxelisation of x at the points of z; maps cached per stride (utils.py:69-105)."""
+    s = x.s
+    point_maps(x, z, nearest)
     out = PointTensor(F.spdevoxelize(x.F, z.idx_query[s], z.weights[s]), z.C,
                       idx_query=z.idx_query, weights=z.weights)
     out.additional_features = z.additional_features

@@ -927,3 +927,35 @@ def test_lovasz_softmax_edges_and_autograd(hip):
         val = crit(x, target)
     val.backward()
     assert torch.isfinite(val) and torch.isfinite(x.grad).all() and x.grad.dtype == torch.float32
+
+
+def test_classifier_on_the_voxels_equals_the_literal_order(hip, monkeypatch):
+    """workloads/minkunet.py forms the class scores on the voxels and devoxelises num_class channels
+    (`FusedLinear.devoxelized_part`) instead of devoxelising 480 channels and contracting on the points: the same
+    function (interpolation is linear). One training step with dropout ACTIVE (same generator state: the out-of-place
+    dropout draws the mask of the in-place one) against PCS_CLASSIFIER_COMMUTE=0: logits 2e-6 of their maximum, loss 1e-6
+    relative, every parameter gradient 2e-4 of its abs-sum (fp32 summation order through the whole backward pass)."""
+    from openpcseg_amd.sparse import SparseTensor
+    from openpcseg_amd.workloads.minkunet import MinkUNet
+    from openpcseg_amd.workloads.synthetic import make_batch
+    from seeded import seeded_state
+    b = make_batch([0, 1], n_points=30000)
+    coords = b["lidar"].C.to(DEV)
+    model = MinkUNet(num_class=20, cr=0.5)
+    seeded_state(model)
+    model.to(DEV).train()
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PCS_CLASSIFIER_COMMUTE", mode)
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(7)
+        out = model({"lidar": SparseTensor(b["lidar"].F.to(DEV), coords), "targets": SparseTensor(b["targets"].F.to(DEV), coords)})
+        out["loss"].backward()
+        res[mode] = (out["logits"].detach().float().clone(), float(out["loss"]),
+                     {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    (la, lossa, ga), (lb, lossb, gb) = res["0"], res["1"]
+    assert float((la - lb).abs().max()) <= 2e-6 * float(la.abs().max())
+    assert abs(lossa - lossb) <= 1e-6 * abs(lossa)
+    assert ga.keys() == gb.keys()
+    for n in ga:
+        assert float((ga[n] - gb[n]).abs().sum()) <= 2e-4 * float(ga[n].abs().sum()) + 1e-12, n
