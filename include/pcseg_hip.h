@@ -302,7 +302,10 @@ int pcs_denselize_bwd_f32(const float *gout, const int32_t *count_map, const int
  *             -> pcs_bn_apply_f32: y = act((x - mean) * invstd * w + b [+ res])
  *   backward: pcs_bn_bwd_stats_f32 (g = dy * [y > 0] when relu) -> [all-reduce sums2]
  *             -> pcs_bn_bwd_apply_f32: dx = (g - sum_g/N - xhat * sum_gxhat/N) * invstd * w, dres = g
- *             (dw = sums2[c:], db = sums2[:c]).
+ *             (dw = sums2[c:], db = sums2[:c]). ABI v7: `sums2` holds 2c doubles FOLLOWED BY the same 2c values as floats
+ *             (3c doubles of storage): the parameter gradients in the parameters' dtype without a conversion launch.
+ *   single process, statistics from the convolution's write-back: pcs_bn_reduce_partials_finalize = pcs_bn_reduce_partials +
+ *             pcs_bn_finalize_f32 (count = n) in one launch (ABI v7; `sums` may be NULL there).
  * partial_ws: pcs_bn_num_partials() * 2 * c floats.
  * mask (optional, c % 32 == 0): n * c/32 words written by the apply pass, bit = [y > 0]; handed to the two backward
  *   passes instead of y (then y may be NULL) -- the ReLU gate costs 1/32 of a tensor read instead of a whole one.
@@ -310,6 +313,8 @@ int pcs_denselize_bwd_f32(const float *gout, const int32_t *count_map, const int
 int32_t pcs_bn_num_partials(void);
 int pcs_bn_stats_f32(const float *x, int64_t n, int32_t c, float *partial_ws, double *sums, void *stream);
 int pcs_bn_reduce_partials(const double *partial, int64_t nrows, int32_t c, int64_t n, double *sums, void *stream);
+int pcs_bn_reduce_partials_finalize(const double *partial, int64_t nrows, int32_t c, int64_t n, double eps, double momentum,
+                                    float *running_mean, float *running_var, double *sums, double *stat, void *stream);
 int pcs_bn_finalize_f32(const double *sums, double count, const double *count_dev, int32_t c, double eps,
                         double momentum, float *running_mean, float *running_var, double *stat, void *stream);
 /* concat fusion (torchsparse.cat([bn_relu(up_conv(x)), skip]), TS:torchsparse/operators.py:10-17 as used by

@@ -141,10 +141,17 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const void *__restrict_
 // together. Forward (pivot != NULL): the partials are sums of (x - pivot) and (x - pivot)^2; the raw moments
 //   sum x = S0 + n p,   sum x^2 = S1 + 2 p S0 + n p^2
 // are formed here in double, and sums[2c] = n (the vector a data-parallel run all-reduces: SyncBN needs the global count).
+// Optional tails of the same launch (each channel's totals sit in one thread, so neither needs another kernel):
+//   f32copy (2c floats): the sums again in fp32 -- backward: the weight / bias gradients in the parameters' dtype;
+//   stat (2c doubles):   bn_finalize_kernel's mean / invstd + running statistics with count = n -- the forward of a
+//                        single-process run, where nothing has to be all-reduced between the reduction and the finalize.
 template <typename PT>
 __global__ void __launch_bounds__(1024) bn_reduce_kernel(const PT *__restrict__ partial, int nblk, int c,
                                                          const float *__restrict__ pivot, int64_t n,
-                                                         double *__restrict__ sums, int write_count) {
+                                                         double *__restrict__ sums, int write_count,
+                                                         float *__restrict__ f32copy = nullptr, double *__restrict__ stat = nullptr,
+                                                         double eps = 0.0, double momentum = 0.0, float *running_mean = nullptr,
+                                                         float *running_var = nullptr) {
   __shared__ double red[2][64][17];
   const int ch = blockIdx.x * 16 + threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
@@ -172,10 +179,29 @@ __global__ void __launch_bounds__(1024) bn_reduce_kernel(const PT *__restrict__ 
       t1 = t1 + 2.0 * p * t0 + dn * p * p;
       t0 = t0 + dn * p;
     }
-    sums[ch] = t0;
-    sums[c + ch] = t1;
+    if (sums) {
+      sums[ch] = t0;
+      sums[c + ch] = t1;
+    }
+    if (f32copy) {
+      f32copy[ch] = (float)t0;
+      f32copy[c + ch] = (float)t1;
+    }
+    if (stat) {  // bn_finalize_kernel below, count = n
+      const double count = n > 0 ? (double)n : 1.0;
+      const double mean = t0 / count;
+      double var = t1 / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      stat[ch] = mean;
+      stat[c + ch] = 1.0 / sqrt(var + eps);
+      if (running_mean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+        running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+      }
+    }
   }
-  if (write_count && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) sums[2 * c] = (double)n;
+  if (sums && write_count && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) sums[2 * c] = (double)n;
 }
 
 // stat[0..c) = mean, stat[c..2c) = invstd; running stats updated like nn.BatchNorm1d (unbiased var, momentum)
@@ -337,8 +363,10 @@ static int bn_partial(bool bwd, int dtype, const void *x, const void *dy, const 
     else PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_partial_kernel<false, 1, ET>), dim3(kStatBlocks), block, lds, st, x, dy, y, mask, stat, n, c, cv, relu, partial, lddy));
   }
     const float *pivot = bwd ? nullptr : partial + (size_t)kStatBlocks * 2 * c;  // written by workgroup 0 above
+  // backward: the sums once more in fp32 behind the 2c doubles (the parameter gradients, no conversion launch)
   hipLaunchKernelGGL(bn_reduce_kernel<float>, dim3((unsigned)ceil_div(c, 16)), dim3(16, 64), 0, st, partial, kStatBlocks, c,
-                     pivot, n, sums, bwd ? 0 : 1);
+                     pivot, n, sums, bwd ? 0 : 1, bwd ? reinterpret_cast<float *>(sums + 2 * (size_t)c) : (float *)nullptr,
+                     (double *)nullptr, 0.0, 0.0, (float *)nullptr, (float *)nullptr);
   return check_launch("pcs_bn_partial");
 }
 
@@ -402,8 +430,24 @@ extern "C" int pcs_bn_stats_h(const void *x, int64_t n, int32_t c, int32_t dtype
 extern "C" int pcs_bn_reduce_partials(const double *partial, int64_t nrows, int32_t c, int64_t n, double *sums, void *stream) {
   if (nrows < 0 || nrows > 0x7FFFFFFF || c <= 0 || n < 0 || !partial || !sums) { set_error("pcs_bn_reduce_partials: bad args"); return PCS_EINVAL; }
   hipLaunchKernelGGL(bn_reduce_kernel<double>, dim3((unsigned)ceil_div(c, 16)), dim3(16, 64), 0, as_stream(stream), partial,
-                     (int)nrows, c, (const float *)nullptr, n, sums, 1);
+                     (int)nrows, c, (const float *)nullptr, n, sums, 1, (float *)nullptr, (double *)nullptr, 0.0, 0.0,
+                     (float *)nullptr, (float *)nullptr);
   return check_launch("pcs_bn_reduce_partials");
+}
+
+// the same reduction with pcs_bn_finalize_f32 (count = n) in its tail: stat (2c) from the convolution's partials in ONE launch.
+// sums (2c + 1) may be NULL. Not for SyncBN (the sums of all ranks must be added between the two steps).
+extern "C" int pcs_bn_reduce_partials_finalize(const double *partial, int64_t nrows, int32_t c, int64_t n, double eps,
+                                               double momentum, float *running_mean, float *running_var, double *sums,
+                                               double *stat, void *stream) {
+  if (nrows < 0 || nrows > 0x7FFFFFFF || c <= 0 || n <= 0 || !partial || !stat || (!running_mean) != (!running_var)) {
+    set_error("pcs_bn_reduce_partials_finalize: bad args");
+    return PCS_EINVAL;
+  }
+  hipLaunchKernelGGL(bn_reduce_kernel<double>, dim3((unsigned)ceil_div(c, 16)), dim3(16, 64), 0, as_stream(stream), partial,
+                     (int)nrows, c, (const float *)nullptr, n, sums, 1, (float *)nullptr, stat, eps, momentum, running_mean,
+                     running_var);
+  return check_launch("pcs_bn_reduce_partials_finalize");
 }
 
 extern "C" int pcs_bn_finalize_f32(const double *sums, double count, const double *count_dev, int32_t c, double eps,

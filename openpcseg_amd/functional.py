@@ -232,8 +232,9 @@ class _SparseConv(Function):
 
     @staticmethod
     def forward(ctx, input, weight, entry, transposed, want_stats=False):
-        """want_stats: also return the BatchNorm statistics vector of the output ([sum x | sum x^2 | n], float64) when
-        the kernel produced it in its write-back, else an empty tensor (the BatchNorm then runs its own pass)."""
+        """want_stats: also return the BatchNorm statistics of the output when the kernel produced them in its write-back
+        -- on the HIP backend the per-tile partials ([tiles][2][cout] float64; `_FusedBN` reduces them), on others the
+        reduced vector [sum x | sum x^2 | n] --, else an empty tensor (the BatchNorm then runs its own pass)."""
         be = _be()
         hd = _amp_dtype(input)
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
@@ -241,6 +242,8 @@ class _SparseConv(Function):
         kmap = entry.rev if transposed else entry.fwd
         got = [] if want_stats else None
         kw = {"bn_sums": got} if want_stats else {}
+        if want_stats and getattr(be, "supports_bn_raw", False):
+            kw["bn_raw"] = True   # the per-tile partials themselves: the BatchNorm reduces and finalizes them in ONE launch
         if hd is not None and input.is_cuda and be.conv_h_applies(cin, cout, k):
             x = input.contiguous().to(hd)
             wp = be.prepare_weights_h(w3.detach().float().contiguous(), hd, transpose=False)

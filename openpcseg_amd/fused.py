@@ -82,17 +82,24 @@ class _FusedBN(Function):
         n, c = x.shape
         # [sum x | sum x^2 | n]: handed over by the producing convolution (its write-back computed them), else one pass
         syncing = _syncing(sync)
-        if pre is not None and pre.numel() == 2 * c + 1:
+        count, count_dev, stat = float(n), None, None
+        raw = pre is not None and pre.numel() != 2 * c + 1 and pre.numel() > 0 and pre.numel() % (2 * c) == 0
+        if raw and not syncing and n > 0:
+            # the producing convolution's per-tile partials: reduction and finalize in one launch (nothing to all-reduce)
+            stat = be.bn_reduce_finalize(pre, c, n, eps, momentum, running_mean, running_var)
+        elif raw:
+            sums = be.bn_reduce_partials(pre, c, n)
+        elif pre is not None and pre.numel() == 2 * c + 1:
             sums = pre.clone() if syncing else pre  # the all-reduce below works in place
         else:
             sums = be.bn_stats(x)
-        count, count_dev = float(n), None
         if syncing:
             # ONE collective per layer and direction: the row count rides in the statistics vector and the global
             # count stays on the device (finalize / bwd_apply read it there) -- no count all-reduce, no host sync
             dist.all_reduce(sums, group=_stats_group())
             count_dev = sums[2 * c:]
-        stat = be.bn_finalize(sums, count, eps, momentum, running_mean, running_var, count_dev=count_dev)
+        if stat is None:
+            stat = be.bn_finalize(sums, count, eps, momentum, running_mean, running_var, count_dev=count_dev)
         # c % 32 == 0: the backward passes read the ReLU gate as a bit mask (1/32 of a tensor) instead of y
         if relu and c % 32 == 0 and c % 4 == 0:
             y, gate = be.bn_apply(x, res, stat, weight, bias, relu, want_mask=True, tail=tail)
@@ -122,8 +129,10 @@ class _FusedBN(Function):
             dist.all_reduce(sums2, group=_stats_group())
         dx, dres = be.bn_bwd_apply(dy, x, gate, stat, sums2, count, weight, relu, has_res, count_dev=count_dev)
         dw = db = None
-        if weight is not None:  # local sums: DDP averages parameter grads; one cast for both halves
-            lw = local.to(weight.dtype)
+        if weight is not None:  # local sums: DDP averages parameter grads
+            lw = getattr(local, "_pcs_f32", None)   # the HIP reduction leaves them in fp32 as well
+            if lw is None or lw.dtype != weight.dtype:
+                lw = local.to(weight.dtype)         # one cast for both halves
             dw, db = lw[c:], lw[:c]
         return dx, dres, dw, db, None, None, None, None, None, None, None, None, None, dtail
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "pcs_conv_gather_gemm_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32,
                                            _P, c_int32, c_int64, _P, _P, _P, _P, _P]),
     "pcs_bn_reduce_partials": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P]),
+    "pcs_bn_reduce_partials_finalize": (c_int32, [_P, c_int64, c_int32, c_int64, c_double, c_double, _P, _P, _P, _P, _P]),
     "pcs_transpose_kab_f32": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_conv_wgrad_ws_bytes": (c_size_t, [_P, c_int32, c_int32, c_int32]),
     "pcs_conv_wgrad_f32": (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, c_int32, _P,
@@ -553,14 +554,34 @@ class HipBackend:
         ntiles = (kmap.n_dst + t - 1) // t
         return torch.empty(ntiles * 2 * cout, dtype=torch.float64, device=device)
 
-    def _bn_reduce(self, partial, t, kmap, cout, bn_sums):
-        ntiles = (kmap.n_dst + t - 1) // t
-        sums = torch.empty(2 * cout + 1, dtype=torch.float64, device=partial.device)
-        _check(self.lib.pcs_bn_reduce_partials(_ptr(partial), ntiles, cout, kmap.n_dst, _ptr(sums), _stream()),
-               "pcs_bn_reduce_partials")
-        bn_sums.append(sums)
+    supports_bn_raw = True   # the conv entries take bn_raw=True: hand on the per-tile partials, not the reduced vector
 
-    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True):
+    def _bn_reduce(self, partial, t, kmap, cout, bn_sums, raw=False):
+        if raw:   # the consumer reduces (and, single process, finalizes in the same launch: bn_reduce_finalize)
+            bn_sums.append(partial)
+            return
+        bn_sums.append(self.bn_reduce_partials(partial, cout, kmap.n_dst))
+
+    def bn_reduce_partials(self, partial, c, n):
+        """[ntiles][2][c] double partials of a conv write-back -> the (2c + 1) `sums` vector bn_stats would return."""
+        partial = _dev(partial, "partial", torch.float64)
+        sums = torch.empty(2 * c + 1, dtype=torch.float64, device=partial.device)
+        _check(self.lib.pcs_bn_reduce_partials(_ptr(partial), partial.numel() // (2 * c), c, n, _ptr(sums), _stream()),
+               "pcs_bn_reduce_partials")
+        return sums
+
+    def bn_reduce_finalize(self, partial, c, n, eps, momentum, running_mean, running_var):
+        """bn_reduce_partials + bn_finalize(count = n) in one launch -> stat (2c); single-process forward only."""
+        partial = _dev(partial, "partial", torch.float64)
+        stat = torch.empty(2 * c, dtype=torch.float64, device=partial.device)
+        _check(self.lib.pcs_bn_reduce_partials_finalize(_ptr(partial), partial.numel() // (2 * c), c, n, float(eps),
+                                                        float(momentum),
+                                                        _ptr(running_mean) if running_mean is not None else None,
+                                                        _ptr(running_var) if running_var is not None else None, None,
+                                                        _ptr(stat), _stream()), "pcs_bn_reduce_partials_finalize")
+        return stat
+
+    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True, bn_raw=False):
         """dst[d] = sum_{(s,d) in offset k} src[s] @ weight[k] (+bias); kmap dst-sorted. bn_sums: a list; when the
         kernel can, the [sum x | sum x^2 | n] vector of dst (what bn_stats(dst) returns) is appended to it, computed in
         the convolution's write-back instead of by a pass over dst. ordered: True = heaviest-first tile order where it
@@ -586,7 +607,7 @@ class HipBackend:
                                                  _ptr(order) if order is not None else None,
                                                  _stream()), "pcs_conv_gather_gemm_f32")
         if part is not None:
-            self._bn_reduce(part, t, kmap, cout, bn_sums)
+            self._bn_reduce(part, t, kmap, cout, bn_sums, bn_raw)
         return dst
 
     # -- half-precision convolution (bf16 / fp16 MFMA) ------------------------------------------------------
@@ -610,7 +631,7 @@ class HipBackend:
         wp._pcs_prepared = ("half", dtype, k, con, cols)  # what the opaque buffer holds: checked by the conv call
         return wp
 
-    def conv_gather_gemm_h(self, src, wp, k, cout, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True):
+    def conv_gather_gemm_h(self, src, wp, k, cout, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True, bn_raw=False):
         """Half-precision fused conv: src (n, cin) bf16 / fp16, wp = prepare_weights_h(...) of the same dtype."""
         if src.dtype not in self._HALF:
             raise TypeError("openpcseg_amd: conv_gather_gemm_h wants bfloat16 / float16 features, got %s" % src.dtype)
@@ -634,7 +655,7 @@ class HipBackend:
                                                _ptr(order) if order is not None else None,
                                                _stream()), "pcs_conv_gather_gemm_h")
         if part is not None:
-            self._bn_reduce(part, t, kmap, cout, bn_sums)
+            self._bn_reduce(part, t, kmap, cout, bn_sums, bn_raw)
         return dst
 
     # -- fp32 convolution on the 16-bit MFMAs (three bf16 planes per operand, opt-in) ------------------------------
@@ -656,7 +677,7 @@ class HipBackend:
         wp._pcs_prepared = ("x3", k, con, cols)
         return wp
 
-    def conv_gather_gemm_x3(self, src, wp, k, cout, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True):
+    def conv_gather_gemm_x3(self, src, wp, k, cout, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True, bn_raw=False):
         """fp32 fused conv on the bf16 MFMAs: src (n, cin) fp32, wp = prepare_weights_x3(...); fp32 out (fp32-grade)."""
         src = _dev(src, "input", torch.float32)
         cin = src.shape[1]
@@ -680,7 +701,7 @@ class HipBackend:
                                                         _ptr(order) if order is not None else None, _stream()),
                "pcs_conv_gather_gemm_f32_bf16x3")
         if part is not None:
-            self._bn_reduce(part, t, kmap, cout, bn_sums)
+            self._bn_reduce(part, t, kmap, cout, bn_sums, bn_raw)
         return dst
 
     def conv_wgrad_h(self, fa, fb, kmap, a_col):
@@ -899,7 +920,9 @@ class HipBackend:
         n, c = x.shape
         dy, lddy = self._rows(dy, "grad_output", x, c)
         ws = torch.empty(self.lib.pcs_bn_num_partials() * 2 * c, dtype=torch.float32, device=x.device)
-        sums2 = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        buf = torch.empty(3 * c, dtype=torch.float64, device=x.device)   # 2c doubles, then the same 2c values as floats
+        sums2 = buf[:2 * c]
+        sums2._pcs_f32 = buf[2 * c:].view(torch.float32)   # [sum g | sum g xhat] in fp32: db | dw without a conversion launch
         yp, mp = self._gate(gate, relu)
         if x.dtype == torch.float32:
             _check(self.lib.pcs_bn_bwd_stats_f32(_ptr(dy), _ptr(x), yp, mp, _ptr(stat), n, c, int(relu),

@@ -959,3 +959,30 @@ def test_classifier_on_the_voxels_equals_the_literal_order(hip, monkeypatch):
     assert ga.keys() == gb.keys()
     for n in ga:
         assert float((ga[n] - gb[n]).abs().sum()) <= 2e-4 * float(ga[n].abs().sum()) + 1e-12, n
+
+
+def test_bn_reduce_finalize_in_one_launch_and_fp32_sums(hip):
+    """`pcs_bn_reduce_partials_finalize` (statistics of a conv write-back -> mean / invstd + running stats, one launch) is
+    bit-identical to pcs_bn_reduce_partials + pcs_bn_finalize_f32; the backward reduction leaves [sum g | sum g xhat] in
+    fp32 behind the doubles (the parameter gradients without a conversion launch)."""
+    rng = np.random.default_rng(5)
+    c = random_scene(rng, 60000, 60, 2)
+    from openpcseg_amd import functional as F
+    from openpcseg_amd.sparse import SparseTensor
+    x = SparseTensor(t(rng.normal(size=(c.shape[0], 64)).astype(np.float32) * 3 + 1.5), t(c))
+    w = t(rng.normal(size=(27, 64, 96)).astype(np.float32) / 20)
+    out = F.conv3d(x, w, 3, bn_stats=True)
+    pre = out.bn_sums[0]
+    n, ch = out.F.shape
+    assert pre.dtype == torch.float64 and pre.numel() % (2 * ch) == 0 and pre.numel() > 2 * ch + 1   # the raw per-tile partials
+    rm_a, rv_a = torch.zeros(ch, device=DEV), torch.ones(ch, device=DEV)
+    rm_b, rv_b = rm_a.clone(), rv_a.clone()
+    stat_a = hip.bn_reduce_finalize(pre, ch, n, 1e-5, 0.1, rm_a, rv_a)
+    stat_b = hip.bn_finalize(hip.bn_reduce_partials(pre, ch, n), float(n), 1e-5, 0.1, rm_b, rv_b)
+    assert torch.equal(stat_a, stat_b) and torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
+    ref = hip.bn_finalize(hip.bn_stats(out.F), float(n), 1e-5, 0.1, None, None)
+    assert float((stat_a - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+    y, gate = hip.bn_apply(out.F, None, stat_a, None, None, True, want_mask=True)
+    dy = t(rng.normal(size=(n, ch)).astype(np.float32))
+    s2 = hip.bn_bwd_stats(dy, out.F, gate, stat_a, True)
+    assert s2.shape == (2 * ch,) and s2._pcs_f32.dtype == torch.float32 and torch.equal(s2._pcs_f32, s2.float())

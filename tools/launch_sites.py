@@ -48,7 +48,13 @@ def main():
         if ev.name not in WATCH:
             continue
         frames = [f for f in (ev.stack or []) if root in f or "openpcseg_amd" in f or "bench.py" in f]
-        site = " <- ".join(f.replace(root + "/", "") for f in frames[:3]) or "(no repo frame: %s)" % "; ".join((ev.stack or [])[:2])
+        site = " <- ".join(f.replace(root + "/", "") for f in frames[:3])
+        if not site:   # no python stacks on this build: the chain of enclosing CPU ops (autograd Function names included)
+            chain, par = [], getattr(ev, "cpu_parent", None)
+            while par is not None and len(chain) < 6:
+                chain.append(par.name[:48])
+                par = getattr(par, "cpu_parent", None)
+            site = " <- ".join(chain) or "(top level)"
         agg[(ev.name, site)] += 1
     print("events per step by name (top 40):")
     for n, c in names.most_common(40):

@@ -5,6 +5,7 @@ R=$GRAFT_REPO_ROOT
 TAG=$1; shift
 rm -rf /tmp/prof_$TAG && PCS_BENCH_PREHEAT=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --models none "$@" > $R/gpurun_out/${TAG}_prof.log 2>&1
 f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1); cp "$f" $R/gpurun_out/${TAG}_kernel_stats.csv
+t=$(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1); python $R/tools/kernel_shapes.py "$t" bn_ devoxelize lovasz > $R/gpurun_out/${TAG}_small_kernels.txt 2>&1
 cd $R && timeout 400 python bench.py --models none "$@" > gpurun_out/${TAG}_bench.log 2> gpurun_out/${TAG}_bench.err; tail -1 gpurun_out/${TAG}_bench.log | cut -c1-400
 python - <<PY
 import csv
