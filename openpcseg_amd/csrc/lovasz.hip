@@ -83,13 +83,23 @@ __device__ __forceinline__ bool label_valid(int64_t l, int nc, int has_ignore, i
 
 __global__ __launch_bounds__(256) void lovasz_count_kernel(const int64_t *__restrict__ labels, int64_t n, int nc, int has_ignore,
                                                           int64_t ignore, Header *hdr) {
+  // lane c of every wave counts class c (nc <= 60 < 64) from the ballots of the wave's 64 labels: no same-address atomics
   __shared__ int32_t h[64];
   if (threadIdx.x < 64) h[threadIdx.x] = 0;
   __syncthreads();
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int64_t l = labels[i];
-    if (label_valid(l, nc, has_ignore, ignore)) atomicAdd(&h[l], 1);
+  const int lane = threadIdx.x & 63;
+  int cnt = 0;
+  const int64_t span = (int64_t)gridDim.x * 256;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += span) {   // (uniform trip count over the wave)
+    const int64_t i = i0 + threadIdx.x;
+    const int64_t l = i < n ? labels[i] : -1;
+    const int cls = label_valid(l, nc, has_ignore, ignore) ? (int)l : -1;
+    for (int c = 0; c < nc; ++c) {
+      const unsigned long long m = __ballot(cls == c);
+      if (lane == c) cnt += __popcll(m);
+    }
   }
+  if (cnt) atomicAdd(&h[lane], cnt);
   __syncthreads();
   if (threadIdx.x < nc && h[threadIdx.x]) atomicAdd(&hdr->cnt[threadIdx.x], h[threadIdx.x]);
 }
@@ -219,27 +229,29 @@ __global__ __launch_bounds__(256) void lovasz_final_kernel(const uint64_t *__res
   if (t == 0) blockloss[(int64_t)s * nblk + b] = (dl[0] + dl[1]) + (dl[2] + dl[3]);
 }
 
-__global__ __launch_bounds__(256) void lovasz_reduce_kernel(const Header *__restrict__ hdr, const double *__restrict__ blockloss,
-                                                           int64_t nblk, int nc, int ncp, int skip, float *__restrict__ loss) {
-  __shared__ double part[256];
-  double total = 0.0;
-  int npresent = 0;
-  for (int s = 0; s < ncp; ++s) {
+// one wave per class slot (16 waves): lane-strided sums of the slot's block partials, combined in a fixed shuffle order
+__global__ __launch_bounds__(1024) void lovasz_reduce_kernel(const Header *__restrict__ hdr, const double *__restrict__ blockloss,
+                                                            int64_t nblk, int nc, int ncp, int skip, float *__restrict__ loss) {
+  __shared__ double per_class[64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int s = wave; s < ncp; s += 16) {
     const int c = s + (skip >= 0 && s >= skip ? 1 : 0);
-    if (hdr->cnt[c] <= 0) continue;   // (uniform over the workgroup)
-    ++npresent;
     double a = 0.0;
-    for (int64_t j = threadIdx.x; j < nblk; j += 256) a += blockloss[(int64_t)s * nblk + j];
-    part[threadIdx.x] = a;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
-      __syncthreads();
-    }
-    total += part[0];
-    __syncthreads();
+    if (hdr->cnt[c] > 0)
+      for (int64_t j = lane; j < nblk; j += 64) a += blockloss[(int64_t)s * nblk + j];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
+    if (lane == 0) per_class[s] = a;
   }
-  if (threadIdx.x == 0) loss[0] = npresent > 0 ? (float)(total / (double)npresent) : 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double total = 0.0;
+    int npresent = 0;
+    for (int s = 0; s < ncp; ++s) {
+      const int c = s + (skip >= 0 && s >= skip ? 1 : 0);
+      if (hdr->cnt[c] > 0) { total += per_class[s]; ++npresent; }
+    }
+    loss[0] = npresent > 0 ? (float)(total / (double)npresent) : 0.f;
+  }
 }
 
 }  // namespace
@@ -296,7 +308,7 @@ int pcs_lovasz_softmax_f32(const float *probas, const int64_t *labels, int64_t n
   const dim3 grid((unsigned)p.nblk, (unsigned)p.ncp);
   lovasz_blocksum_kernel<<<grid, 256, 0, st>>>(vals.current(), n, p.nblk, blocksum);
   lovasz_final_kernel<<<grid, 256, 0, st>>>(keys.current(), vals.current(), hdr, blocksum, n, p.nblk, p.nc, p.skip, grad, blockloss);
-  lovasz_reduce_kernel<<<1, 256, 0, st>>>(hdr, blockloss, p.nblk, p.nc, p.ncp, p.skip, loss);
+  lovasz_reduce_kernel<<<1, 1024, 0, st>>>(hdr, blockloss, p.nblk, p.nc, p.ncp, p.skip, loss);
   return check_launch("pcs_lovasz_softmax_f32");
 }
 

@@ -135,16 +135,17 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const void *__restrict_
 }
 
 // sums[ch] / sums[c + ch] = sum over the nblk partial rows of partial[b][0][ch] / partial[b][1][ch], accumulated in
-// double in a FIXED order (thread ty sums rows ty, ty+64, ...; then ty = 0..63 in order): deterministic. 16 channels x
-// 64 row lanes per workgroup: the kernel is pure latency (a few MB once per BatchNorm pass, 378 launches per training
-// step), so the rows are spread over as many lanes as a workgroup holds and each lane keeps its loads in flight
-// together. Forward (pivot != NULL): the partials are sums of (x - pivot) and (x - pivot)^2; the raw moments
+// double in a FIXED order (lane ty sums rows ty, ty+256, ...; groups of 16 lanes in order; the 16 group sums in order):
+// deterministic. The kernel is pure latency (a few MB once per BatchNorm pass, ~250 launches per training step), so the
+// rows are spread over as many lanes as a workgroup holds and each lane keeps its loads in flight together. Forward (pivot != NULL): the partials are sums of (x - pivot) and (x - pivot)^2; the raw moments
 //   sum x = S0 + n p,   sum x^2 = S1 + 2 p S0 + n p^2
 // are formed here in double, and sums[2c] = n (the vector a data-parallel run all-reduces: SyncBN needs the global count).
 // Optional tails of the same launch (each channel's totals sit in one thread, so neither needs another kernel):
 //   f32copy (2c floats): the sums again in fp32 -- backward: the weight / bias gradients in the parameters' dtype;
 //   stat (2c doubles):   bn_finalize_kernel's mean / invstd + running statistics with count = n -- the forward of a
 //                        single-process run, where nothing has to be all-reduced between the reduction and the finalize.
+constexpr int kRedCh = 4;       // channels per workgroup of bn_reduce_kernel
+constexpr int kRedLanes = 256;  // row lanes per workgroup
 template <typename PT>
 __global__ void __launch_bounds__(1024) bn_reduce_kernel(const PT *__restrict__ partial, int nblk, int c,
                                                          const float *__restrict__ pivot, int64_t n,
@@ -152,15 +153,19 @@ __global__ void __launch_bounds__(1024) bn_reduce_kernel(const PT *__restrict__ 
                                                          float *__restrict__ f32copy = nullptr, double *__restrict__ stat = nullptr,
                                                          double eps = 0.0, double momentum = 0.0, float *running_mean = nullptr,
                                                          float *running_var = nullptr) {
-  __shared__ double red[2][64][17];
-  const int ch = blockIdx.x * 16 + threadIdx.x;
+  // 4 channels x 256 row lanes per workgroup (round 4; was 16 x 64): c / 4 workgroups instead of c / 16 -- a 96-channel
+  // layer's 3 000 conv-tile partial rows went through 6 CUs (32 us), the 1 024 rows of the BatchNorm passes took 15 us
+  // whatever c: the kernel is latency, so it is spread over more CUs and every lane issues all its loads at once.
+  __shared__ double red[2][kRedLanes][kRedCh + 1];
+  __shared__ double red2[2][16][kRedCh + 1];
+  const int ch = blockIdx.x * kRedCh + threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
   if (ch < c) {
     PT v0[8], v1[8];
-    for (int b0 = threadIdx.y; b0 < nblk; b0 += 64 * 8) {
+    for (int b0 = threadIdx.y; b0 < nblk; b0 += kRedLanes * 8) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int b = b0 + 64 * u;
+        const int b = b0 + kRedLanes * u;
         v0[u] = b < nblk ? partial[(int64_t)b * 2 * c + ch] : (PT)0;
         v1[u] = b < nblk ? partial[(int64_t)b * 2 * c + c + ch] : (PT)0;
       }
@@ -171,9 +176,16 @@ __global__ void __launch_bounds__(1024) bn_reduce_kernel(const PT *__restrict__ 
   red[0][threadIdx.y][threadIdx.x] = s0;
   red[1][threadIdx.y][threadIdx.x] = s1;
   __syncthreads();
+  if (threadIdx.y < 16) {   // fixed order: 16 groups of 16 lanes, then the 16 group sums
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < 16; ++r) { a += red[0][threadIdx.y * 16 + r][threadIdx.x]; b += red[1][threadIdx.y * 16 + r][threadIdx.x]; }
+    red2[0][threadIdx.y][threadIdx.x] = a;
+    red2[1][threadIdx.y][threadIdx.x] = b;
+  }
+  __syncthreads();
   if (threadIdx.y == 0 && ch < c) {
     double t0 = 0.0, t1 = 0.0;
-    for (int r = 0; r < 64; ++r) { t0 += red[0][r][threadIdx.x]; t1 += red[1][r][threadIdx.x]; }
+    for (int r = 0; r < 16; ++r) { t0 += red2[0][r][threadIdx.x]; t1 += red2[1][r][threadIdx.x]; }
     if (pivot) {
       const double p = n > 0 ? (double)pivot[ch] : 0.0, dn = (double)n;
       t1 = t1 + 2.0 * p * t0 + dn * p * p;
@@ -323,7 +335,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const void *__restric
 struct Geo { dim3 block, grid; int cv; };
 template <int V> Geo geo(int64_t n, int c) {
   Geo g; g.cv = c / V;
-  int tx = 1; while (tx < g.cv && tx < 64) tx <<= 1;
+  // one x-lane per channel vector up to 64 (NOT rounded to a power of two: 96 channels = 24 vectors would idle 8 of 32
+  // lanes on the two widest levels); rows of a workgroup are contiguous in memory either way. The ReLU-mask shuffles of
+  // bn_apply_kernel work on aligned groups of 8 lanes: c % 32 == 0 there, so cv % 8 == 0 and the groups stay aligned.
+  const int tx = g.cv < 64 ? (g.cv > 0 ? g.cv : 1) : 64;
   g.block = dim3(tx, 256 / tx);
   int64_t gr = ceil_div(n > 0 ? n : 1, (256 / tx) * 4);
   if (gr > 2048) gr = 2048;
@@ -352,7 +367,7 @@ static int bn_partial(bool bwd, int dtype, const void *x, const void *dy, const 
   const bool vec = (c & 3) == 0 && (lddy & 3) == 0 && al_v4(dtype, x) && al_v4(dtype, dy) && al_v4(dtype, y);
   if (mask && (!vec || (c & 31))) { set_error("pcs_bn: the ReLU bit mask needs c % 32 == 0 and aligned rows"); return PCS_EUNSUPPORTED; }
   const int V = vec ? 4 : 1, cv = c / V;
-  int tx = 1; while (tx < cv && tx < 64) tx <<= 1;
+  const int tx = cv < 64 ? cv : 64;   // as geo(): one x-lane per channel vector, no power-of-two rounding
   dim3 block(tx, 256 / tx);
   const size_t lds = (size_t)(256 / tx) * 2 * tx * V * sizeof(float);
   if (vec) {
@@ -364,7 +379,7 @@ static int bn_partial(bool bwd, int dtype, const void *x, const void *dy, const 
   }
     const float *pivot = bwd ? nullptr : partial + (size_t)kStatBlocks * 2 * c;  // written by workgroup 0 above
   // backward: the sums once more in fp32 behind the 2c doubles (the parameter gradients, no conversion launch)
-  hipLaunchKernelGGL(bn_reduce_kernel<float>, dim3((unsigned)ceil_div(c, 16)), dim3(16, 64), 0, st, partial, kStatBlocks, c,
+  hipLaunchKernelGGL(bn_reduce_kernel<float>, dim3((unsigned)ceil_div(c, kRedCh)), dim3(kRedCh, kRedLanes), 0, st, partial, kStatBlocks, c,
                      pivot, n, sums, bwd ? 0 : 1, bwd ? reinterpret_cast<float *>(sums + 2 * (size_t)c) : (float *)nullptr,
                      (double *)nullptr, 0.0, 0.0, (float *)nullptr, (float *)nullptr);
   return check_launch("pcs_bn_partial");
@@ -429,7 +444,7 @@ extern "C" int pcs_bn_stats_h(const void *x, int64_t n, int32_t c, int32_t dtype
 // (pcs_conv_gather_gemm_*'s bn_partial: [nrows][2][c] raw sums) -- replaces the pcs_bn_stats_* pass over the tensor
 extern "C" int pcs_bn_reduce_partials(const double *partial, int64_t nrows, int32_t c, int64_t n, double *sums, void *stream) {
   if (nrows < 0 || nrows > 0x7FFFFFFF || c <= 0 || n < 0 || !partial || !sums) { set_error("pcs_bn_reduce_partials: bad args"); return PCS_EINVAL; }
-  hipLaunchKernelGGL(bn_reduce_kernel<double>, dim3((unsigned)ceil_div(c, 16)), dim3(16, 64), 0, as_stream(stream), partial,
+  hipLaunchKernelGGL(bn_reduce_kernel<double>, dim3((unsigned)ceil_div(c, kRedCh)), dim3(kRedCh, kRedLanes), 0, as_stream(stream), partial,
                      (int)nrows, c, (const float *)nullptr, n, sums, 1, (float *)nullptr, (double *)nullptr, 0.0, 0.0,
                      (float *)nullptr, (float *)nullptr);
   return check_launch("pcs_bn_reduce_partials");
@@ -444,7 +459,7 @@ extern "C" int pcs_bn_reduce_partials_finalize(const double *partial, int64_t nr
     set_error("pcs_bn_reduce_partials_finalize: bad args");
     return PCS_EINVAL;
   }
-  hipLaunchKernelGGL(bn_reduce_kernel<double>, dim3((unsigned)ceil_div(c, 16)), dim3(16, 64), 0, as_stream(stream), partial,
+  hipLaunchKernelGGL(bn_reduce_kernel<double>, dim3((unsigned)ceil_div(c, kRedCh)), dim3(kRedCh, kRedLanes), 0, as_stream(stream), partial,
                      (int)nrows, c, (const float *)nullptr, n, sums, 1, (float *)nullptr, stat, eps, momentum, running_mean,
                      running_var);
   return check_launch("pcs_bn_reduce_partials_finalize");
