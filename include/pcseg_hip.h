@@ -462,6 +462,26 @@ int pcs_voxel_label_vote(const int64_t *inverse, const int64_t *labels, int64_t 
 int pcs_rows_argmax_gather_f32(const float *logits, int64_t m, int32_t c, const int64_t *inverse, int64_t n,
                                int64_t *out, void *stream);
 
+/* ---- all layers' weight preparation in one launch (ABI v7) ---------------------------------------------------------
+ * pcs_transpose_kab_f32 (kind 0: dst (K, B, A) fp32 = per-offset transposed weights for dgrad) and
+ * pcs_conv_prepare_weights_h (kind 1 bf16 / 2 fp16: dst = prepared half weights of pcs_conv_prepared_weights_bytes bytes,
+ * `transpose` as there) for a whole list of layers: the weights change once per optimizer step, so a training step
+ * needs one launch instead of one per layer call (csrc/weights_multi.hip). Element-wise identical to the per-layer calls.
+ *   pcs_weights_multi_plan : fills nctt / nt16 / ns / first_block of the HOST job table, returns the launch's work-block
+ *                            count (-1 + pcs_last_error on a bad job);
+ *   pcs_weights_multi      : jobs_dev = the planned table copied to the device. */
+typedef struct {
+  const float *src; /* (K, A, B) fp32 master weights */
+  void *dst;
+  int32_t K, A, B;
+  int32_t kind;      /* 0 transpose, 1 prepare bf16, 2 prepare fp16 */
+  int32_t transpose; /* kinds 1 / 2: 0 = forward (contract over A), 1 = dgrad (contract over B) */
+  int32_t nctt, nt16, ns; /* filled by the plan call */
+  int64_t first_block;    /* filled by the plan call */
+} pcs_weight_job;
+int64_t pcs_weights_multi_plan(pcs_weight_job *jobs_host, int32_t n_jobs);
+int pcs_weights_multi(const pcs_weight_job *jobs_dev, int32_t n_jobs, int64_t total_blocks, void *stream);
+
 /* ---- Lovasz-softmax of the training criterion (the timed step's loss tail) -----------------
  * lovasz_softmax(probas, labels, classes='present', per_image=False, ignore) of
  * R:tools/utils/common/lovasz_losses.py:158-204 (+ lovasz_grad :23-35, flatten_probas :207-228) as the reference's

@@ -296,6 +296,40 @@ __global__ void __launch_bounds__(256) devoxelize_bwd_csr_kernel(const float *__
   }
 }
 
+// The same reduction for NARROW rows (c <= 32, 16-byte granular: the class scores the workload devoxelises since round 4):
+// one WAVE per voxel, 8 x-lanes over the row's float4 pieces times 8 entry lanes striding over the voxel's segment, combined
+// by shuffles in a fixed order (deterministic). A coarse voxel's ~250 entries are 32 trips of 8 independent row loads instead
+// of 125 trips of two in one thread row, and a stride-1 voxel's 8 entries are one trip.
+__global__ void __launch_bounds__(256) devoxelize_bwd_csr_narrow_kernel(const float *__restrict__ gout,
+                                                                        const int64_t *__restrict__ order,
+                                                                        const int64_t *__restrict__ rowptr,
+                                                                        const float *__restrict__ w8, int64_t m, int c, int cv,
+                                                                        float *__restrict__ gfeat) {
+  const int x = threadIdx.x & 7, el = (threadIdx.x >> 3) & 7, wv = threadIdx.x >> 6;
+  for (int64_t v = (int64_t)blockIdx.x * 4 + wv; v < m; v += (int64_t)gridDim.x * 4) {   // (uniform over the wave)
+    const int64_t e0 = rowptr[v], e1 = rowptr[v + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t e = e0 + el; e < e1; e += 16) {   // two independent row loads in flight per lane
+      const int64_t p0 = order[e];
+      const bool two = e + 8 < e1;
+      const int64_t p1 = two ? order[e + 8] : p0;
+      const float w0 = w8[p0], w1 = w8[p1];
+      if (x < cv) {
+        const float4 g0 = reinterpret_cast<const float4 *>(gout + (p0 >> 3) * c)[x];
+        const float4 g1 = reinterpret_cast<const float4 *>(gout + (p1 >> 3) * c)[x];
+        acc = vfma(w0, g0, acc);
+        if (two) acc = vfma(w1, g1, acc);   // (not a zero weight: 0 x Inf of a diverged gradient must not turn into NaN here)
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 8; o >>= 1) {
+      acc.x += __shfl_down(acc.x, o, 64); acc.y += __shfl_down(acc.y, o, 64);
+      acc.z += __shfl_down(acc.z, o, 64); acc.w += __shfl_down(acc.w, o, 64);
+    }
+    if (el == 0 && x < cv) reinterpret_cast<float4 *>(gfeat + v * c)[x] = acc;
+  }
+}
+
 }  // namespace
 
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -422,7 +456,11 @@ extern "C" int pcs_devoxelize_bwd_csr_f32(const float *gout, const int64_t *orde
   if (m == 0) return PCS_OK;
   if (!gout || !order || !rowptr || !w8 || !gfeat) { set_error("pcs_devoxelize_bwd_csr: null pointer"); return PCS_EINVAL; }
   hipStream_t st = as_stream(stream);
-  if ((c & 3) == 0 && aligned16(gout) && aligned16(gfeat)) {
+  if ((c & 3) == 0 && c <= 32 && aligned16(gout) && aligned16(gfeat)) {
+    int64_t g = ceil_div(m, 4);
+    if (g > 256 * 64) g = 256 * 64;
+    hipLaunchKernelGGL(devoxelize_bwd_csr_narrow_kernel, dim3((unsigned)g), dim3(256), 0, st, gout, order, rowptr, w8, m, c, c / 4, gfeat);
+  } else if ((c & 3) == 0 && aligned16(gout) && aligned16(gfeat)) {
     RowLaunch rl = row_launch<4>(m, c);
     hipLaunchKernelGGL(devoxelize_bwd_csr_kernel<4>, rl.grid, rl.block, 0, st, gout, order, rowptr, w8, m, c, rl.cv, gfeat);
   } else {

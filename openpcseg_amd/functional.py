@@ -221,6 +221,55 @@ def _amp_dtype(t):
     return None
 
 
+class _WeightPrep:
+    """Prepared copies of the convolution weights (dgrad's per-offset transposes in fp32, the fragment-ordered half weights of
+    forward and dgrad under autocast), refreshed for ALL layers by one launch the first time a step finds one stale
+    (`native.weights_multi`). The reference transposes / casts inside every layer call
+    (TS:torchsparse/backend/convolution/convolution_cuda.cu:196-206, TS:torchsparse/nn/functional/conv.py:19); weights only
+    change at the optimizer step, which bumps the parameter's in-place version counter -- the staleness test. Only leaf fp32
+    (K, A, B) device parameters are cached; anything else (padded copies, 2-D weights, other backends) takes the per-call path.
+    PCS_WEIGHT_PREP=0 switches the cache off (A/B)."""
+
+    def __init__(self):
+        self.entries = {}   # id(weight) -> [weakref, version the copies were made at, {key: tensor}, set of valid keys]
+
+    @staticmethod
+    def usable(be, weight):
+        return (hasattr(be, "weights_multi") and isinstance(weight, torch.nn.Parameter) and weight.is_cuda and weight.dim() == 3 and
+                weight.dtype == torch.float32 and weight.is_contiguous() and os.environ.get("PCS_WEIGHT_PREP", "1") != "0")
+
+    def get(self, be, weight, key):
+        """key: ("t",) or (half dtype, transpose)."""
+        import weakref
+        e = self.entries.get(id(weight))
+        if e is None or e[0]() is not weight:
+            if len(self.entries) > 4096:
+                self.entries = {i: v for i, v in self.entries.items() if v[0]() is not None}
+            e = [weakref.ref(weight), -1, {}, set()]
+            self.entries[id(weight)] = e
+        if e[1] == weight._version and key in e[3]:
+            return e[2][key]
+        if key not in e[2]:
+            e[2][key] = be.prepared_weights_buffer(weight, *((("t", False)) if key == ("t",) else key))
+        jobs, marks = [], []
+        for v in self.entries.values():
+            w = v[0]()
+            if w is None or w.device != weight.device:
+                continue
+            stale = v[1] != w._version
+            for k_, dst in v[2].items():
+                if stale or k_ not in v[3]:
+                    jobs.append((w.detach(), dst, "t" if k_ == ("t",) else k_[0], False if k_ == ("t",) else k_[1]))
+            marks.append((v, w._version))
+        be.weights_multi(jobs)
+        for v, ver in marks:
+            v[1], v[3] = ver, set(v[2].keys())
+        return e[2][key]
+
+
+_WEIGHT_PREP = _WeightPrep()
+
+
 class _SparseConv(Function):
     """out = conv(input) over a kernel map; backward = dgrad (same fused kernel on the other
     map, per-offset transposed weights) + wgrad (split reduction).
@@ -246,7 +295,10 @@ class _SparseConv(Function):
             kw["bn_raw"] = True   # the per-tile partials themselves: the BatchNorm reduces and finalizes them in ONE launch
         if hd is not None and input.is_cuda and be.conv_h_applies(cin, cout, k):
             x = input.contiguous().to(hd)
-            wp = be.prepare_weights_h(w3.detach().float().contiguous(), hd, transpose=False)
+            if _WeightPrep.usable(be, weight):
+                wp = _WEIGHT_PREP.get(be, weight, (hd, False))
+            else:
+                wp = be.prepare_weights_h(w3.detach().float().contiguous(), hd, transpose=False)
             out = be.conv_gather_gemm_h(x, wp, k, cout, kmap, **kw)
         elif hd is None and input.is_cuda and _CONV_POLICY["mode"] == "bf16x3" and be.conv_x3_applies(cin, cout, k):
             x = input.contiguous().float()
@@ -282,13 +334,19 @@ class _SparseConv(Function):
         if need_dx:
             dmap = entry.fwd if transposed else entry.rev
             if hd is not None and be.conv_h_applies(cout, cin, k):
-                wp = be.prepare_weights_h(w3.detach().float().contiguous(), hd, transpose=True)
+                if _WeightPrep.usable(be, weight):
+                    wp = _WEIGHT_PREP.get(be, weight, (hd, True))
+                else:
+                    wp = be.prepare_weights_h(w3.detach().float().contiguous(), hd, transpose=True)
                 grad_input = be.conv_gather_gemm_h(grad_output.contiguous().to(hd), wp, k, cin, dmap)
             elif hd is None and grad_output.is_cuda and _CONV_POLICY["mode"] == "bf16x3" and be.conv_x3_applies(cout, cin, k):
                 wp = be.prepare_weights_x3(w3.detach().float().contiguous(), transpose=True)
                 grad_input = be.conv_gather_gemm_x3(grad_output.contiguous().float(), wp, k, cin, dmap)
             else:
-                wt = be.transpose_weights(w3.detach().float().contiguous())
+                if _WeightPrep.usable(be, weight):
+                    wt = _WEIGHT_PREP.get(be, weight, ("t",))
+                else:
+                    wt = be.transpose_weights(w3.detach().float().contiguous())
                 grad_input = be.conv_gather_gemm(grad_output.contiguous().float(), wt, dmap)
             # the gradient leaves in the dtype the forward input arrived in (what autograd expects)
             grad_input = grad_input.to(x.dtype if hd is None else hd)

@@ -99,9 +99,16 @@ SIGNATURES = {
     "pcs_cylinder_partition_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "pcs_voxel_label_vote": (c_int32, [_P, _P, c_int64, c_int64, c_int32, c_int64, _P, _P, _P, _P]),
     "pcs_rows_argmax_gather_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
+    "pcs_weights_multi_plan": (c_int64, [_P, c_int32]),
+    "pcs_weights_multi": (c_int32, [_P, c_int32, c_int64, _P]),
     "pcs_lovasz_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32, c_int64]),
     "pcs_lovasz_softmax_f32": (c_int32, [_P, _P, c_int64, c_int32, c_int32, c_int64, _P, _P, _P, c_int64, _P]),
 }
+
+class _WeightJob(ctypes.Structure):   # pcs_weight_job of include/pcseg_hip.h
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("K", c_int32), ("A", c_int32), ("B", c_int32), ("kind", c_int32),
+                ("transpose", c_int32), ("nctt", c_int32), ("nt16", c_int32), ("ns", c_int32), ("first_block", c_int64)]
+
 
 ABI_VERSION = 7  # include/pcseg_hip.h PCS_ABI_VERSION (7: pcs_lovasz_*; 6: ring kernel switch / query; 5: fp32 convolution on the bf16 MFMAs, pcs_conv_*_x3; 4: tile order)
 _lib = None
@@ -725,6 +732,48 @@ class HipBackend:
         out = torch.empty((k, b, a), dtype=torch.float32, device=w.device)
         _check(self.lib.pcs_transpose_kab_f32(_ptr(w), k, a, b, _ptr(out), _stream()), "pcs_transpose_kab_f32")
         return out
+
+    def prepared_weights_buffer(self, weight, kind, transpose):
+        """An empty destination for one weights_multi job: kind "t" -> (K, B, A) fp32, a half dtype -> the fragment-ordered
+        buffer of prepare_weights_h (tagged like its result)."""
+        k, a, b = weight.shape
+        if kind == "t":
+            return torch.empty((k, b, a), dtype=torch.float32, device=weight.device)
+        con, cols = (b, a) if transpose else (a, b)
+        nbytes = self.lib.pcs_conv_prepared_weights_bytes(k, con, cols)
+        if nbytes == 0:
+            raise RuntimeError("openpcseg_amd: shape (%d, %d, %d) is not served by the half-precision kernels" % (k, a, b))
+        wp = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+        wp._pcs_prepared = ("half", kind, k, con, cols)
+        return wp
+
+    def weights_multi(self, jobs):
+        """jobs: [(weight (K, A, B) fp32, dst, kind, transpose)], kind "t" = transpose_weights into dst, torch.bfloat16 /
+        torch.float16 = prepare_weights_h(weight, kind, transpose) into dst -- all of them in ONE launch
+        (csrc/weights_multi.hip). The device copy of the job table is kept while the pointers stay the same."""
+        if not jobs:
+            return
+        arr = (_WeightJob * len(jobs))()
+        sig = []
+        for j, (w, dst, kind, tr) in zip(arr, jobs):
+            w = _dev(w, "weight", torch.float32)
+            if not w.is_contiguous() or w.dim() != 3:
+                raise ValueError("openpcseg_amd: weights_multi wants contiguous (K, A, B) weights")
+            j.src, j.dst = w.data_ptr(), dst.data_ptr()
+            j.K, j.A, j.B = w.shape
+            j.kind = 0 if kind == "t" else self._HALF[kind]
+            j.transpose = int(bool(tr))
+            sig.append((j.src, j.dst, j.K, j.A, j.B, j.kind, j.transpose))
+        sig = (tuple(sig), str(jobs[0][0].device))
+        hit = getattr(self, "_wm_table", None)
+        if hit is None or hit[0] != sig:
+            blocks = self.lib.pcs_weights_multi_plan(ctypes.byref(arr), len(jobs))
+            if blocks < 0:
+                _check(-1, "pcs_weights_multi_plan")
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).pin_memory()
+            hit = (sig, host.to(jobs[0][0].device, non_blocking=True), int(blocks), host)
+            self._wm_table = hit
+        _check(self.lib.pcs_weights_multi(_ptr(hit[1]), len(jobs), hit[2], _stream()), "pcs_weights_multi")
 
     def conv_wgrad(self, fa, fb, kmap, a_col, split=False):
         """gW[k] = sum_{pairs of k} fa[pair[a_col]]^T (x) fb[pair[1-a_col]] -> (K, ca, cb). split=True: the operands go

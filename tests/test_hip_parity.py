@@ -96,10 +96,12 @@ def test_voxelize_golden(hip, golden):
     close(out, golden["vox_out"], 1e-6)
 
 
-@pytest.mark.parametrize("c", [5, 32, 96, 256])
-def test_devoxelize(hip, c):
-    rng = np.random.default_rng(c)
-    n, m = 30000, 4000
+@pytest.mark.parametrize("c,m", [(5, 4000), (32, 4000), (96, 4000), (256, 4000), (20, 4000), (20, 37), (8, 100000)])
+def test_devoxelize(hip, c, m):
+    """c <= 32 (16-byte granular) takes the wave-per-voxel backward kernel: m = 37 -> ~6 500 entries per voxel, m = 100 000 ->
+    mostly empty and one-entry voxels."""
+    rng = np.random.default_rng(c + m)
+    n = 30000
     idx8 = rng.integers(-1, m, size=(n, 8)).astype(np.int32)
     w8 = rng.uniform(0, 1, size=(n, 8)).astype(np.float32)
     feat = rng.normal(size=(m, c)).astype(np.float32)
@@ -986,3 +988,53 @@ def test_bn_reduce_finalize_in_one_launch_and_fp32_sums(hip):
     dy = t(rng.normal(size=(n, ch)).astype(np.float32))
     s2 = hip.bn_bwd_stats(dy, out.F, gate, stat_a, True)
     assert s2.shape == (2 * ch,) and s2._pcs_f32.dtype == torch.float32 and torch.equal(s2._pcs_f32, s2.float())
+
+
+def test_weights_multi(hip, monkeypatch):
+    """csrc/weights_multi.hip: the transposes and half re-packs of a list of layers in one launch are element-wise the
+    per-layer entry points' results; `functional._WeightPrep` refreshes every registered copy when a weight's version
+    changes and a training step gives bit-identical loss and gradients with the cache on and off (fp32 and bf16)."""
+    rng = np.random.default_rng(9)
+    shapes = [(27, 96, 96), (8, 128, 96), (27, 56, 112), (1, 256, 128), (27, 32, 64), (5, 40, 72)]
+    ws = [t(rng.normal(size=s).astype(np.float32)) for s in shapes]
+    jobs, want = [], []
+    for w in ws:
+        jobs.append((w, hip.prepared_weights_buffer(w, "t", False), "t", False))
+        want.append(hip.transpose_weights(w))
+        for dt, tr in ((torch.bfloat16, False), (torch.float16, True)):
+            k, a, b = w.shape
+            if hip.conv_h_applies(*((b, a) if tr else (a, b)), k):
+                jobs.append((w, hip.prepared_weights_buffer(w, dt, tr), dt, tr))
+                want.append(hip.prepare_weights_h(w, dt, transpose=tr))
+    hip.weights_multi(jobs)
+    hip.weights_multi(jobs)   # second call: the cached device job table
+    assert len(jobs) > len(ws)
+    for (w, dst, kind, tr), ref in zip(jobs, want):
+        assert dst.shape == ref.shape and torch.equal(dst, ref), (tuple(w.shape), kind, tr)
+    from openpcseg_amd.sparse import SparseTensor
+    from openpcseg_amd.workloads.minkunet import MinkUNet
+    from openpcseg_amd.workloads.synthetic import make_batch
+    from seeded import seeded_state
+    b = make_batch([0], n_points=20000)
+    coords = b["lidar"].C.to(DEV)
+    for amp in (None, torch.bfloat16):
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("PCS_WEIGHT_PREP", mode)
+            model = MinkUNet(num_class=20, cr=0.5)
+            seeded_state(model)
+            model.to(DEV).train()
+            opt = torch.optim.SGD(model.parameters(), lr=0.05)
+            losses = []
+            for it in range(3):   # the optimizer steps in between make every cached copy stale
+                opt.zero_grad(set_to_none=True)
+                torch.manual_seed(it)
+                with torch.autocast("cuda", dtype=amp or torch.bfloat16, enabled=amp is not None):
+                    out = model({"lidar": SparseTensor(b["lidar"].F.to(DEV), coords), "targets": SparseTensor(b["targets"].F.to(DEV), coords)})
+                out["loss"].backward()
+                losses.append(float(out["loss"]))
+                if it < 2:
+                    opt.step()
+            res[mode] = (losses, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+        assert res["0"][0] == res["1"][0], (amp, res["0"][0], res["1"][0])
+        assert all(torch.equal(res["0"][1][n], res["1"][1][n]) for n in res["0"][1]), amp
