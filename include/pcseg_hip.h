@@ -493,7 +493,7 @@ int pcs_weights_multi(const pcs_weight_job *jobs_dev, int32_t n_jobs, int64_t to
  *   float32 = d loss / d probas, every element written (may be NULL: value only).
  *   Ties between equal errors keep point order (what torch's stable descending sort gives the reference).
  *   ws: pcs_lovasz_workspace_bytes(n, num_class, has_ignore, ignore) bytes (-1 + pcs_last_error on bad sizes;
- *   20 B per point and class + the sort's temporaries). num_class <= 60, n * num_class < 2^32 - 1. */
+ *   28 B per point and class + the sort's temporaries). num_class <= 60, n * num_class < 2^32 - 1. */
 int64_t pcs_lovasz_workspace_bytes(int64_t n, int32_t num_class, int32_t has_ignore, int64_t ignore);
 int pcs_lovasz_softmax_f32(const float *probas, const int64_t *labels, int64_t n, int32_t num_class, int32_t has_ignore,
                            int64_t ignore, float *loss, float *grad, void *ws, int64_t ws_bytes, void *stream);
