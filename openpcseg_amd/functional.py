@@ -243,8 +243,8 @@ class _WeightPrep:
         import weakref
         e = self.entries.get(id(weight))
         if e is None or e[0]() is not weight:
-            if len(self.entries) > 4096:
-                self.entries = {i: v for i, v in self.entries.items() if v[0]() is not None}
+            # a new parameter: drop the copies of parameters that no longer exist (models come and go in one process)
+            self.entries = {i: v for i, v in self.entries.items() if v[0]() is not None}
             e = [weakref.ref(weight), -1, {}, set()]
             self.entries[id(weight)] = e
         if e[1] == weight._version and key in e[3]:
@@ -404,11 +404,19 @@ class _PointwiseConv(Function):
         if ctx.needs_input_grad[1]:
             km = _identity_map(feats.shape[0], feats.device, ctx.cache)
             ca, cb = feats.shape[1], grad_output.shape[1]
-            if hd is not None and ca % 4 == 0 and cb % 4 == 0:
-                gw = _be().conv_wgrad_h(feats.contiguous().to(hd), grad_output.to(hd), km, 0)[0]
+            fa, gb = feats.contiguous(), grad_output
+            pa, pb = (-ca) % 4, (-cb) % 4
+            if (pa or pb) and feats.is_cuda and ca + pa >= 32:
+                # widths that are not 16-byte granular (cr 1.6: 153, 409, 613 ...): zero columns bring the operands onto the MFMA
+                # weight-gradient kernels (the generic kernel ran these 1x1x1 layers at 16-19 TFLOP/s); the padding's rows /
+                # columns of the result are cut off again
+                fa = torch.nn.functional.pad(fa, (0, pa)) if pa else fa
+                gb = torch.nn.functional.pad(gb, (0, pb)) if pb else gb
+            if hd is not None and fa.shape[1] % 4 == 0 and gb.shape[1] % 4 == 0:
+                gw = _be().conv_wgrad_h(fa.to(hd), gb.to(hd), km, 0)[0]
             else:
-                gw = _be().conv_wgrad(feats.contiguous().float(), grad_output.float(), km, 0)[0]
-            gw = gw.to(weight.dtype)
+                gw = _be().conv_wgrad(fa.float(), gb.float(), km, 0)[0]
+            gw = gw[:ca, :cb].to(weight.dtype)
         return gin, gw, None
 
 

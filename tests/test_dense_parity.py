@@ -631,3 +631,39 @@ def test_conv3d_odd_widths_run_padded_on_the_mfma_kernels(hip, levels, stride, c
         close_half(y.F, ref, amp)
         close_half(xs.F.grad.to(amp), ogx, amp)
         close(wt.grad, ogw, 2e-5)
+
+
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_pointwise_conv_odd_widths(hip, amp):
+    """1x1x1 convolutions of the cr 1.6 widths (204 -> 153 ...): the weight gradient x^T dy runs zero-padded on the MFMA
+    weight-gradient kernels; forward / input gradient are dense GEMMs. Against float64 matrix products."""
+    from openpcseg_amd import functional as F
+    from openpcseg_amd.sparse import SparseTensor
+    rng = np.random.default_rng(3)
+    n, cin, cout = 50000, 204, 153
+    c = np.unique(np.concatenate([rng.integers(0, 80, size=(n, 3)), np.zeros((n, 1), np.int64)], 1).astype(np.int32), axis=0)
+    n = c.shape[0]
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    w = (rng.normal(size=(cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    gy = rng.normal(size=(n, cout)).astype(np.float32)
+    seen = []
+    orig, orig_h = hip.conv_wgrad, hip.conv_wgrad_h
+    hip.conv_wgrad = lambda fa, fb, *a, **k: (seen.append((fa.shape[1], fb.shape[1])), orig(fa, fb, *a, **k))[1]
+    hip.conv_wgrad_h = lambda fa, fb, *a, **k: (seen.append((fa.shape[1], fb.shape[1])), orig_h(fa, fb, *a, **k))[1]
+    from openpcseg_amd import native
+    prev = native._BACKEND
+    native._BACKEND = hip
+    try:
+        xs = SparseTensor(t(x).requires_grad_(True), t(c))
+        wt = t(w).requires_grad_(True)
+        with torch.autocast("cuda", dtype=amp or torch.bfloat16, enabled=amp is not None):
+            y = F.conv3d(xs, wt, 1)
+        y.F.backward(t(gy).to(y.F.dtype))
+    finally:
+        hip.conv_wgrad, hip.conv_wgrad_h, native._BACKEND = orig, orig_h, prev
+    assert seen == [(204, 156)], seen
+    tol = 2e-5 if amp is None else 2e-2
+    x64, w64, g64 = x.astype(np.float64), w.astype(np.float64), gy.astype(np.float64)
+    for got, ref in ((y.F, x64 @ w64), (xs.F.grad, g64 @ w64.T), (wt.grad, x64.T @ g64)):
+        ref_t = torch.from_numpy(ref)
+        assert float((got.double().cpu() - ref_t).abs().max()) <= tol * float(ref_t.abs().max())
