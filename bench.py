@@ -679,7 +679,7 @@ def main():
             "config": {"workload": "MinkUNet-34 cr1.0 train step, %d x 120k-pt synthetic SemanticKITTI-shape scans per GPU, 0.05 m voxels, %s"
                                    % (args.frames_per_gpu, "fp32" if amp is None else "autocast " + amp),
                        "global_batch": args.frames_per_gpu * world, "voxels_per_gpu_batch": n_vox, "parallelism": "dp%d" % world,
-                       "wgrad": "fp32" if amp is not None else args.wgrad, "notes": "profiles/bench_notes.json"},
+                       "wgrad": "fp32" if amp is not None else args.wgrad, "loss": head["loss"], "notes": "profiles/bench_notes.json"},
             "roofline": pick(head["roofline"]),
         }
         if head["comm"] is not None:
