@@ -162,17 +162,22 @@ __device__ __forceinline__ float jaccard(int gts, int64_t pos, int cs) {   // lo
 
 __global__ __launch_bounds__(256) void lovasz_final_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                           const Header *__restrict__ hdr, const int32_t *__restrict__ blocksum,
-                                                          int64_t n, int64_t nblk, int nc, int skip, float *__restrict__ gradt,
-                                                          double *__restrict__ blockloss) {
+                                                          int64_t n, int64_t nblk, int nc, int ncp, int skip,
+                                                          float *__restrict__ gradt, double *__restrict__ blockloss) {
   // gradt (may be NULL): the gradient class-slot-major, gradt[s n + point] -- the sorted stream scatters it by point, and a
   // slot's n floats (4.6 MB at 1.16 M points) stay cache-resident while its workgroups run, where the (point, class) layout
   // spread the same writes over the whole 93 MB tensor (0.47 ms); lovasz_grad_rows_kernel turns it into rows afterwards.
   __shared__ int lds[4];
   __shared__ int wave_tot[4];
   __shared__ double dl[4];
-  const int s = blockIdx.y;
+  // workgroup -> (class slot, block): every workgroup of a slot on ONE XCD (the dispatcher deals linear workgroup ids round-robin
+  // over the 8 XCDs), slot s on XCD s % 8 -- the slot's scattered gradient stores then fill whole lines in one L2 instead of
+  // leaving byte-masked pieces of every line in eight of them
+  const int64_t lin = blockIdx.x, q = lin >> 3;
+  const int s = (int)(lin & 7) + 8 * (int)(q / nblk);
+  if (s >= ncp) return;
   const int c = s + (skip >= 0 && s >= skip ? 1 : 0);
-  const int64_t b = blockIdx.x;
+  const int64_t b = q % nblk;
   const int t = threadIdx.x;
   const int gts = hdr->cnt[c];
   const int npresent = block_sum_256(t < nc && hdr->cnt[t] > 0 ? 1 : 0, lds);
@@ -331,7 +336,10 @@ int pcs_lovasz_softmax_f32(const float *probas, const int64_t *labels, int64_t n
   const dim3 grid((unsigned)p.nblk, (unsigned)p.ncp);
   lovasz_blocksum_kernel<<<grid, 256, 0, st>>>(vals.current(), n, p.nblk, blocksum);
   float *gradt = grad != nullptr ? reinterpret_cast<float *>(base + p.off_gradt) : nullptr;
-  lovasz_final_kernel<<<grid, 256, 0, st>>>(keys.current(), vals.current(), hdr, blocksum, n, p.nblk, p.nc, p.skip, gradt, blockloss);
+  const int64_t final_grid = 8 * p.nblk * ceil_div(p.ncp, 8);
+  if (final_grid > 0x7FFFFFFF) { set_error("pcs_lovasz_softmax_f32: too many work blocks"); return PCS_EINVAL; }
+  lovasz_final_kernel<<<(unsigned)final_grid, 256, 0, st>>>(keys.current(), vals.current(), hdr, blocksum, n, p.nblk, p.nc, p.ncp,
+                                                            p.skip, gradt, blockloss);
   if (grad != nullptr)
     lovasz_grad_rows_kernel<<<(unsigned)ceil_div(n, kRows), 256, sizeof(float) * kRows * stride, st>>>(gradt, n, p.nc, p.ncp, p.skip, grad);
   lovasz_reduce_kernel<<<1, 1024, 0, st>>>(hdr, blockloss, p.nblk, p.nc, p.ncp, p.skip, loss);

@@ -171,7 +171,7 @@ def test_bench_one_rank_over_rccl():
     def run(env_extra, launcher, extra=()):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", PCS_BENCH_PREHEAT="0", **env_extra)  # same number of optimizer steps
         cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--frames-per-gpu", "2",
-                          "--no-cpu-baseline"] + list(extra)
+                          "--no-cpu-baseline", "--models", "none"] + list(extra)
         out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
         assert out.returncode == 0, out.stderr[-3000:]
         lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
