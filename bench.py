@@ -385,9 +385,13 @@ def cpu_baseline(compact=True):
     ref.setdefault("cores", CPU_BASELINE_THREADS)
     ref.setdefault("kind", "reference")
     pt = _run_worker("--cpu-pytorch-worker", 300)
-    if compact:
+    if compact:   # the driver keeps the last 2 000 characters of the line: short sample texts (the long ones: --verbose-json)
         ref.pop("sample_long", None)
+        if ref.get("value") is not None:
+            ref["sample"] = "n=1 full frame fwd+bwd, reference CPU backend (oracle/_ref), no extrapolation"
         pt = {k: pt.get(k) for k in ("value", "seconds_per_frame", "sample") if k in pt}
+        if pt.get("value") is not None:
+            pt["sample"] = "config 1: reference SPVCNN, one 2000-pt scan, pure-PyTorch CPU path"
     ref["pytorch"] = pt
     return ref
 
@@ -676,7 +680,7 @@ def main():
             "value": head["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": amp or "f32", "data": "synthetic",
-            "config": {"workload": "MinkUNet-34 cr1.0 train step, %d x 120k-pt synthetic SemanticKITTI-shape scans per GPU, 0.05 m voxels, %s"
+            "config": {"workload": "MinkUNet-34 cr1.0 train step, %d x 120k-pt synthetic SemanticKITTI scans/GPU, %s"
                                    % (args.frames_per_gpu, "fp32" if amp is None else "autocast " + amp),
                        "global_batch": args.frames_per_gpu * world, "voxels_per_gpu_batch": n_vox, "parallelism": "dp%d" % world,
                        "wgrad": "fp32" if amp is not None else args.wgrad, "loss": head["loss"], "notes": "profiles/bench_notes.json"},
@@ -696,6 +700,9 @@ def main():
             if args.verbose_json:
                 res["fp32_bf16x3"]["roofline"] = third["roofline"]
         if models is not None:
+            if not args.verbose_json and "error" not in models:
+                # [fp32, bf16] frames/s of one training step per model (ms per step and batch sizes: --verbose-json, bench_notes.json)
+                models = dict({"fmt": "[fp32,bf16] frames/s"}, **{k: [v.get("f32"), v.get("bf16")] for k, v in models.items()})
             res["models"] = models
         if world == 1 and not args.no_cpu_baseline and amp is None:
             res["cpu_baseline"] = cpu_baseline(compact=not args.verbose_json)
