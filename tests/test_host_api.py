@@ -311,3 +311,82 @@ def test_arithmetic_policies_are_opt_in():
     assert lib.pcs_conv_x3_applies(4, 32, 27) == 0 and lib.pcs_conv_x3_applies(96, 16, 27) == 0 and lib.pcs_conv_x3_applies(100, 64, 27) == 0
     assert lib.pcs_conv_x3_column_tiles(96) == 6 and lib.pcs_conv_x3_column_tiles(256) == 4 and lib.pcs_conv_x3_column_tiles(32) == 2
     assert lib.pcs_conv_prepared_weights_x3_bytes(27, 96, 96) == 3 * 27 * 6 * 3 * 1024
+
+
+def test_weights_multi_plan_is_a_host_function():
+    """pcs_weights_multi_plan fills the launch geometry of a job table without a device: work-block prefix sums for transposes
+    (one 32 x 32 tile per block) and half re-packs (256 fragment words per block), and refuses shapes the half kernels do not serve."""
+    import ctypes
+    from openpcseg_amd import native
+    lib = native.load_library()
+    arr = (native._WeightJob * 3)()
+    for j, (k, a, b, kind, tr) in zip(arr, ((27, 96, 96, 0, 0), (8, 128, 96, 1, 1), (27, 56, 112, 2, 0))):
+        j.src, j.dst, j.K, j.A, j.B, j.kind, j.transpose = 4096, 8192, k, a, b, kind, tr
+    blocks = lib.pcs_weights_multi_plan(ctypes.byref(arr), 3)
+    t0 = 27 * 3 * 3
+    assert arr[0].first_block == 0 and arr[1].first_block == t0
+    # job 1: dgrad of 128 -> 96: contraction over B = 96 (3 steps), columns A = 128
+    assert arr[1].ns == 3 and arr[1].nt16 * 16 >= 128 and arr[1].nctt in (2, 4, 6, 8)
+    w1 = (8 * arr[1].nt16 * arr[1].ns * 64 + 255) // 256
+    assert arr[2].first_block == t0 + w1 and arr[2].ns == 2   # 56 channels: two 32-channel steps, the second zero-padded
+    assert blocks == arr[2].first_block + (27 * arr[2].nt16 * arr[2].ns * 64 + 255) // 256
+    arr[1].A = 30   # contraction / columns the half kernels do not serve
+    assert lib.pcs_weights_multi_plan(ctypes.byref(arr), 3) == -1 and b"job 1" in lib.pcs_last_error()
+
+
+def test_weight_prep_cache_refreshes_all_layers_once(monkeypatch):
+    """functional._WeightPrep: the first stale copy met in a step refreshes every registered layer's copies in ONE backend call;
+    unchanged weights cost no call; a dead parameter's copies are dropped."""
+    import torch
+    from openpcseg_amd import functional as F
+
+    class FakeBackend:
+        def __init__(self):
+            self.calls = []
+
+        def prepared_weights_buffer(self, weight, kind, transpose):
+            return torch.zeros(1)
+
+        def weights_multi(self, jobs):
+            self.calls.append([(w.data_ptr(), kind, bool(tr)) for w, dst, kind, tr in jobs])
+
+    monkeypatch.setattr(F._WeightPrep, "usable", staticmethod(lambda be, w: True))
+    prep, be = F._WeightPrep(), FakeBackend()
+    ws = [torch.nn.Parameter(torch.randn(27, 8, 8)) for _ in range(3)]
+    for w in ws:                      # first step: every layer is new -> one call each (nothing else is stale yet)
+        prep.get(be, w, ("t",))
+    assert [len(c) for c in be.calls] == [1, 1, 1]
+    be.calls.clear()
+    for w in ws:                      # weights unchanged: cache hits only
+        prep.get(be, w, ("t",))
+    assert be.calls == []
+    with torch.no_grad():
+        for w in ws:
+            w.add_(1.0)               # the optimizer step
+    prep.get(be, ws[2], ("t",))       # the first layer backward meets ...
+    assert len(be.calls) == 1 and len(be.calls[0]) == 3   # ... refreshes all three
+    prep.get(be, ws[0], ("t",))
+    prep.get(be, ws[1], (torch.bfloat16, True))           # a new kind for one layer: only that copy
+    assert len(be.calls) == 2 and be.calls[1] == [(ws[1].data_ptr(), torch.bfloat16, True)]
+    del ws[0]
+    import gc
+    gc.collect()
+    fresh = torch.nn.Parameter(torch.randn(8, 4, 4))
+    prep.get(be, fresh, ("t",))       # registering a new parameter drops the dead one's copies
+    assert sum(1 for v in prep.entries.values() if v[0]() is not None) == len(prep.entries) == 3
+
+
+def test_step_budget_tools(tmp_path):
+    """tools/stats_diff.py + tools/step_budget.py: the difference of two kernel-statistics files grouped by owner."""
+    import subprocess
+    import sys as _sys
+    a, b, d = tmp_path / "a.csv", tmp_path / "b.csv", tmp_path / "d.csv"
+    head = '"Name","Calls","TotalDurationNs","AverageNs"\n'
+    a.write_text(head + '"void (anonymous namespace)::conv_os5_kernel<4>(pcs::ConvArgs)",30,30000000,1000000\n"__amd_rocclr_copyBuffer",600,2400000,4000\n')
+    b.write_text(head + '"void (anonymous namespace)::conv_os5_kernel<4>(pcs::ConvArgs)",70,70000000,1000000\n"__amd_rocclr_copyBuffer",680,2720000,4000\n'
+                        '"void (anonymous namespace)::bn_apply_kernel<4, F32>(void const*)",252,12600000,50000\n')
+    tools = os.path.join(ROOT, "tools")
+    subprocess.run([_sys.executable, os.path.join(tools, "stats_diff.py"), str(a), str(b), str(d)], check=True)
+    out = subprocess.run([_sys.executable, os.path.join(tools, "step_budget.py"), str(d), "4", "t"], check=True, capture_output=True, text=True).stdout
+    assert "| conv fwd / dgrad (fused gather-GEMM-scatter) | 10 | 10.00 |" in out
+    assert "| copies / fills (runtime) | 20 | 0.08 |" in out and "| BatchNorm" in out and "| **total** | **93** |" in out
