@@ -7,7 +7,7 @@ import torch
 
 from openpcseg_amd import cpu_fallback, native
 from openpcseg_amd import functional as F
-from openpcseg_amd.sparse import SparseTensor, get_kernel_offsets
+from openpcseg_amd.sparse import SparseTensor
 
 
 @pytest.fixture()

@@ -510,7 +510,6 @@ def test_commit_variants_bit_identical(hip, levels):
     """PCS_COMMIT_NOWAIT=0 / PCS_COMMIT_PHASED=0 (the fenced ticket hand-over and the compiler-interleaved commit kept behind
     macros in conv_wave5.hip, conv_wave5h.hip and conv_wave5x.hip) produce the same bits as the default build: a variant
     library is built here (hipcc is on the GPU box too) and both libraries run the same launches in subprocesses."""
-    import hashlib
     import os
     import subprocess
     import sys
