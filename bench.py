@@ -660,7 +660,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         try:
             import modelbench
-            models = modelbench.run(args.models, dev, steps=min(args.steps, 3), warmup=min(args.warmup, 2))
+            models = modelbench.run(args.models, dev, steps=min(args.steps, 10), warmup=min(args.warmup, 2))
         except Exception as e:  # e.g. the reference sources are not staged on this box: the record says so
             models = {"error": (type(e).__name__ + ": " + str(e))[:160]}
     if rank == 0:

@@ -34,7 +34,7 @@ extern "C" {
 #define PCS_ELAUNCH (-3)  /* hipLaunch / hipMemsetAsync failed (pcs_last_error has text) */
 #define PCS_EUNSUPPORTED (-4)
 
-#define PCS_ABI_VERSION 7
+#define PCS_ABI_VERSION 8
 
 int pcs_abi_version(void);
 const char *pcs_last_error(void);
@@ -304,6 +304,9 @@ int pcs_denselize_bwd_f32(const float *gout, const int32_t *count_map, const int
  *             -> pcs_bn_bwd_apply_f32: dx = (g - sum_g/N - xhat * sum_gxhat/N) * invstd * w, dres = g
  *             (dw = sums2[c:], db = sums2[:c]). ABI v7: `sums2` holds 2c doubles FOLLOWED BY the same 2c values as floats
  *             (3c doubles of storage): the parameter gradients in the parameters' dtype without a conversion launch.
+ *             ABI v8: the caller states the size of `sums2` in doubles (`sums2_doubles` >= 3c, else PCS_EWORKSPACE) -- a v6 caller's
+ *             2c-double buffer fails loudly instead of being overrun. (v8 also drops pcs_conv_ring_enable / pcs_conv_ring_applies:
+ *             the experimental ring kernels left the product library, tools/experimental/.)
  *   single process, statistics from the convolution's write-back: pcs_bn_reduce_partials_finalize = pcs_bn_reduce_partials +
  *             pcs_bn_finalize_f32 (count = n) in one launch (ABI v7; `sums` may be NULL there).
  * partial_ws: pcs_bn_num_partials() * 2 * c floats.
@@ -326,8 +329,8 @@ int pcs_bn_apply_f32(const float *x, const float *res, const double *stat, const
                      int64_t n, int32_t c, int32_t relu, float *y, uint32_t *mask, int64_t ldy, const float *tail,
                      int32_t ctail, void *stream);
 int pcs_bn_bwd_stats_f32(const float *dy, const float *x, const float *y, const uint32_t *mask, const double *stat,
-                         int64_t n, int32_t c, int32_t relu, float *partial_ws, double *sums2, int64_t lddy,
-                         void *stream);
+                         int64_t n, int32_t c, int32_t relu, float *partial_ws, double *sums2, int64_t sums2_doubles,
+                         int64_t lddy, void *stream);
 int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float *y, const uint32_t *mask, const double *stat,
                          const double *sums2, double count, const double *count_dev, const float *w, int64_t n,
                          int32_t c, int32_t relu, float *dx, float *dres, int64_t lddy, void *stream);
@@ -339,8 +342,8 @@ int pcs_bn_apply_h(const void *x, const void *res, const double *stat, const flo
                    int32_t c, int32_t relu, int32_t dtype, void *y, uint32_t *mask, int64_t ldy, const void *tail,
                    int32_t ctail, void *stream);
 int pcs_bn_bwd_stats_h(const void *dy, const void *x, const void *y, const uint32_t *mask, const double *stat, int64_t n,
-                       int32_t c, int32_t relu, int32_t dtype, float *partial_ws, double *sums2, int64_t lddy,
-                       void *stream);
+                       int32_t c, int32_t relu, int32_t dtype, float *partial_ws, double *sums2, int64_t sums2_doubles,
+                       int64_t lddy, void *stream);
 int pcs_bn_bwd_apply_h(const void *dy, const void *x, const void *y, const uint32_t *mask, const double *stat,
                        const double *sums2, double count, const double *count_dev, const float *w, int64_t n,
                        int32_t c, int32_t relu, int32_t dtype, void *dx, void *dres, int64_t lddy, void *stream);
@@ -410,17 +413,6 @@ int pcs_conv_gather_gemm_f32_bf16x3(const float *src, int64_t n_src, int32_t cin
  *   wgrad   : pcs_conv_wgrad_f32 with half operands; accumulated and returned in fp32 (gW, ws as in _f32).
  */
 int pcs_conv_h_applies(int32_t cin, int32_t cout, int32_t K);
-/* The fused convolution has two kernel structures behind pcs_conv_gather_gemm_f32 / pcs_conv_gather_gemm_h: the
- * wave-autonomous ones (conv_os5_kernel / conv_os5h_kernel: row-block groups per wave, ticket commit) and the ring ones
- * (csrc/conv_ring6f.hip, conv_ring6h.hip: the waves of a workgroup split the tile's COLUMNS; gathered rows enter the CU once
- * per column tile through an LDS ring filled by LDS-DMA, every weight slab once per tile; no ticket).
- *   pcs_conv_ring_enable : kind 0 = the fp32 kernel, 1 = the half kernels; mode 0 = never, 1 = wherever it applies,
- *                          -1 = the library's per-shape policy (default; the environment variables PCS_CONV_RINGF /
- *                          PCS_CONVH_RING preset it). Returns the previous mode.
- *   pcs_conv_ring_applies: 1 when the entry point would run the ring kernel for this shape and tile height now
- *                          (dtype 0 fp32, 1 / 2 bf16 / fp16). */
-int32_t pcs_conv_ring_enable(int32_t kind, int32_t mode);
-int32_t pcs_conv_ring_applies(int32_t cin, int32_t cout, int32_t K, int32_t tile_rows, int32_t dtype);
 size_t pcs_conv_prepared_weights_bytes(int32_t K, int32_t contraction, int32_t columns);
 int pcs_conv_prepare_weights_h(const float *W, int32_t K, int32_t A, int32_t B, int32_t transpose, int32_t dtype,
                                void *Wp, void *stream);

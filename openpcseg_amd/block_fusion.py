@@ -1,0 +1,398 @@
+"""Block fusion for the reference's OWN, unmodified segmentors (SURVEY.md section 8f-2 on the route north_star names).
+
+The reference builds its backbones from three blocks (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:23-129, identical
+copies in fusion/spvcnn/spvcnn.py and fusion/rpvnet/rpvnet.py):
+
+    BasicConvolutionBlock / BasicDeconvolutionBlock   nn.Sequential(spnn.Conv3d, BatchNorm, spnn.ReLU)
+    ResidualBlock (and Bottleneck)                     relu(net(x) + downsample(x)),  net = Sequential(Conv3d, BN, ReLU, Conv3d, BN)
+    stem                                               nn.Sequential(Conv3d, BN, ReLU, Conv3d, BN, ReLU)
+
+where `BatchNorm` / `SyncBatchNorm` are classes the model file defines itself (nn.BatchNorm1d / nn.SyncBatchNorm through
+`fapply`), the decoder concatenates with `torchsparse.cat([up(x), skip])` and the criterion is `pcseg.loss.Losses`
+(CrossEntropyLoss + lovasz_softmax, R:pcseg/loss/__init__.py:106-115).
+
+`fuse(model)` walks the module tree ONCE and swaps the `forward` of the containers it recognises BY STRUCTURE for the fused
+passes of this package -- the model source, its parameters, buffers and state_dict keys stay untouched (checkpoints are
+interchangeable both ways; `unfuse(model)` restores the original forwards):
+
+  * Conv3d -> BatchNorm [-> ReLU] runs inside an nn.Sequential as: convolution whose write-back also produces the BatchNorm
+    statistics (csrc/conv_common.h) -> ONE apply pass (normalise + affine [+ residual] [+ ReLU], csrc/norm.hip) and ONE backward
+    pass; SyncBatchNorm layers all-reduce the (sum, sum^2, n) vector exactly like `fused.FusedBatchNorm(sync=True)`;
+  * `relu(net(x) + downsample(x))`: the residual add and the final ReLU ride in the apply pass of net's last BatchNorm;
+  * an up-convolution block's output is handed on as a pending tensor: `torchsparse.cat([y, skip])` then lets the apply pass
+    write the concatenation (no torch.cat copy; strided dy in backward); any other use materialises it on first access;
+  * `Losses.lov_loss` (the reference's per-class python loop: 19 sorts + ~25 launches per class and their autograd graph) ->
+    `pcs_lovasz_softmax_f32` for device tensors, same value and gradient (tests/test_hip_parity.py::test_lovasz_softmax_*);
+    `Losses.ce_loss` (plain nn.CrossEntropyLoss: torch's nll_loss reduces on ONE workgroup) -> the written-out masked mean.
+
+Anything the pass does not recognise keeps its own forward; a module with forward hooks on a BatchNorm / ReLU that would be
+skipped is left alone. `install_as_torchsparse(fuse=True)` applies the pass automatically the first time a model is called.
+"""
+import inspect
+import os
+import re
+
+import torch
+from torch import nn
+
+from . import modules as spnn
+from . import native
+from .fused import _FusedBN
+from .sparse import SparseTensor
+
+__all__ = ["fuse", "unfuse", "install_auto_fuse", "uninstall_auto_fuse", "PendingBatchNorm"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BatchNorm of any nn.BatchNorm1d / nn.SyncBatchNorm subclass through the fused passes
+def _bn_like(m):
+    """A BatchNorm over SparseTensor features: an nn.BatchNorm1d / nn.SyncBatchNorm (sub)class with the standard state."""
+    return (isinstance(m, (nn.BatchNorm1d, nn.SyncBatchNorm)) and m.affine and m.track_running_stats and
+            m.momentum is not None and m.weight is not None and m.bias is not None)
+
+
+def _relu_like(m):
+    return isinstance(m, nn.ReLU)
+
+
+def _quiet(m):
+    """No forward hooks that the fused pass would skip."""
+    return not (m._forward_hooks or m._forward_pre_hooks)
+
+
+def _backend_fuses(feats):
+    be = native.backend()
+    return hasattr(be, "bn_apply") and feats.dim() == 2 and feats.dtype in (torch.float32, torch.bfloat16, torch.float16)
+
+
+def bn_forward(bn, input, residual=None, relu=False, cat_with=None):
+    """`relu(bn(input) + residual)` [concatenated with cat_with] as one fused pass, on the parameters / buffers of the
+    caller's own BatchNorm module (nn.BatchNorm1d semantics in train and eval mode; nn.SyncBatchNorm: the statistics are
+    all-reduced over the default process group)."""
+    x = input.feats
+    r = residual.feats if isinstance(residual, SparseTensor) else residual
+    tail = cat_with.feats if isinstance(cat_with, SparseTensor) else cat_with
+    if tail is not None and (x.shape[1] % 4 or tail.shape[1] % 4 or tail.shape[0] != x.shape[0] or tail.dtype != x.dtype):
+        y = bn_forward(bn, input, residual=residual, relu=relu)
+        return y._like(torch.cat([y.feats, tail.to(y.feats.dtype)], dim=1))
+    if r is not None and r.dtype != x.dtype:
+        r = r.to(x.dtype)
+    if bn.training:
+        if bn.__dict__.get("_pcs_bumped", False):
+            bn.__dict__["_pcs_bumped"] = False   # the root model's pre-forward hook already counted this step (one _foreach_add_)
+        else:
+            bn.num_batches_tracked.add_(1)
+        pre = getattr(input, "bn_sums", None)
+        if pre is not None:
+            sums, of, ver = pre
+            pre = sums if (of is x and x._version == ver) else None
+        y = _FusedBN.apply(x, r, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu,
+                           isinstance(bn, nn.SyncBatchNorm), input.cmaps, input.stride, pre, tail)
+    else:
+        inv = torch.rsqrt(bn.running_var.double() + bn.eps)
+        stat = torch.cat([bn.running_mean.double(), inv]).contiguous()
+        y = native.backend().bn_apply(x.contiguous(), r.contiguous() if r is not None else None, stat, bn.weight, bn.bias, relu,
+                                      tail=tail.contiguous() if tail is not None else None)
+    return input._like(y)
+
+
+class PendingBatchNorm(SparseTensor):
+    """The output of a fused up-convolution block before its BatchNorm apply pass has run. `torchsparse.cat([pending, skip])`
+    lets that pass write the concatenation; reading `.feats` / `.F` (any other consumer) runs the plain pass first."""
+
+    def __init__(self, conv_out, bn, relu):
+        self._feats = None
+        self._todo = (conv_out, bn, relu)
+        self.coords, self.stride = conv_out.coords, conv_out.stride
+        self.cmaps, self.kmaps = conv_out.cmaps, conv_out.kmaps
+
+    def _resolve(self, cat_with=None):
+        if self._todo is not None:
+            conv_out, bn, relu = self._todo
+            self._todo = None
+            out = bn_forward(bn, conv_out, relu=relu, cat_with=cat_with)
+            if cat_with is not None:
+                return out
+            self._feats = out.feats
+        return None
+
+    @property
+    def feats(self):
+        self._resolve()
+        return self._feats
+
+    @feats.setter
+    def feats(self, v):
+        self._todo = None
+        self._feats = v
+
+    F = property(lambda self: self.feats, lambda self, v: setattr(self, "feats", v))
+
+    def cat_with(self, other):
+        """cat([self, other]) -- fused into the apply pass when it has not run yet."""
+        if self._todo is not None and isinstance(other, SparseTensor) and other.feats.shape[0] == self._todo[0].feats.shape[0]:
+            return self._resolve(cat_with=other)
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# nn.Sequential of sparse layers
+class _Plan:
+    """What a recognised nn.Sequential runs: ('cbr', conv, bn, relu_module or None) triples and ('m', module) for the rest."""
+
+    def __init__(self, seq):
+        mods = list(seq.children())
+        self.steps, i = [], 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, spnn.Conv3d) and i + 1 < len(mods) and _bn_like(mods[i + 1]) and m.bias is None:
+                act = mods[i + 2] if i + 2 < len(mods) and _relu_like(mods[i + 2]) else None
+                self.steps.append(("cbr", m, mods[i + 1], act))
+                i += 3 if act is not None else 2
+            else:
+                self.steps.append(("m", m))
+                i += 1
+        self.n_fused = sum(1 for s in self.steps if s[0] == "cbr")
+        last = self.steps[-1] if self.steps else None
+        self.ends_in_bn = last is not None and last[0] == "cbr" and last[3] is None     # residual + final ReLU can ride here
+        self.pending = last is not None and last[0] == "cbr" and last[1].transposed    # decoder up-conv: cat may follow
+
+
+def _run_plan(seq, plan, x, residual=None, final_relu=False):
+    n = len(plan.steps)
+    for j, st in enumerate(plan.steps):
+        if st[0] == "m":
+            x = st[1](x)
+            continue
+        _, conv, bn, act = st
+        h = conv(x)   # the module call (its hooks run); emit_bn_stats makes the write-back leave the BatchNorm statistics
+        if not (isinstance(h, SparseTensor) and _backend_fuses(h.feats) and _quiet(bn) and (act is None or _quiet(act))):
+            h = bn(h)
+            x = act(h) if act is not None else h
+            if j == n - 1 and residual is not None:
+                x = x + residual
+                x = x._like(torch.relu(x.feats)) if final_relu else x
+            continue
+        last = j == n - 1
+        if last and residual is not None:
+            x = bn_forward(bn, h, residual=residual, relu=final_relu or act is not None)
+        elif last and plan.pending and residual is None and os.environ.get("PCS_CAT_FUSED", "1") != "0":
+            x = PendingBatchNorm(h, bn, act is not None)
+        else:
+            x = bn_forward(bn, h, relu=act is not None or (last and final_relu))
+    return x
+
+
+def _sequential_forward(self, input):
+    """forward of a recognised nn.Sequential (class-level: the module is re-classed, so copy.deepcopy keeps working)."""
+    if not isinstance(input, SparseTensor):
+        return nn.Sequential.forward(self, input)
+    return _run_plan(self, self.__dict__["_pcs_plan"], input)
+
+
+_RESIDUAL_SRC = re.compile(r"self\.relu\(\s*self\.net\(x\)\s*\+\s*self\.downsample\(x\)\s*\)")
+
+
+def _residual_block(m):
+    """`out = self.relu(self.net(x) + self.downsample(x))` (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:83-129, also the
+    Bottleneck :132-186): recognised by its attributes AND by the source of its forward."""
+    net, ds, act = getattr(m, "net", None), getattr(m, "downsample", None), getattr(m, "relu", None)
+    if not (isinstance(net, nn.Sequential) and _relu_like(act) and isinstance(ds, (nn.Identity, nn.Sequential))):
+        return None
+    try:
+        src = inspect.getsource(type(m).forward)
+    except (OSError, TypeError):
+        return None
+    if not _RESIDUAL_SRC.search(src) or src.count("self.") != 3:
+        return None
+    plan = _Plan(net)
+    if not plan.ends_in_bn:
+        return None
+    ds_plan = None
+    if isinstance(ds, nn.Sequential):
+        ds_plan = _Plan(ds)
+    return plan, ds_plan
+
+
+def _residual_forward(self, x):
+    plan, ds_plan = self.__dict__["_pcs_plan"]
+    if not (isinstance(x, SparseTensor) and _quiet(self.relu) and _quiet(self.net) and _quiet(self.downsample)):
+        return self.__dict__["_pcs_orig_class"].forward(self, x)
+    r = x if ds_plan is None else _run_plan(self.downsample, ds_plan, x)
+    return _run_plan(self.net, plan, x, residual=r, final_relu=True)
+
+
+_FUSED_CLASSES = {}
+
+
+def _reclass(m, forward, plan, undo):
+    """Give `m` a subclass of its own class whose forward is the fused one (cached per class; same name and module)."""
+    cls = type(m)
+    sub = _FUSED_CLASSES.get((cls, forward))
+    if sub is None:
+        sub = type(cls.__name__, (cls,), {"forward": forward, "__module__": cls.__module__, "_pcs_fused_class": True})
+        sub.__qualname__ = cls.__qualname__
+        _FUSED_CLASSES[(cls, forward)] = sub
+    m.__dict__["_pcs_plan"], m.__dict__["_pcs_orig_class"] = plan, cls
+    m.__class__ = sub
+    undo.append(("class", m, cls))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the criterion
+class _MaskedCE(nn.Module):
+    """nn.CrossEntropyLoss(ignore_index, label_smoothing, weight=None, reduction='mean') on (N, C) logits, written out as a
+    log-softmax + gather + masked mean (same value; torch's nll_loss forward / backward reduce on one workgroup: 1.3 ms each
+    for 1.2 M rows). Holds no state: swapping it in changes no state_dict."""
+
+    def __init__(self, ce):
+        super().__init__()
+        self.ignore_index, self.label_smoothing, self._orig = ce.ignore_index, float(ce.label_smoothing), [ce]
+
+    def forward(self, logits, target):
+        if not (logits.is_cuda and logits.dim() == 2 and target.dim() == 1 and not target.is_floating_point()):
+            return self._orig[0](logits, target)
+        logp = torch.nn.functional.log_softmax(logits.float(), dim=1)
+        keep = target != self.ignore_index
+        picked = logp.gather(1, target.clamp(0, logits.shape[1] - 1).unsqueeze(1)).squeeze(1)
+        per_row = -(1.0 - self.label_smoothing) * picked
+        if self.label_smoothing > 0:
+            per_row = per_row - self.label_smoothing * logp.mean(dim=1)
+        return (per_row * keep).sum() / keep.sum()
+
+
+def _lovasz_router(orig):
+    from .workloads.losses import lovasz_softmax_device
+
+    def lovasz_softmax(probas, labels, classes="present", per_image=False, ignore=None):
+        ok = (isinstance(probas, torch.Tensor) and probas.is_cuda and probas.dim() == 2 and classes == "present" and
+              not per_image and probas.shape[1] <= 60 and labels.dim() == 1 and not labels.is_floating_point())
+        if not ok:
+            return orig(probas, labels, classes=classes, per_image=per_image, ignore=ignore)
+        return lovasz_softmax_device(probas.float(), labels.long(), ignore=ignore)
+    lovasz_softmax._pcs_orig = orig
+    return lovasz_softmax
+
+
+def _fuse_criterion(m, undo):
+    n = 0
+    lov = m.__dict__.get("lov_loss")
+    if (callable(lov) and getattr(lov, "__name__", "") == "lovasz_softmax" and not hasattr(lov, "_pcs_orig") and
+            getattr(lov, "__module__", "").endswith("lovasz_losses")):
+        m.lov_loss = _lovasz_router(lov)
+        undo.append(("attr", m, "lov_loss", lov))
+        n += 1
+    ce = m._modules.get("ce_loss")
+    if type(ce) is nn.CrossEntropyLoss and ce.weight is None and ce.reduction == "mean" and _quiet(ce):
+        m._modules["ce_loss"] = _MaskedCE(ce)
+        undo.append(("submodule", m, "ce_loss", ce))
+        n += 1
+    return n
+
+
+def _bump(module, args):
+    """Root pre-forward hook: num_batches_tracked of every fused BatchNorm in one _foreach_add_ per training step instead of one
+    scalar kernel per layer; a layer that is not reached in a forward is corrected when the next forward starts."""
+    st = module.__dict__.get("_pcs_fused")
+    if st is None:
+        return
+    bns = st["bns"]
+    if module.training and bns and all(b.training for b in bns):
+        for b in bns:
+            if b.__dict__.get("_pcs_bumped", False):   # counted last step but never ran: take that count back
+                b.num_batches_tracked.sub_(1)
+            b.__dict__["_pcs_bumped"] = True
+        torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _adopt(plan, bns):
+    for st in plan.steps:
+        if st[0] == "cbr":
+            st[1].emit_bn_stats = True
+            bns.append(st[2])
+    return plan.n_fused
+
+
+def fuse(model, criterion=True):
+    """Swap the forwards of the blocks this pass recognises (see the module docstring). Idempotent. Returns a dict of counts:
+    {"sequential": .., "residual": .., "conv_bn": .., "criterion": ..}."""
+    if model.__dict__.get("_pcs_fused") is not None:
+        return dict(model.__dict__["_pcs_fused"]["counts"])
+    counts = {"sequential": 0, "residual": 0, "conv_bn": 0, "criterion": 0}
+    undo, bns, owned = [], [], set()
+    mods = list(model.modules())
+    for m in mods:
+        m.__dict__["_pcs_fuse_seen"] = True
+    for m in mods:
+        if isinstance(m, nn.Sequential) or getattr(type(m), "_pcs_fused_class", False):
+            continue
+        got = _residual_block(m)
+        if got is None:
+            continue
+        _reclass(m, _residual_forward, got, undo)
+        counts["residual"] += 1
+        for p, owner in ((got[0], m.net), (got[1], m.downsample)):
+            if p is not None:
+                counts["conv_bn"] += _adopt(p, bns)
+                owned.add(id(owner))
+    for m in mods:
+        if isinstance(m, nn.Sequential) and type(m).forward is nn.Sequential.forward:
+            plan = _Plan(m)
+            if plan.n_fused == 0:
+                continue
+            _reclass(m, _sequential_forward, plan, undo)   # (a residual block's net too: serves the block's unfused fallback)
+            if id(m) not in owned:
+                counts["sequential"] += 1
+                counts["conv_bn"] += _adopt(plan, bns)
+        elif criterion and not isinstance(m, nn.Sequential):
+            counts["criterion"] += _fuse_criterion(m, undo)
+    handle = model.register_forward_pre_hook(_bump) if bns else None
+    model.__dict__["_pcs_fused"] = {"counts": counts, "undo": undo, "hook": handle, "bns": bns}
+    return dict(counts)
+
+
+def unfuse(model):
+    st = model.__dict__.pop("_pcs_fused", None)
+    if st is None:
+        return
+    for u in reversed(st["undo"]):
+        if u[0] == "class":
+            u[1].__class__ = u[2]
+            u[1].__dict__.pop("_pcs_plan", None)
+            u[1].__dict__.pop("_pcs_orig_class", None)
+        elif u[0] == "attr":
+            setattr(u[1], u[2], u[3])
+        else:
+            u[1]._modules[u[2]] = u[3]
+    if st["hook"] is not None:
+        st["hook"].remove()
+    for b in st["bns"]:
+        if b.__dict__.pop("_pcs_bumped", False):
+            b.num_batches_tracked.sub_(1)
+    for m in model.modules():
+        m.__dict__.pop("_pcs_fuse_seen", None)
+        if isinstance(m, spnn.Conv3d):
+            m.emit_bn_stats = False
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+_AUTO = {"handle": None}
+
+
+def install_auto_fuse():
+    """`install_as_torchsparse(fuse=True)`: a process-wide forward pre-hook fuses every model the first time it is called (the
+    first module called in a forward pass is the root). Costs one dict lookup per module call afterwards."""
+    if _AUTO["handle"] is not None:
+        return
+
+    def hook(module, args):
+        if "_pcs_fuse_seen" not in module.__dict__:
+            fuse(module)
+    _AUTO["handle"] = torch.nn.modules.module.register_module_forward_pre_hook(hook)
+
+
+def uninstall_auto_fuse():
+    if _AUTO["handle"] is not None:
+        _AUTO["handle"].remove()
+        _AUTO["handle"] = None

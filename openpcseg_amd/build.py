@@ -19,9 +19,7 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-
 # per-file additions. The wave kernels: no SLP vectorisation -- it packs the 48 accumulate adds of the ticket-ordered commit
 # into v_pk_add_f32 at the price of two register moves each, inside the one serial chain of a workgroup
 EXTRA_FLAGS = {"conv_wave5.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"],
-               "conv_wave5h.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"],
-               "conv_ring6h.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"],
-               "conv_ring6f.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"]}
+               "conv_wave5h.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"]}
 
 
 def sources():
@@ -42,6 +40,9 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
+    for stale in glob.glob(os.path.join(LIB_DIR, "*.hip.o")):   # objects of sources that left csrc/ must not be linked
+        if os.path.basename(stale)[:-2] not in {os.path.basename(s) for s in sources()}:
+            os.remove(stale)
     objs = []
     procs = []
     for s in sources():

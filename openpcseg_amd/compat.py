@@ -19,7 +19,13 @@ def _module(name, **attrs):
     return m
 
 
-def install_as_torchsparse(force=False):
+def install_as_torchsparse(force=False, fuse=False):
+    """fuse=True: every model is passed through `openpcseg_amd.fuse` the first time it is called (block fusion for the
+    reference's unmodified segmentors: conv-epilogue BatchNorm statistics, BN + residual + ReLU in one pass, concat written by
+    the apply pass, device Lovasz-softmax; see block_fusion.py). State dicts are unchanged either way."""
+    if fuse:
+        from .block_fusion import install_auto_fuse
+        install_auto_fuse()
     if "torchsparse" in sys.modules and not force:
         existing = sys.modules["torchsparse"]
         if getattr(existing, "__openpcseg_amd__", False):
@@ -60,11 +66,11 @@ def install_as_torchsparse(force=False):
     return top
 
 
-def install_reference_aliases():
+def install_reference_aliases(fuse=False):
     """Everything the reference's sparse segmentors import from outside its own tree, served by this package:
     torchsparse (+ backend), torch_scatter (scatter_max / scatter_mean), range_utils (map_count / denselize)."""
     from .rangelib import install_as_range_utils
     from .scatter import install_as_torch_scatter
-    install_as_torchsparse()
+    install_as_torchsparse(fuse=fuse)
     install_as_torch_scatter()
     install_as_range_utils()

@@ -50,7 +50,7 @@ extern "C" int pcs_transpose_kab_f32(const float *src, int32_t K, int32_t A, int
 
 // Bumped whenever a fused-conv kernel, its launch shape picker or its epilogue changes: measurements keyed to kernels
 // (profiles/*_conv_traffic.json) carry the revision they were taken on and bench.py refuses a stale one.
-extern "C" const char *pcs_conv_kernel_revision(void) { return "r4.0-ring6h"; }
+extern "C" const char *pcs_conv_kernel_revision(void) { return "r5.0"; }
 
 extern "C" int32_t pcs_conv_tile_rows(int32_t cin, int32_t cout) {
   (void)cin;
@@ -240,6 +240,7 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
   return launch_conv_block(a, vec, st);
 }
 
+#if PCS_WITH_RING   // variant build only (tools/build_variant_lib.sh ring): not part of include/pcseg_hip.h
 extern "C" int32_t pcs_conv_ring_enable(int32_t kind, int32_t mode) {
   int &m = kind == 0 ? pcs::conv_ringf_mode() : pcs::conv_ring_mode();
   const int prev = m;
@@ -251,3 +252,4 @@ extern "C" int32_t pcs_conv_ring_applies(int32_t cin, int32_t cout, int32_t K, i
   if (dtype == 0) return pcs::conv_ringf_applies(cin, cout, K, tile_rows, nullptr) ? 1 : 0;
   return pcs::conv_ring_applies(cin, cout, K, tile_rows, nullptr) ? 1 : 0;
 }
+#endif

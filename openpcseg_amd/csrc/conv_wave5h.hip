@@ -18,7 +18,7 @@
 // the host layer and take the fp32 kernels. cin % 32 != 0 (56, 112, 168, 336 of RPVNet cr 1.75 ...) runs the TAIL
 // instance: the last step holds 8 / 16 / 24 channels, its out-of-range lane groups read a clamped in-row address
 // and are zeroed, and the prepared weights are zero-padded to the full step.
-#include "conv_half.h"
+#include "conv_ring.h"
 
 using namespace pcs;
 

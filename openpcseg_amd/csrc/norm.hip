@@ -487,14 +487,16 @@ extern "C" int pcs_bn_apply_h(const void *x, const void *res, const double *stat
 
 extern "C" int pcs_bn_bwd_stats_f32(const float *dy, const float *x, const float *y, const uint32_t *mask,
                                     const double *stat, int64_t n, int32_t c, int32_t relu, float *partial_ws,
-                                    double *sums2, int64_t lddy, void *stream) {
+                                    double *sums2, int64_t sums2_doubles, int64_t lddy, void *stream) {
   if (n < 0 || c <= 0 || !dy || !x || !stat || !partial_ws || !sums2 || (relu && !y && !mask)) { set_error("pcs_bn_bwd_stats: bad args"); return PCS_EINVAL; }
+  if (sums2_doubles < 3 * (int64_t)c) { set_error("pcs_bn_bwd_stats: sums2 must hold 3c doubles (2c sums + the same 2c values as floats)"); return PCS_EWORKSPACE; }
   return bn_partial(true, 0, x, dy, y, mask, stat, n, c, relu, partial_ws, sums2, as_stream(stream), lddy);
 }
 extern "C" int pcs_bn_bwd_stats_h(const void *dy, const void *x, const void *y, const uint32_t *mask,
                                   const double *stat, int64_t n, int32_t c, int32_t relu, int32_t dtype, float *partial_ws,
-                                  double *sums2, int64_t lddy, void *stream) {
+                                  double *sums2, int64_t sums2_doubles, int64_t lddy, void *stream) {
   if (n < 0 || c <= 0 || !dy || !x || !stat || !partial_ws || !sums2 || (relu && !y && !mask) || bad_half(dtype)) { set_error("pcs_bn_bwd_stats_h: bad args"); return PCS_EINVAL; }
+  if (sums2_doubles < 3 * (int64_t)c) { set_error("pcs_bn_bwd_stats_h: sums2 must hold 3c doubles (2c sums + the same 2c values as floats)"); return PCS_EWORKSPACE; }
   return bn_partial(true, dtype, x, dy, y, mask, stat, n, c, relu, partial_ws, sums2, as_stream(stream), lddy);
 }
 

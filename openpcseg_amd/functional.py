@@ -223,20 +223,35 @@ def _amp_dtype(t):
 
 class _WeightPrep:
     """Prepared copies of the convolution weights (dgrad's per-offset transposes in fp32, the fragment-ordered half weights of
-    forward and dgrad under autocast), refreshed for ALL layers by one launch the first time a step finds one stale
-    (`native.weights_multi`). The reference transposes / casts inside every layer call
-    (TS:torchsparse/backend/convolution/convolution_cuda.cu:196-206, TS:torchsparse/nn/functional/conv.py:19); weights only
-    change at the optimizer step, which bumps the parameter's in-place version counter -- the staleness test. Only leaf fp32
-    (K, A, B) device parameters are cached; anything else (padded copies, 2-D weights, other backends) takes the per-call path.
-    PCS_WEIGHT_PREP=0 switches the cache off (A/B)."""
+    forward and dgrad under autocast), refreshed for ALL layers by one launch (`native.weights_multi`) instead of inside every
+    layer call like the reference (TS:torchsparse/backend/convolution/convolution_cuda.cu:196-206,
+    TS:torchsparse/nn/functional/conv.py:19).
+
+    When a copy is stale: the copies belong to one PASS over the model. A pass ends the moment a (weight, copy) pair that was
+    already handed out in it is asked for again -- the next forward has started -- and the first request of a new pass
+    re-prepares every known copy from the live weights, whatever happened to them in between: an optimizer step, `load_state_dict`,
+    but also writes the autograd version counter does not see (`w.data.copy_()`, `w.data = t`, EMA / SWA swaps,
+    `vector_to_parameters`, multi-tensor optimizers writing through raw pointers). Inside a pass a copy is additionally refreshed
+    when the parameter's version counter or storage address changed. A training step pays the one launch it always paid
+    (the optimizer made everything stale anyway); inference pays one ~0.1 ms launch per forward. `invalidate()` forces a refresh.
+    Only leaf fp32 (K, A, B) device parameters are cached; anything else (padded copies, 2-D weights, other backends) takes the
+    per-call path. PCS_WEIGHT_PREP=0 switches the cache off (A/B)."""
 
     def __init__(self):
-        self.entries = {}   # id(weight) -> [weakref, version the copies were made at, {key: tensor}, set of valid keys]
+        self.entries = {}   # id(weight) -> [weakref, (pass, version, data_ptr) the copies were made at, {key: tensor}, keys handed out in that pass]
+        self.pass_id = 0
 
     @staticmethod
     def usable(be, weight):
         return (hasattr(be, "weights_multi") and isinstance(weight, torch.nn.Parameter) and weight.is_cuda and weight.dim() == 3 and
                 weight.dtype == torch.float32 and weight.is_contiguous() and os.environ.get("PCS_WEIGHT_PREP", "1") != "0")
+
+    def invalidate(self):
+        """Every prepared copy is stale from now on (call after writing weights behind autograd's back mid-pass)."""
+        self.pass_id += 1
+
+    def _stamp(self, w):
+        return (self.pass_id, w._version, w.data_ptr())
 
     def get(self, be, weight, key):
         """key: ("t",) or (half dtype, transpose)."""
@@ -245,9 +260,12 @@ class _WeightPrep:
         if e is None or e[0]() is not weight:
             # a new parameter: drop the copies of parameters that no longer exist (models come and go in one process)
             self.entries = {i: v for i, v in self.entries.items() if v[0]() is not None}
-            e = [weakref.ref(weight), -1, {}, set()]
+            e = [weakref.ref(weight), None, {}, set()]
             self.entries[id(weight)] = e
-        if e[1] == weight._version and key in e[3]:
+        if e[1] is not None and e[1][0] == self.pass_id and key in e[3]:
+            self.pass_id += 1   # this copy was already handed out in the current pass: a new pass over the model has begun
+        if e[1] == self._stamp(weight) and key in e[2]:
+            e[3].add(key)
             return e[2][key]
         if key not in e[2]:
             e[2][key] = be.prepared_weights_buffer(weight, *((("t", False)) if key == ("t",) else key))
@@ -256,14 +274,18 @@ class _WeightPrep:
             w = v[0]()
             if w is None or w.device != weight.device:
                 continue
-            stale = v[1] != w._version
-            for k_, dst in v[2].items():
-                if stale or k_ not in v[3]:
-                    jobs.append((w.detach(), dst, "t" if k_ == ("t",) else k_[0], False if k_ == ("t",) else k_[1]))
-            marks.append((v, w._version))
+            stamp = self._stamp(w)
+            if v[1] != stamp or (v is e):
+                for k_, dst in v[2].items():
+                    if v[1] != stamp or k_ == key:
+                        jobs.append((w.detach(), dst, "t" if k_ == ("t",) else k_[0], False if k_ == ("t",) else k_[1]))
+                marks.append((v, stamp))
         be.weights_multi(jobs)
-        for v, ver in marks:
-            v[1], v[3] = ver, set(v[2].keys())
+        for v, stamp in marks:
+            if v[1] != stamp:
+                v[3] = set()
+            v[1] = stamp
+        e[3].add(key)
         return e[2][key]
 
 

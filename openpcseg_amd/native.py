@@ -66,12 +66,12 @@ SIGNATURES = {
     "pcs_bn_stats_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P]),
     "pcs_bn_finalize_f32": (c_int32, [_P, c_double, _P, c_int32, c_double, c_double, _P, _P, _P, _P]),
     "pcs_bn_apply_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, c_int32, _P]),
-    "pcs_bn_bwd_stats_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P]),
+    "pcs_bn_bwd_stats_f32": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, c_int64, _P]),
     "pcs_bn_bwd_apply_f32": (c_int32, [_P, _P, _P, _P, _P, _P, c_double, _P, _P, c_int64, c_int32, c_int32, _P, _P,
                                        c_int64, _P]),
     "pcs_bn_stats_h": (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
     "pcs_bn_apply_h": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, c_int64, _P, c_int32, _P]),
-    "pcs_bn_bwd_stats_h": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, c_int64, _P]),
+    "pcs_bn_bwd_stats_h": (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, c_int64, c_int64, _P]),
     "pcs_bn_bwd_apply_h": (c_int32, [_P, _P, _P, _P, _P, _P, c_double, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P,
                                      c_int64, _P]),
     "pcs_quantize_floor": (c_int32, [_P, c_int32, c_int64, c_int32, _P, _P, _P, _P]),
@@ -79,8 +79,6 @@ SIGNATURES = {
     "pcs_quantize_flags": (c_int32, [_P, c_int64, _P, _P]),
     "pcs_quantize_emit": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "pcs_conv_h_applies": (c_int32, [c_int32, c_int32, c_int32]),
-    "pcs_conv_ring_enable": (c_int32, [c_int32, c_int32]),
-    "pcs_conv_ring_applies": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "pcs_conv_prepared_weights_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "pcs_conv_prepare_weights_h": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_conv_gather_gemm_h": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32, _P, c_int32, c_int64,
@@ -110,7 +108,7 @@ class _WeightJob(ctypes.Structure):   # pcs_weight_job of include/pcseg_hip.h
                 ("transpose", c_int32), ("nctt", c_int32), ("nt16", c_int32), ("ns", c_int32), ("first_block", c_int64)]
 
 
-ABI_VERSION = 7  # include/pcseg_hip.h PCS_ABI_VERSION (7: pcs_lovasz_*; 6: ring kernel switch / query; 5: fp32 convolution on the bf16 MFMAs, pcs_conv_*_x3; 4: tile order)
+ABI_VERSION = 8  # include/pcseg_hip.h PCS_ABI_VERSION (8: sums2 size argument of pcs_bn_bwd_stats_*, ring switch removed; 7: pcs_lovasz_*; 6: ring kernel switch / query; 5: fp32 convolution on the bf16 MFMAs, pcs_conv_*_x3; 4: tile order)
 _lib = None
 
 
@@ -975,10 +973,10 @@ class HipBackend:
         yp, mp = self._gate(gate, relu)
         if x.dtype == torch.float32:
             _check(self.lib.pcs_bn_bwd_stats_f32(_ptr(dy), _ptr(x), yp, mp, _ptr(stat), n, c, int(relu),
-                                                 _ptr(ws), _ptr(sums2), lddy, _stream()), "pcs_bn_bwd_stats_f32")
+                                                 _ptr(ws), _ptr(sums2), buf.numel(), lddy, _stream()), "pcs_bn_bwd_stats_f32")
         else:
             _check(self.lib.pcs_bn_bwd_stats_h(_ptr(dy), _ptr(x), yp, mp, _ptr(stat), n, c, int(relu), self._HALF[x.dtype],
-                                               _ptr(ws), _ptr(sums2), lddy, _stream()), "pcs_bn_bwd_stats_h")
+                                               _ptr(ws), _ptr(sums2), buf.numel(), lddy, _stream()), "pcs_bn_bwd_stats_h")
         return sums2
 
     def bn_bwd_apply(self, dy, x, gate, stat, sums2, count, w, relu, want_res, count_dev=None):

@@ -103,6 +103,11 @@ class PointTensor:
 
 def cat(inputs):
     """Channel-concatenate SparseTensors that share coordinates."""
+    fused = getattr(inputs[0], "cat_with", None)   # block_fusion.PendingBatchNorm: the BatchNorm apply pass writes the concatenation
+    if fused is not None and len(inputs) == 2:
+        out = fused(inputs[1])
+        if out is not None:
+            return out
     return inputs[0]._like(torch.cat([x.feats for x in inputs], dim=1))
 
 

@@ -38,13 +38,22 @@ MODEL_CFG = {
 # config 2 on a TWO-frame batch (seeds 0 and 4): batch-level BatchNorm statistics, loss and gradients over frames that never
 # share a voxel (the batch index is part of every hashed coordinate) -- what the one-frame fixtures cannot pin
 MODEL_CFG["config2x2"] = MODEL_CFG["config2"]
+# the graph BASELINE.json's metric is quoted on (and bench.py's headline times): MinkUNet-34 cr1.0,
+# R:tools/cfgs/voxel/semantic_kitti/minkunet_mk34_cr10.yaml:17-20 (NUM_LAYER [2,3,4,6,2,2,2,2]); one full frame, seed 6
+MODEL_CFG["config_mk34"] = dict(MODEL_CFG["config2"], NUM_LAYER=[2, 3, 4, 6, 2, 2, 2, 2])
+# training-trajectory fixture (make_golden.py trajectory): MinkUNet-18 cr0.5, the optimizer of the shipped yaml
+# (R:tools/cfgs/voxel/semantic_kitti/minkunet_mk34_cr10.yaml:25-33: SGD, momentum 0.9, weight decay 1e-4, clip 10) at a fixed lr
+MODEL_CFG["trajectory"] = dict(MODEL_CFG["config2"], cr=0.5)
+TRAJ = dict(seeds=[11, 12], n_points=20000, steps=10, lr=0.02, momentum=0.9, weight_decay=1e-4, clip=10.0)
 BATCH_SEEDS = {"config2x2": [0, 4]}
 MODEL_PATH = {"config2x2": ("pcseg.model.segmentor.voxel.minkunet.minkunet", "MinkUNet"),
+              "config_mk34": ("pcseg.model.segmentor.voxel.minkunet.minkunet", "MinkUNet"),
+              "trajectory": ("pcseg.model.segmentor.voxel.minkunet.minkunet", "MinkUNet"),
               "config2": ("pcseg.model.segmentor.voxel.minkunet.minkunet", "MinkUNet"),
               "config3": ("pcseg.model.segmentor.fusion.spvcnn.spvcnn", "SPVCNN"),
               "config4": ("pcseg.model.segmentor.voxel.cylinder3d.cylinder_ts", "Cylinder_TS"),
               "config5": ("pcseg.model.segmentor.fusion.rpvnet.rpvnet", "RPVNet")}
-FRAME_SEED = {"config2": 0, "config3": 1, "config4": 2, "config5": 3}
+FRAME_SEED = {"config2": 0, "config3": 1, "config4": 2, "config5": 3, "config_mk34": 6}
 CYL_LO, CYL_HI, CYL_GRID = [0, -180, -4], [50, 180, 2], [480, 360, 32]   # cylinder_cy480_cr10.yaml:7-9
 RANGE_H, RANGE_W = 64, 2048                                                # SemanticKITTI range image of the reference
 

@@ -489,17 +489,8 @@ def main_lovasz():
     print("wrote lovasz_golden.npz:", {k: float(v) for k, v in g.items() if k.endswith("_loss")})
 
 
-def main_full(cfg_name):
-    """BASELINE configs 2-5 at full size (tests/golden/fullsize.py holds the shared definitions): the reference's own
-    segmentor, fp32, ONE full synthetic frame (120 000 rays), TRAIN mode (batch statistics), forward + loss + backward
-    (R:train.py:360-371) on the reference's torchsparse + its compiled CPU backend. Inputs are regenerated from the
-    seed by the tests, so the fixture keeps their CRCs, every 16th row of the logits, float64 column sums over all rows,
-    the loss and per-parameter gradient fingerprints.
-    Substitutions, none of which changes semantics: devoxelize_backward_cpu (wrong in the reference's CPU twin,
-    devoxelize_cpu.cpp:51-53) -> the restatement of devoxelize_cuda.cu:37-57; torch_scatter / range_lib (no CPU build)
-    -> install_scatter_stub / install_range_stub (configs 4 / 5 inherit 'parity unpinned' for those two ops only)."""
-    import time
-    import fullsize as fs
+def _reference_cpu_setup(per_frame_kernel_hash):
+    """The reference's torchsparse on its compiled CPU backend, with the substitutions main_full's docstring lists."""
     ts = import_reference_torchsparse()
     from oracle import oracle as orc
     backend = sys.modules["torchsparse.backend"]
@@ -507,7 +498,7 @@ def main_full(cfg_name):
     def devox_bwd(gout, idx, w, n):
         return torch.from_numpy(orc.devoxelize_bwd(gout.contiguous().numpy(), idx.numpy(), w.numpy(), int(n)))
     backend.devoxelize_backward_cpu = devox_bwd
-    if cfg_name in fs.BATCH_SEEDS:
+    if per_frame_kernel_hash:
         # multi-frame batch: the reference's CPU kernel_hash reads the batch index of row 0 for every row (hash_cpu.cpp:29;
         # its CUDA twin hash_cuda.cu:42-46 is right) -- called per frame here, which restates the CUDA semantics
         kh_one = backend.kernel_hash_cpu
@@ -520,7 +511,21 @@ def main_full(cfg_name):
             return out
         backend.kernel_hash_cpu = kernel_hash_per_frame
     install_scatter_stub()
-    rnf = install_range_stub()
+    return ts, install_range_stub()
+
+
+def main_full(cfg_name):
+    """BASELINE configs 2-5 at full size (tests/golden/fullsize.py holds the shared definitions): the reference's own
+    segmentor, fp32, ONE full synthetic frame (120 000 rays), TRAIN mode (batch statistics), forward + loss + backward
+    (R:train.py:360-371) on the reference's torchsparse + its compiled CPU backend. Inputs are regenerated from the
+    seed by the tests, so the fixture keeps their CRCs, every 16th row of the logits, float64 column sums over all rows,
+    the loss and per-parameter gradient fingerprints.
+    Substitutions, none of which changes semantics: devoxelize_backward_cpu (wrong in the reference's CPU twin,
+    devoxelize_cpu.cpp:51-53) -> the restatement of devoxelize_cuda.cu:37-57; torch_scatter / range_lib (no CPU build)
+    -> install_scatter_stub / install_range_stub (configs 4 / 5 inherit 'parity unpinned' for those two ops only)."""
+    import time
+    import fullsize as fs
+    ts, rnf = _reference_cpu_setup(per_frame_kernel_hash=cfg_name in fs.BATCH_SEEDS)
     dotted, cls = fs.MODEL_PATH[cfg_name]
     mod = import_reference_model(dotted)
     if cfg_name == "config5":
@@ -548,6 +553,57 @@ def main_full(cfg_name):
     np.savez_compressed(os.path.join(OUT, "%s_golden.npz" % cfg_name), **g)
     print("wrote %s_golden.npz: rows" % cfg_name, logits.shape, "kept", g["logits_rows"].shape, "loss", loss,
           "|logit| max %.2f" % np.abs(logits).max(), "params with grad", len(g["grad_names"]))
+
+
+def main_trajectory():
+    """Stand-in for the mIoU clause of north_star (no dataset / checkpoint here): a TRAINING TRAJECTORY of the reference.
+    MinkUNet-18 cr0.5 (tests/golden/fullsize.py MODEL_CFG["trajectory"]) on a two-frame batch of 20 000-ray scans, `steps`
+    iterations in the order of R:train.py:355-371 -- zero_grad, forward, loss.backward, clip_grad_norm_, optimizer.step -- with the
+    shipped optimizer (SGD momentum 0.9, weight decay 1e-4, clip 10; minkunet_mk34_cr10.yaml:25-33) at a fixed learning rate, on
+    the reference's torchsparse + compiled CPU backend. Keeps the loss of every step and a fingerprint (float64 sum / abs-sum /
+    abs-max + eight samples) of every parameter and BatchNorm buffer after the last step."""
+    import time
+    import fullsize as fs
+    from torch.nn.utils import clip_grad_norm_
+    ts, _ = _reference_cpu_setup(per_frame_kernel_hash=True)
+    from openpcseg_amd.workloads.synthetic import make_batch
+    T = fs.TRAJ
+    dotted, cls = fs.MODEL_PATH["trajectory"]
+    mod = import_reference_model(dotted)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    model = getattr(mod, cls)(_AttrDict(fs.MODEL_CFG["trajectory"]), 20)
+    seeded_state(model)
+    model.train()
+    b = make_batch(T["seeds"], n_points=T["n_points"])
+    feats, coords, labels = b["lidar"].feats, b["lidar"].coords, b["targets"].feats
+    g = {"crc_feats": np.array(fs.crc(feats.numpy())), "crc_coords": np.array(fs.crc(coords.numpy())),
+         "crc_labels": np.array(fs.crc(labels.numpy()))}
+    opt = torch.optim.SGD(model.parameters(), lr=T["lr"], momentum=T["momentum"], weight_decay=T["weight_decay"])
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    losses, norms = [], []
+    t0 = time.time()
+    try:
+        for it in range(T["steps"]):
+            model.train()
+            opt.zero_grad()
+            batch = {"lidar": ts.SparseTensor(feats.clone(), coords), "targets": ts.SparseTensor(labels, coords), "offset": None}
+            ret = model(batch)
+            loss = ret[0]["loss"].mean()
+            loss.backward()
+            norms.append(float(clip_grad_norm_(model.parameters(), T["clip"])))
+            opt.step()
+            losses.append(float(loss.detach()))
+            print("step %d loss %.6f grad norm %.4f (%.0f s)" % (it, losses[-1], norms[-1], time.time() - t0), flush=True)
+    finally:
+        torch.Tensor.cuda = orig
+    g["losses"], g["grad_norms"] = np.array(losses, dtype=np.float64), np.array(norms, dtype=np.float64)
+    state = [(n, t) for n, t in model.state_dict().items() if t.dtype.is_floating_point]
+    fp = fs.grad_fingerprint(state)
+    g["state_names"], g["state_stats"], g["state_samples"] = fp["grad_names"], fp["grad_stats"], fp["grad_samples"]
+    np.savez_compressed(os.path.join(OUT, "trajectory_golden.npz"), **g)
+    print("wrote trajectory_golden.npz: losses", losses)
 
 
 def main_cylinder():
@@ -590,8 +646,10 @@ def main_cylinder():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cylinder":
         main_cylinder()
-    elif len(sys.argv) > 1 and sys.argv[1] in ("config2", "config3", "config4", "config5", "config2x2"):
+    elif len(sys.argv) > 1 and sys.argv[1] in ("config2", "config3", "config4", "config5", "config2x2", "config_mk34"):
         main_full(sys.argv[1])
+    elif len(sys.argv) > 1 and sys.argv[1] == "trajectory":
+        main_trajectory()
     elif len(sys.argv) > 1 and sys.argv[1] == "models":
         main_models()
     elif len(sys.argv) > 1 and sys.argv[1] == "quantize":

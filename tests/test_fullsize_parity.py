@@ -51,7 +51,14 @@ BOUNDS = {
     "config4/reference": (1e-3, 1e-5, 3e-3, 3.6e-2, 1.8e-2, 5.5e-2),  # 8.8e-4   1.5e-3 / 1.8e-2   8.8e-3 / 2.7e-2 (see above)
     "config2x2/reference": (9e-4, 1e-5, 9e-4, 4e-3, 4e-3, 1.3e-2),    # 4.5e-4   4.5e-4 / 2.0e-3   1.9e-3 / 6.7e-3 (two-frame batch, logit scale 150; r4)
     "config5/reference": (8e-4, 2e-5, 2e-4, 6e-4, 5e-4, 4e-3),       # 4.1e-4   7.8e-5 / 2.9e-4   2.3e-4 / 1.8e-3
+    # [r5] the graph the headline metric is quoted on: MinkUNet-34 cr1.0 (NUM_LAYER [2,3,4,6,2,2,2,2]), one full frame (seed 6),
+    # logit scale 318 (3x config 2's)
+    "config_mk34/reference": (1.5e-3, 3e-5, 1e-3, 4e-3, 8e-3, 2e-2),
+    "config_mk34/workload": (1.5e-3, 3e-5, 1e-3, 4e-3, 8e-3, 2e-2),
 }
+# the same reference sources after openpcseg_amd.fuse(model) (block fusion, openpcseg_amd/block_fusion.py): the bounds of the plain route
+for _k in ("config2", "config3", "config5", "config2x2", "config_mk34"):
+    BOUNDS[_k + "/reference+fuse"] = BOUNDS[_k + "/reference"]
 _MEASURED = {}
 
 
@@ -116,36 +123,53 @@ def _reference_model(cfg):
     return model
 
 
-@pytest.mark.parametrize("cfg", ["config2", "config3", "config4", "config5", "config2x2"])
+@pytest.mark.parametrize("cfg", ["config2", "config3", "config4", "config5", "config2x2", "config_mk34"])
 def test_fullsize_inputs_regenerate(cfg):
     """CPU: the seeded frame of every fixture regenerates bit-identically (what makes the fixtures usable at all)."""
     _inputs(cfg, _golden(cfg))
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["config2", "config3", "config4", "config5", "config2x2"])
-def test_fullsize_reference_model_on_hip(cfg, hip):
-    """The reference's own segmentor source on libpcseg_hip.so: logits, loss and every parameter gradient of one full
-    training step vs the reference's run on its own CPU backend."""
+def _reference_step_on_hip(cfg, fuse):
+    import openpcseg_amd
     from openpcseg_amd.sparse import SparseTensor
     g = _golden(cfg)
     dev = torch.device("cuda:0")
     batch = fs.to_device(cfg, _inputs(cfg, g), dev, SparseTensor)
     model = fs.freeze_dropout(_reference_model(cfg).to(dev).train())
+    if fuse:
+        counts = openpcseg_amd.fuse(model)
+        assert counts["residual"] >= 16 and counts["criterion"] == 2, counts
     logits, loss = fs.run_train_step(cfg, model, batch)
     m = fs.compare(g, logits, loss, fs.model_grads(model))
     m["loss_ref"] = float(g["loss"])
-    _record(cfg + "/reference", m)
-    _assert_bounds(cfg + "/reference", m)
+    name = cfg + ("/reference+fuse" if fuse else "/reference")
+    _record(name, m)
+    _assert_bounds(name, m)
 
 
-def _workload(g, dev, amp=None, wgrad="fp32", conv="fp32"):
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["config2", "config3", "config4", "config5", "config2x2", "config_mk34"])
+def test_fullsize_reference_model_on_hip(cfg, hip):
+    """The reference's own segmentor source on libpcseg_hip.so: logits, loss and every parameter gradient of one full
+    training step vs the reference's run on its own CPU backend."""
+    _reference_step_on_hip(cfg, fuse=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["config2", "config3", "config5", "config2x2", "config_mk34"])
+def test_fullsize_reference_model_fused_on_hip(cfg, hip):
+    """The same sources after `openpcseg_amd.fuse(model)` -- conv-epilogue BatchNorm statistics, BN + residual + ReLU in one pass,
+    concat written by the apply pass, device Lovasz-softmax / masked-mean CE -- against the same fixtures with the same bounds."""
+    _reference_step_on_hip(cfg, fuse=True)
+
+
+def _workload(g, dev, amp=None, wgrad="fp32", conv="fp32", cfg="config2"):
     from seeded import seeded_state
     from openpcseg_amd import functional as pcsF
     from openpcseg_amd.sparse import SparseTensor
-    from openpcseg_amd.workloads.minkunet import MK18_LAYERS, MinkUNet
-    batch = fs.to_device("config2", _inputs("config2", g), dev, SparseTensor)
-    model = MinkUNet(num_class=20, num_layer=MK18_LAYERS, cr=1.0)
+    from openpcseg_amd.workloads.minkunet import MinkUNet
+    batch = fs.to_device(cfg, _inputs(cfg, g), dev, SparseTensor)
+    model = MinkUNet(num_class=20, num_layer=fs.MODEL_CFG[cfg]["NUM_LAYER"], cr=1.0)
     seeded_state(model)
     model.to(dev).train()
     pcsF.set_wgrad_policy(wgrad)
@@ -180,28 +204,43 @@ def test_fullsize_workload_minkunet18_on_hip(hip, wgrad):
     _assert_bounds("config2/workload", m)
 
 
+@pytest.mark.gpu
+def test_fullsize_workload_minkunet34_on_hip(hip):
+    """[r5] The exact graph bench.py's headline times -- this package's fused MinkUNet with MK34_LAYERS, cr 1.0 -- against the
+    reference's MinkUNet-34 run (tests/golden/config_mk34_golden.npz: R:tools/cfgs/voxel/semantic_kitti/minkunet_mk34_cr10.yaml)."""
+    g = _golden("config_mk34")
+    logits, loss, grads = _workload(g, torch.device("cuda:0"), cfg="config_mk34")
+    m = fs.compare(g, logits, loss, grads)
+    m["loss_ref"] = float(g["loss"])
+    _record("config_mk34/workload", m)
+    _assert_bounds("config_mk34/workload", m)
+
+
 # bf16 / fp16 autocast: 16-bit storage of every activation (8 / 11 significant bits), fp32 accumulation. The bound is per
 # point, relative to the RMS of the reference logits (measured: see profiles/round3_fullsize_parity.json).
 # measured (bf16 / fp16): max 0.21 / 0.026 of the RMS, mean 0.0098 / 0.0013, worst parameter-gradient abs-sum 8.7 % / 2.8 %,
 # arg-max agreement with the fp32 reference 98.6 % / 99.7 % of the points
 AMP_BOUNDS = {torch.bfloat16: (0.30, 0.02, 0.12, 0.975), torch.float16: (0.05, 0.0025, 0.04, 0.99)}  # max / rms, mean / rms, grad, arg-max
+# [r5] MinkUNet-34 (the headline graph, 15 more residual blocks than config 2)
+AMP_BOUNDS_MK34 = {torch.bfloat16: (0.45, 0.03, 0.18, 0.97), torch.float16: (0.08, 0.004, 0.06, 0.985)}
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["config2", "config_mk34"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-def test_fullsize_workload_autocast_vs_fp32_reference(dtype, hip):
+def test_fullsize_workload_autocast_vs_fp32_reference(dtype, cfg, hip):
     """Model-level half-precision check against the fp32 REFERENCE logits and gradients (not against our own fp32 run):
     a wrong layer, a dropped residual or a mis-scaled gradient in the 16-bit path moves these by O(1)."""
-    g = _golden("config2")
-    logits, loss, grads = _workload(g, torch.device("cuda:0"), amp=dtype)
+    g = _golden(cfg)
+    logits, loss, grads = _workload(g, torch.device("cuda:0"), amp=dtype, cfg=cfg)
     step, ref = int(g["row_step"]), g["logits_rows"]
     rms = float(np.sqrt((ref.astype(np.float64) ** 2).mean()))
     err = np.abs(logits[::step] - ref)
     m = fs.compare(g, logits, loss, grads)
     m.update({"logit_rms": rms, "logit_max_err_over_rms": float(err.max() / rms), "logit_mean_err_over_rms": float(err.mean() / rms),
               "argmax_agreement": float((logits[::step].argmax(1) == ref.argmax(1)).mean()), "loss_ref": float(g["loss"])})
-    _record("config2/workload/" + str(dtype).split(".")[1], m)
-    bmax, bmean, bgrad, bagree = AMP_BOUNDS[dtype]
+    _record(cfg + "/workload/" + str(dtype).split(".")[1], m)
+    bmax, bmean, bgrad, bagree = (AMP_BOUNDS if cfg == "config2" else AMP_BOUNDS_MK34)[dtype]
     assert m["logit_max_err_over_rms"] < bmax, m
     assert m["logit_mean_err_over_rms"] < bmean, m
     assert m["argmax_agreement"] > bagree, m

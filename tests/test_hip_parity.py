@@ -1,6 +1,7 @@
 """Parity of the HIP path (through the C ABI) with the oracle and the reference goldens.
 Run with `-m gpu` on an MI355X. Integer / index work: bit-exact. fp32: tolerance stated per test.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -1038,3 +1039,55 @@ def test_weights_multi(hip, monkeypatch):
             res[mode] = (losses, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
         assert res["0"][0] == res["1"][0], (amp, res["0"][0], res["1"][0])
         assert all(torch.equal(res["0"][1][n], res["1"][1][n]) for n in res["0"][1]), amp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("amp", [None, torch.bfloat16], ids=["fp32", "bf16"])
+def test_weight_prep_sees_writes_behind_autograd(hip, amp):
+    """`w.data.copy_()`, `w.data = t` (EMA / SWA swaps, `module._apply`, raw-pointer optimizers) do not bump
+    the parameter's version counter. The prepared copies (`functional._WeightPrep`: dgrad transposes, fragment-ordered half
+    weights) belong to one pass over the model and are rebuilt when the next pass starts, so forward AND input gradient follow
+    the live weight -- checked against a fresh, cache-less computation after each kind of write."""
+    from openpcseg_amd import functional as F
+    from openpcseg_amd import modules as spnn
+    from openpcseg_amd.sparse import SparseTensor
+    from openpcseg_amd.workloads.synthetic import make_batch
+    b = make_batch([1], n_points=6000)
+    coords = b["lidar"].C.to(DEV)
+    torch.manual_seed(0)
+    conv = spnn.Conv3d(64, 96, 3).to(DEV)
+    assert F._WeightPrep.usable(hip, conv.kernel)
+    x0 = torch.randn(coords.shape[0], 64, device=DEV)
+
+    def run(cached):
+        os.environ["PCS_WEIGHT_PREP"] = "1" if cached else "0"
+        try:
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=amp or torch.bfloat16, enabled=amp is not None):
+                y = conv(SparseTensor(x, coords)).F
+            y.float().square().sum().backward()
+            return y.detach().float().clone(), x.grad.clone()
+        finally:
+            os.environ.pop("PCS_WEIGHT_PREP", None)
+
+    def check(what):
+        conv.zero_grad(set_to_none=True)
+        y1, g1 = run(True)
+        y0, g0 = run(False)
+        assert torch.equal(y1, y0) and torch.equal(g1, g0), what
+
+    check("first pass")
+    check("unchanged weights")
+    ver = conv.kernel._version
+    conv.kernel.data.mul_(2.0)                       # in place through .data: same version, same storage
+    assert conv.kernel._version == ver
+    check(".data.mul_")
+    conv.kernel.data.copy_(torch.randn_like(conv.kernel) * 0.05)
+    check(".data.copy_")
+    conv.kernel.data = torch.randn_like(conv.kernel) * 0.05   # new storage, same Parameter object
+    check(".data = tensor")
+    with torch.no_grad():
+        conv.kernel.add_(0.01)                       # the ordinary, version-bumping update
+    check("in-place under no_grad")
+    F._WEIGHT_PREP.invalidate()
+    check("explicit invalidate")

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = native.load_library()  # dlopen works without a GPU
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pcs_abi_version() == native.ABI_VERSION == 7
+    assert lib.pcs_abi_version() == native.ABI_VERSION == 8
     assert lib.pcs_hashtable_capacity(1000) == 2048
     assert lib.pcs_hashtable_bytes(2048) == 2048 * 12
     assert lib.pcs_conv_tile_rows(32, 32) in (64, 128)
@@ -335,8 +335,10 @@ def test_weights_multi_plan_is_a_host_function():
 
 
 def test_weight_prep_cache_refreshes_all_layers_once(monkeypatch):
-    """functional._WeightPrep: the first stale copy met in a step refreshes every registered layer's copies in ONE backend call;
-    unchanged weights cost no call; a dead parameter's copies are dropped."""
+    """functional._WeightPrep: the prepared copies belong to one PASS over the model. The first request of a new pass (= a copy
+    that was already handed out is asked for again) refreshes every registered layer's copies in ONE backend call, whatever
+    happened to the weights in between -- including writes the version counter does not see (`w.data.copy_()`); within a
+    pass a version bump or a new storage also refreshes; a dead parameter's copies are dropped."""
     import torch
     from openpcseg_amd import functional as F
 
@@ -353,21 +355,31 @@ def test_weight_prep_cache_refreshes_all_layers_once(monkeypatch):
     monkeypatch.setattr(F._WeightPrep, "usable", staticmethod(lambda be, w: True))
     prep, be = F._WeightPrep(), FakeBackend()
     ws = [torch.nn.Parameter(torch.randn(27, 8, 8)) for _ in range(3)]
-    for w in ws:                      # first step: every layer is new -> one call each (nothing else is stale yet)
+    for w in ws:                      # first pass: every layer is new -> one call each (nothing else is stale yet)
         prep.get(be, w, ("t",))
     assert [len(c) for c in be.calls] == [1, 1, 1]
     be.calls.clear()
-    for w in ws:                      # weights unchanged: cache hits only
+    for w in ws:                      # second pass, weights untouched: ONE call for all three, at the first request
         prep.get(be, w, ("t",))
-    assert be.calls == []
+    assert [len(c) for c in be.calls] == [3]
+    be.calls.clear()
+    ws[1].data.mul_(2.0)              # behind autograd's back: same version counter, same storage
+    prep.get(be, ws[2], ("t",))       # third pass starts at another layer ...
+    assert len(be.calls) == 1 and len(be.calls[0]) == 3   # ... and refreshes all three, the silently rewritten one included
+    prep.get(be, ws[1], ("t",))
+    assert len(be.calls) == 1         # same pass: a hit
     with torch.no_grad():
-        for w in ws:
-            w.add_(1.0)               # the optimizer step
-    prep.get(be, ws[2], ("t",))       # the first layer backward meets ...
-    assert len(be.calls) == 1 and len(be.calls[0]) == 3   # ... refreshes all three
+        ws[0].add_(1.0)               # a versioned write in the middle of a pass (ws[0] not handed out yet in this pass)
     prep.get(be, ws[0], ("t",))
+    assert len(be.calls) == 2 and be.calls[1] == [(ws[0].data_ptr(), "t", False)]
     prep.get(be, ws[1], (torch.bfloat16, True))           # a new kind for one layer: only that copy
-    assert len(be.calls) == 2 and be.calls[1] == [(ws[1].data_ptr(), torch.bfloat16, True)]
+    assert len(be.calls) == 3 and be.calls[2] == [(ws[1].data_ptr(), torch.bfloat16, True)]
+    ws[2].data = torch.randn(27, 8, 8)                    # new storage for a parameter of this pass ...
+    prep.invalidate()                                     # ... and the explicit switch: everything is stale
+    be.calls.clear()
+    prep.get(be, ws[0], ("t",))
+    assert len(be.calls) == 1 and len(be.calls[0]) == 4   # three transposes + the bf16 copy
+    assert (ws[2].data_ptr(), "t", False) in be.calls[0]
     del ws[0]
     import gc
     gc.collect()

@@ -1,0 +1,117 @@
+"""Training-trajectory parity: the stand-in for north_star's "val mIoU within 0.2 of the reference checkpoint" (no dataset and no
+checkpoint exist in this environment).
+
+Fixture: tests/golden/trajectory_golden.npz, made by `make_golden.py trajectory` by RUNNING the reference -- its MinkUNet-18 cr0.5
+source on its own torchsparse + compiled CPU backend -- for 10 iterations of R:train.py:355-371 (zero_grad -> forward -> backward ->
+clip_grad_norm_ -> SGD step; optimizer of R:tools/cfgs/voxel/semantic_kitti/minkunet_mk34_cr10.yaml:25-33) on a two-frame batch of
+20 000-ray synthetic scans. It keeps the loss and the clipped gradient norm of every step and a fingerprint of every parameter and
+BatchNorm buffer after the last one.
+
+`-m gpu`: the same ten iterations on libpcseg_hip.so through (a) the reference's source, (b) the reference's source after
+`openpcseg_amd.fuse`, (c) this package's fused MinkUNet workload (what bench.py times). Bounds: every step's loss within 1e-4
+relative, final weights within 1e-3 (abs-sum per tensor, and sampled elements relative to the tensor's largest element)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import fullsize as fs  # noqa: E402
+from stage_reference import reference_root  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden", "trajectory_golden.npz")
+LOSS_REL, WEIGHT_REL = 1e-4, 1e-3
+
+
+def _fixture():
+    if not os.path.exists(GOLDEN):
+        pytest.skip("trajectory_golden.npz not generated")
+    return np.load(GOLDEN)
+
+
+def _batch_arrays(g):
+    from openpcseg_amd.workloads.synthetic import make_batch
+    T = fs.TRAJ
+    b = make_batch(T["seeds"], n_points=T["n_points"])
+    feats, coords, labels = b["lidar"].feats, b["lidar"].coords, b["targets"].feats
+    assert fs.crc(feats.numpy()) == int(g["crc_feats"]) and fs.crc(coords.numpy()) == int(g["crc_coords"])
+    assert fs.crc(labels.numpy()) == int(g["crc_labels"])
+    return feats, coords, labels
+
+
+def test_trajectory_inputs_regenerate():
+    """CPU: the batch the reference trained on regenerates bit-identically from its seeds."""
+    g = _fixture()
+    _batch_arrays(g)
+    assert len(g["losses"]) == fs.TRAJ["steps"] and np.isfinite(g["losses"]).all()
+    assert g["grad_norms"].max() > fs.TRAJ["clip"]      # the clip is active on this trajectory (it is part of what is pinned)
+
+
+def _model(route, dev):
+    from seeded import seeded_state
+    cfg = fs.MODEL_CFG["trajectory"]
+    if route == "workload":
+        from openpcseg_amd.workloads.minkunet import MinkUNet
+        model = MinkUNet(num_class=20, num_layer=cfg["NUM_LAYER"], cr=cfg["cr"], label_smoothing=cfg["LABEL_SMOOTHING"],
+                         dropout=cfg["DROPOUT_P"])
+    else:
+        if reference_root() is None:
+            pytest.skip("neither /root/reference nor tests/_refsrc present")
+        import make_golden as mg
+        import openpcseg_amd
+        openpcseg_amd.install_reference_aliases()
+        dotted, cls = fs.MODEL_PATH["trajectory"]
+        model = getattr(mg.import_reference_model(dotted), cls)(mg._AttrDict(cfg), 20)
+    seeded_state(model)
+    model.to(dev).train()
+    if route == "reference+fuse":
+        import openpcseg_amd
+        openpcseg_amd.fuse(model)
+    return model
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["reference", "reference+fuse", "workload"])
+def test_training_trajectory_on_hip(route, hip):
+    from torch.nn.utils import clip_grad_norm_
+    from openpcseg_amd.sparse import SparseTensor
+    g = _fixture()
+    T = fs.TRAJ
+    dev = torch.device("cuda:0")
+    feats, coords, labels = (t.to(dev) for t in _batch_arrays(g))
+    model = _model(route, dev)
+    opt = torch.optim.SGD(model.parameters(), lr=T["lr"], momentum=T["momentum"], weight_decay=T["weight_decay"])
+    losses, norms = [], []
+    for _ in range(T["steps"]):
+        model.train()
+        opt.zero_grad()
+        ret = model({"lidar": SparseTensor(feats.clone(), coords), "targets": SparseTensor(labels, coords), "offset": None})
+        ret = ret[0] if isinstance(ret, tuple) else ret
+        loss = ret["loss"].mean()
+        loss.backward()
+        norms.append(float(clip_grad_norm_(model.parameters(), T["clip"])))
+        opt.step()
+        losses.append(float(loss.detach()))
+    losses, norms = np.array(losses), np.array(norms)
+    loss_err = np.abs(losses / g["losses"] - 1)
+    norm_err = np.abs(norms / g["grad_norms"] - 1)
+    state = [(n, t) for n, t in model.state_dict().items() if t.dtype.is_floating_point]
+    mine = fs.grad_fingerprint(state)
+    assert [str(n) for n in mine["grad_names"]] == [str(n) for n in g["state_names"]], "state_dict keys differ from the reference's"
+    rs, ms = g["state_stats"], mine["grad_stats"]
+    e_abs = np.abs(ms[:, 1] / rs[:, 1] - 1)
+    e_smp = np.abs(mine["grad_samples"] - g["state_samples"]).max(1) / rs[:, 2]
+    m = {"loss_rel_err_max": float(loss_err.max()), "loss_rel_err_last": float(loss_err[-1]), "grad_norm_rel_err_max": float(norm_err.max()),
+         "weights_abssum_rel_err_max": float(e_abs.max()), "weights_sample_err_rel_max": float(e_smp.max()),
+         "worst_tensor": str(g["state_names"][int(np.argmax(e_abs))]), "losses": [round(float(v), 6) for v in losses]}
+    print("\n[trajectory] %s: %s" % (route, json.dumps(m)))
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "trajectory_%s.json" % route.replace("+", "_")), "w") as f:
+            json.dump(m, f, indent=1)
+    assert m["loss_rel_err_max"] < LOSS_REL, m
+    assert m["weights_abssum_rel_err_max"] < WEIGHT_REL and m["weights_sample_err_rel_max"] < WEIGHT_REL, m

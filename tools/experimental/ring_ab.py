@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the two fused-convolution structures on the real rulebooks of the synthetic batch: the wave-autonomous kernels
+"""[needs the variant library: bash tools/build_variant_lib.sh ring; PCS_LIB_PATH=openpcseg_amd/lib/dbg/ring.so]
+A/B of the two fused-convolution structures on the real rulebooks of the synthetic batch: the wave-autonomous kernels
 (conv_os5_kernel fp32 / conv_os5h_kernel bf16) against the column-parallel ring kernels (conv_ring6f.hip / conv_ring6h.hip),
 switched at run time through pcs_conv_ring_enable. One line per (dtype, shape): time and TFLOP/s of both, the tile heights the
 picker chose, and the largest difference between the two results relative to the tensor maximum.
@@ -9,7 +10,7 @@ picker chose, and the largest difference between the two results relative to the
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 DEFAULT_SHAPES = "0 96 96;0 128 96;1 96 96;1 128 96;2 128 128;2 192 128;2 64 64;3 256 256;3 384 256;3 128 128;4 256 256;1 32 64"
 

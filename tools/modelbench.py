@@ -13,7 +13,11 @@ A step = zero_grad + forward + loss + backward + SGD step on synthetic 120k-poin
 rebuilt each step, as in the reference). The reference sources are read from /root/reference or their staged copy
 tests/_refsrc (bench plumbing: nothing under openpcseg_amd/ imports this file).
 
-    python tools/modelbench.py [spec]        spec = "auto" | comma list of name[:reference|workload][:f32|bf16]
+    python tools/modelbench.py [spec]        spec = "auto" | comma list of name[:reference|fuse|workload][:f32|bf16]
+
+source `fuse` = the reference's source after `openpcseg_amd.fuse(model)` (block fusion, openpcseg_amd/block_fusion.py): the record
+`<name>/ref+fuse`. Timing [r5]: clock pre-heat (windows of 5 steps until a window is no longer > 0.4 % faster than the one before,
+2..6 windows) and PCS_MB_STEPS (default 10) timed steps, like the headline.
 """
 import json
 import os
@@ -30,8 +34,8 @@ import torch  # noqa: E402
 
 FRAMES = {"minkunet18": 16, "spvcnn18": 16, "cylinder": 12, "rpvnet34": 4, "minkunet34": 12}
 CFG_OF = {"minkunet18": "config2", "spvcnn18": "config3", "cylinder": "config4", "rpvnet34": "config5", "minkunet34": "config2"}
-AUTO = ["minkunet34:reference", "minkunet18:reference", "minkunet18:workload", "spvcnn18:reference", "cylinder:reference",
-        "rpvnet34:reference"]
+AUTO = ["minkunet34:reference", "minkunet34:fuse", "minkunet18:reference", "minkunet18:fuse", "minkunet18:workload",
+        "spvcnn18:reference", "spvcnn18:fuse", "cylinder:reference", "rpvnet34:reference", "rpvnet34:fuse"]
 
 
 def _reference_model(name):
@@ -56,7 +60,18 @@ def _reference_model(name):
     return model
 
 
+_BATCHES = {}
+
+
 def _lidar_batch(n_frames, dev, elongation=False, range_view=False):
+    key = (n_frames, str(dev), elongation, range_view)
+    if key not in _BATCHES:   # the same synthetic batch serves every record of one run (generated on the host: seconds each)
+        _BATCHES.clear()
+        _BATCHES[key] = _make_lidar_batch(n_frames, dev, elongation, range_view)
+    return _BATCHES[key]
+
+
+def _make_lidar_batch(n_frames, dev, elongation=False, range_view=False):
     import fullsize as fs
     from openpcseg_amd.sparse import SparseTensor
     from openpcseg_amd.workloads.synthetic import make_batch
@@ -114,6 +129,17 @@ def _time_steps(step, steps, warmup):
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    if os.environ.get("PCS_BENCH_PREHEAT", "1") != "0":   # the headline's clock pre-heat (bench.py::preheat), shortened
+        prev = None
+        for wi in range(6):
+            t0 = time.perf_counter()
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            cur = time.perf_counter() - t0
+            if wi >= 1 and cur >= 0.996 * prev:
+                break
+            prev = cur
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -121,7 +147,7 @@ def _time_steps(step, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
-def bench_one(name, source, dtype, dev, steps=3, warmup=2):
+def bench_one(name, source, dtype, dev, steps=10, warmup=2):
     n_frames = FRAMES[name]
     if source == "workload":
         from seeded import seeded_state
@@ -133,6 +159,9 @@ def bench_one(name, source, dtype, dev, steps=3, warmup=2):
     else:
         model = _reference_model(name)
     model.to(dev).train()
+    if source == "fuse":
+        import openpcseg_amd
+        openpcseg_amd.fuse(model)
     if name == "cylinder":
         fresh, n_vox = _cylinder_batch(n_frames, dev)
     else:
@@ -159,14 +188,14 @@ def bench_one(name, source, dtype, dev, steps=3, warmup=2):
     return {"value": round(n_frames / sec, 2), "ms_per_step": round(sec * 1e3, 1), "frames": n_frames}
 
 
-def run(spec, dev, steps=3, warmup=2):
+def run(spec, dev, steps=10, warmup=2):
     """-> {"<name>/<source>": {"f32": frames/s, "bf16": frames/s, "ms": [..], "frames": B}} (compact: one entry per model)."""
     items = AUTO if spec in ("auto", "", None) else [s for s in spec.split(",") if s]
     out = {}
     for it in items:
         parts = it.split(":")
         name = parts[0]
-        source = parts[1] if len(parts) > 1 and parts[1] in ("reference", "workload") else "reference"
+        source = parts[1] if len(parts) > 1 and parts[1] in ("reference", "workload", "fuse") else "reference"
         dtypes = [parts[-1]] if parts[-1] in ("f32", "bf16", "fp16") else ["f32", "bf16"]
         rec = {}
         for dt in dtypes:
@@ -179,10 +208,10 @@ def run(spec, dev, steps=3, warmup=2):
                 rec[dt] = None
                 rec["error"] = (type(e).__name__ + ": " + str(e))[:120]
             torch.cuda.empty_cache()
-        out["%s/%s" % (name, "ref" if source == "reference" else "fused")] = rec
+        out["%s/%s" % (name, {"reference": "ref", "fuse": "ref+fuse", "workload": "fused"}[source])] = rec
     return out
 
 
 if __name__ == "__main__":
     print(json.dumps(run(sys.argv[1] if len(sys.argv) > 1 else "auto", torch.device("cuda:0"),
-                         steps=int(os.environ.get("PCS_MB_STEPS", "3")), warmup=int(os.environ.get("PCS_MB_WARMUP", "2")))))
+                         steps=int(os.environ.get("PCS_MB_STEPS", "10")), warmup=int(os.environ.get("PCS_MB_WARMUP", "2")))))
