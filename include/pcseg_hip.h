@@ -286,6 +286,26 @@ int pcs_denselize_bwd_csr_f32(const float *gout, const int64_t *order, const int
 int pcs_denselize_bwd_f32(const float *gout, const int32_t *count_map, const int32_t *pxpy, int64_t n,
                           int32_t B, int32_t C, int32_t H, int32_t W, float *gfeat, void *stream);
 
+/* ---- range image -> points (ABI v8) --------------------------------------------------------------------------------------
+ * Replaces R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:31-51 (`resample_grid_stacked` / `range_to_point`: a python loop over
+ * frames around torch.nn.functional.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=False)) for all frames in
+ * one launch, and its backward (torch's grid_sampler_2d_backward: per-point channel loops of float atomics into NCHW planes,
+ * 25 % of an RPVNet step) by an atomic-free segmented pass.
+ *   img  (B, C, H, W) fp32;  pxpy (n, 3) fp32 rows (frame, x, y), x / y in [-1, 1];  out (n, C): out[p] = bilinear sample of
+ *   frame pxpy[p][0] at ix = ((x + 1) W - 1) / 2, iy = ((y + 1) H - 1) / 2; corners outside the image contribute 0; a row whose
+ *   frame is not an integer in [0, B) gives zeros. C % 4 == 0 (16-byte row pieces), else PCS_EUNSUPPORTED.
+ *   backward: pcs_range_sample_corners writes, per point and corner (nw, ne, sw, se), the pixel key (b H + y) W + x (or -1) and the
+ *   bilinear weight: keys / wts of 4 n entries. The caller sorts the keys (stable) into a CSR over the B H W pixels -- order
+ *   (4 n entry ids, the -1 keys first) and rowptr (B H W + 1), once per pxpy and resolution -- and pcs_range_sample_bwd_csr_f32
+ *   writes EVERY element of gimg (B, C, H, W): gimg[b, c, y, x] = sum over the pixel's entries of wts[e] * gout[e / 4, c], in
+ *   ascending entry order (deterministic); no memset needed. */
+int pcs_range_sample_fwd_f32(const float *img, const float *pxpy, int64_t n, int32_t B, int32_t C, int32_t H, int32_t W,
+                             float *out, void *stream);
+int pcs_range_sample_corners(const float *pxpy, int64_t n, int32_t B, int32_t H, int32_t W, int64_t *keys, float *wts,
+                             void *stream);
+int pcs_range_sample_bwd_csr_f32(const float *gout, const int64_t *order, const int64_t *rowptr, const float *wts,
+                                 int32_t B, int32_t C, int32_t H, int32_t W, float *gimg, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Block fusion above the op boundary: training-mode BatchNorm over (N,C)
  * voxel features fused with the residual add and the ReLU that follow it in the reference's

@@ -9,10 +9,10 @@ from .sparse import SparseTensor, PointTensor, cat, fapply, get_kernel_offsets, 
 from .compat import install_as_torchsparse, install_reference_aliases  # noqa: F401
 
 
-def fuse(model, criterion=True):
+def fuse(model, criterion=True, glue=True, forward=True):
     """Block fusion for an unmodified reference segmentor (openpcseg_amd/block_fusion.py)."""
     from .block_fusion import fuse as _fuse
-    return _fuse(model, criterion=criterion)
+    return _fuse(model, criterion=criterion, glue=glue, forward=forward)
 
 
 def unfuse(model):

@@ -25,12 +25,32 @@ interchangeable both ways; `unfuse(model)` restores the original forwards):
     `pcs_lovasz_softmax_f32` for device tensors, same value and gradient (tests/test_hip_parity.py::test_lovasz_softmax_*);
     `Losses.ce_loss` (plain nn.CrossEntropyLoss: torch's nll_loss reduces on ONE workgroup) -> the written-out masked mean.
 
+  * [glue] the module-level helpers `initial_voxelize` / `voxel_to_point` / `point_to_voxel` the model file imported from its
+    `utils.py` (R:pcseg/model/segmentor/voxel/minkunet/utils.py:11-105 and the identical copies next to spvcnn.py / rpvnet.py) are
+    re-bound, in the MODEL module's namespace, to this package's equivalents (workloads/pointvoxel.py: unique + query + count from
+    one stable sort, the whole trilinear corner map in one kernel, the level's cached hash table) -- only when their source text
+    is byte-identical to the reference's (SHA-1 below), i.e. when it is known exactly what they compute;
+    likewise `range_to_point` of rpvnet.py:31-51 (a python loop of `F.grid_sample` per frame, whose torch backward -- channel
+    loops of float atomics into NCHW planes -- is 25 % of an RPVNet step) -> `rangelib.range_to_point` (csrc/rangesample.hip);
+  * [forward] a model whose class is named MinkUNet and whose `forward` source is byte-identical to
+    R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:385-434 runs, in training mode, the same graph with the classifier applied
+    on the voxels before the trilinear interpolation (`fused.devoxelized_linear`: interpolation and the Linear commute; the
+    (N, 480) point-feature tensor and its gradient are never materialised) and ONE `loss.item()` instead of two. Same
+    submodules, same criterion, same returned dictionaries; eval mode keeps the reference's forward.
+
+  * [point MLPs] `nn.Sequential(nn.Linear, nn.BatchNorm1d | nn.SyncBatchNorm, nn.ReLU)` on plain (N, C) point features (the
+    `point_transforms` of R:pcseg/model/segmentor/fusion/spvcnn/spvcnn.py:335-352 and rpvnet.py:571-592): the Linear's weight
+    gradient x^T dy -- a (C_in, C_out) result contracted over ~2 M points, which hipBLASLt runs on a handful of workgroups (8.6 ms
+    per SPVCNN step) -- on the split-reduction wgrad kernel, BatchNorm + ReLU as the fused passes.
+
 Anything the pass does not recognise keeps its own forward; a module with forward hooks on a BatchNorm / ReLU that would be
 skipped is left alone. `install_as_torchsparse(fuse=True)` applies the pass automatically the first time a model is called.
 """
+import hashlib
 import inspect
 import os
 import re
+import sys
 
 import torch
 from torch import nn
@@ -40,7 +60,7 @@ from . import native
 from .fused import _FusedBN
 from .sparse import SparseTensor
 
-__all__ = ["fuse", "unfuse", "install_auto_fuse", "uninstall_auto_fuse", "PendingBatchNorm"]
+__all__ = ["fuse", "unfuse", "restore_glue", "install_auto_fuse", "uninstall_auto_fuse", "PendingBatchNorm"]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -137,8 +157,14 @@ class PendingBatchNorm(SparseTensor):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # nn.Sequential of sparse layers
+def _dense_bn(m):
+    """nn.BatchNorm1d / nn.SyncBatchNorm applied to plain (N, C) tensors: the stock forward, not a SparseTensor wrapper."""
+    return _bn_like(m) and type(m).forward in (nn.BatchNorm1d.forward, nn.SyncBatchNorm.forward, nn.modules.batchnorm._BatchNorm.forward)
+
+
 class _Plan:
-    """What a recognised nn.Sequential runs: ('cbr', conv, bn, relu_module or None) triples and ('m', module) for the rest."""
+    """What a recognised nn.Sequential runs: ('cbr', conv, bn, relu_module or None) triples over SparseTensors, ('lbr', linear, bn,
+    relu or None) triples over plain (N, C) tensors, and ('m', module) for the rest."""
 
     def __init__(self, seq):
         mods = list(seq.children())
@@ -149,13 +175,80 @@ class _Plan:
                 act = mods[i + 2] if i + 2 < len(mods) and _relu_like(mods[i + 2]) else None
                 self.steps.append(("cbr", m, mods[i + 1], act))
                 i += 3 if act is not None else 2
+            elif type(m) is nn.Linear and i + 1 < len(mods) and _dense_bn(mods[i + 1]) and mods[i + 1].num_features == m.out_features:
+                act = mods[i + 2] if i + 2 < len(mods) and type(mods[i + 2]) is nn.ReLU else None
+                self.steps.append(("lbr", m, mods[i + 1], act))
+                i += 3 if act is not None else 2
             else:
                 self.steps.append(("m", m))
                 i += 1
-        self.n_fused = sum(1 for s in self.steps if s[0] == "cbr")
+        self.n_fused = sum(1 for s in self.steps if s[0] in ("cbr", "lbr"))
+        self.n_dense = sum(1 for s in self.steps if s[0] == "lbr")
         last = self.steps[-1] if self.steps else None
         self.ends_in_bn = last is not None and last[0] == "cbr" and last[3] is None     # residual + final ReLU can ride here
         self.pending = last is not None and last[0] == "cbr" and last[1].transposed    # decoder up-conv: cat may follow
+
+
+_POINT_MAPS = {}   # identity maps (row count, device) of the point MLPs' weight gradients: one per step, shared by all of them
+
+
+class _PointLinear(torch.autograd.Function):
+    """y = x W^T + b over ~2 M point rows: forward and input gradient stay dense GEMMs (hipBLASLt through torch), the weight gradient
+    x^T dy -- (C_in, C_out), contracted over every point -- runs on the split-reduction wgrad kernel (as functional._PointwiseConv)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from .functional import _amp_dtype
+        hd = _amp_dtype(x)
+        ctx.save_for_backward(x, weight)
+        ctx.hd, ctx.has_bias = hd, bias is not None
+        if hd is None:
+            return torch.nn.functional.linear(x.float(), weight.float(), bias.float() if bias is not None else None)
+        return torch.nn.functional.linear(x.to(hd), weight.to(hd), bias.to(hd) if bias is not None else None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .functional import _identity_map
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        hd = ctx.hd
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = (dy.float().matmul(weight.float()) if hd is None else dy.to(hd).matmul(weight.to(hd))).to(x.dtype)
+        if ctx.needs_input_grad[1]:
+            if len(_POINT_MAPS) > 4:
+                _POINT_MAPS.clear()
+            km = _identity_map(x.shape[0], x.device, _POINT_MAPS)
+            be = native.backend()
+            if hd is not None:
+                gw = be.conv_wgrad_h(x.contiguous().to(hd), dy.to(hd), km, 0)[0]
+            else:
+                gw = be.conv_wgrad(x.contiguous().float(), dy.float(), km, 0)[0]
+            gw = gw.t().to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = dy.float().sum(0).to(weight.dtype)
+        return gx, gw, gb
+
+
+def _dense_step(lin, bn, act, x):
+    """Linear -> BatchNorm -> [ReLU] on a plain (N, C) tensor through the fused passes; the modules themselves where they do not apply."""
+    ok = (x.dim() == 2 and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and x.shape[0] >= 4096 and
+          lin.in_features % 4 == 0 and lin.out_features % 4 == 0 and hasattr(native.backend(), "bn_apply") and
+          _quiet(lin) and _quiet(bn) and (act is None or _quiet(act)))
+    if not ok:
+        h = bn(lin(x))
+        return act(h) if act is not None else h
+    h = _PointLinear.apply(x, lin.weight, lin.bias)
+    if bn.training:
+        if bn.__dict__.get("_pcs_bumped", False):
+            bn.__dict__["_pcs_bumped"] = False
+        else:
+            bn.num_batches_tracked.add_(1)
+        return _FusedBN.apply(h, None, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act is not None,
+                              isinstance(bn, nn.SyncBatchNorm), None, None, None, None)
+    inv = torch.rsqrt(bn.running_var.double() + bn.eps)
+    stat = torch.cat([bn.running_mean.double(), inv]).contiguous()
+    return native.backend().bn_apply(h.contiguous(), None, stat, bn.weight, bn.bias, act is not None)
 
 
 def _run_plan(seq, plan, x, residual=None, final_relu=False):
@@ -163,6 +256,13 @@ def _run_plan(seq, plan, x, residual=None, final_relu=False):
     for j, st in enumerate(plan.steps):
         if st[0] == "m":
             x = st[1](x)
+            continue
+        if st[0] == "lbr":
+            if isinstance(x, torch.Tensor):
+                x = _dense_step(st[1], st[2], st[3], x)
+            else:
+                x = st[2](st[1](x))
+                x = st[3](x) if st[3] is not None else x
             continue
         _, conv, bn, act = st
         h = conv(x)   # the module call (its hooks run); emit_bn_stats makes the write-back leave the BatchNorm statistics
@@ -185,9 +285,10 @@ def _run_plan(seq, plan, x, residual=None, final_relu=False):
 
 def _sequential_forward(self, input):
     """forward of a recognised nn.Sequential (class-level: the module is re-classed, so copy.deepcopy keeps working)."""
-    if not isinstance(input, SparseTensor):
+    plan = self.__dict__["_pcs_plan"]
+    if not isinstance(input, SparseTensor) and not (plan.n_dense and isinstance(input, torch.Tensor)):
         return nn.Sequential.forward(self, input)
-    return _run_plan(self, self.__dict__["_pcs_plan"], input)
+    return _run_plan(self, plan, input)
 
 
 _RESIDUAL_SRC = re.compile(r"self\.relu\(\s*self\.net\(x\)\s*\+\s*self\.downsample\(x\)\s*\)")
@@ -306,20 +407,152 @@ def _bump(module, args):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# the point <-> voxel glue and the MinkUNet forward, recognised by the SHA-1 of their source text (computed from /root/reference)
+_GLUE_SHA1 = {"initial_voxelize": "d86d7900a8d70be1746f57eb311959ae0e23770a",
+              "voxel_to_point": "ab9c4461fe068ac54a5105b96b90072206bb1f82",
+              "point_to_voxel": "546ed12789757812f69502843a6d5bd4216130af"}
+_MINKUNET_FORWARD_SHA1 = "e5ef7d830c649b15021924421d95424e7a0501c8"
+# R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:31-51: range_to_point = resample_grid_stacked = grid_sample per frame
+_RANGE_TO_POINT_SHA1 = {"range_to_point": "84c1b2d60560e333892da86ed6372b6a55585c61",
+                        "resample_grid_stacked": "c0f10770b7114ddf6cd1193e721fea602d6b905f"}
+
+
+def _source_sha1(fn):
+    try:
+        return hashlib.sha1(inspect.getsource(fn).encode()).hexdigest()
+    except (OSError, TypeError):
+        return None
+
+
+_GLUE_ORIG = {}   # (module name, helper name) -> the reference's function (process-wide: `restore_glue()` puts them back)
+
+
+def restore_glue():
+    """Undo every helper re-binding `fuse(..., glue=True)` made in this process."""
+    for (modname, name), fn in list(_GLUE_ORIG.items()):
+        ns = sys.modules.get(modname)
+        if ns is not None:
+            setattr(ns, name, fn)
+        del _GLUE_ORIG[(modname, name)]
+
+
+def _range_to_point_via(orig):
+    from .rangelib import range_to_point as fused
+
+    def range_to_point(feature_map, pxpy, grid_sample_mode="bilinear"):
+        # one launch each way instead of grid_sample per frame (csrc/rangesample.hip); what the kernels do not serve goes to the
+        # reference's own function
+        return fused(feature_map, pxpy, grid_sample_mode, fallback=orig)
+    range_to_point.__module__ = "openpcseg_amd.rangelib"
+    return range_to_point
+
+
+def _fuse_glue(model):
+    """Re-bind the reference's glue helpers in the namespaces of the modules that define this model's classes. The namespace
+    belongs to the model FILE, so the re-binding serves every instance built from it (same results; `restore_glue()` undoes it)."""
+    from .workloads import pointvoxel as pv
+    n, seen = 0, set()
+    for m in model.modules():
+        modname = type(m).__dict__.get("__module__", type(m).__module__)
+        if modname in seen:
+            continue
+        seen.add(modname)
+        ns = sys.modules.get(modname)
+        if ns is None:
+            continue
+        for name, sha in _GLUE_SHA1.items():
+            fn = ns.__dict__.get(name)
+            if fn is None or getattr(fn, "__module__", "").startswith("openpcseg_amd") or not inspect.isfunction(fn):
+                continue
+            if _source_sha1(fn) == sha:
+                setattr(ns, name, getattr(pv, name))
+                _GLUE_ORIG[(modname, name)] = fn
+                n += 1
+        r2p = ns.__dict__.get("range_to_point")
+        if (inspect.isfunction(r2p) and not getattr(r2p, "__module__", "").startswith("openpcseg_amd") and
+                all(_source_sha1(ns.__dict__.get(k)) == v for k, v in _RANGE_TO_POINT_SHA1.items())):
+            setattr(ns, "range_to_point", _range_to_point_via(r2p))
+            _GLUE_ORIG[(modname, "range_to_point")] = r2p
+            n += 1
+    return n
+
+
+def _minkunet_forward(self, batch_dict, return_logit=False, return_tta=False):
+    """Training-mode forward of the reference's MinkUNet (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:385-434) with the
+    classifier commuted in front of the three trilinear interpolations; everything else line by line as the reference."""
+    from . import sparse as ts
+    from .fused import devoxelized_linear
+    from .workloads.pointvoxel import initial_voxelize, point_maps, voxel_to_point
+    lin = self.classifier[0] if isinstance(self.classifier, nn.Sequential) and len(self.classifier) == 1 else None
+    x = batch_dict["lidar"]
+    if not (self.training and isinstance(lin, nn.Linear) and x.F.is_cuda and _quiet(lin) and _quiet(self.classifier) and
+            _quiet(self.dropout) and hasattr(native.backend(), "corner_map") and os.environ.get("PCS_CLASSIFIER_COMMUTE", "1") != "0"):
+        return self.__dict__["_pcs_orig_class"].forward(self, batch_dict, return_logit, return_tta)
+    x.F = x.F[:, :self.in_feature_dim]
+    z = ts.PointTensor(x.F, x.C.float())
+    x0 = initial_voxelize(z, self.pres, self.vres)
+    x0 = self.stem(x0)
+    z0 = voxel_to_point(x0, z, nearest=False)
+    x1 = self.stage1(x0)
+    x2 = self.stage2(x1)
+    x3 = self.stage3(x2)
+    x4 = self.stage4(x3)
+    drop = self.dropout
+    t1 = devoxelized_linear(lin.weight, 0, x4.F, *point_maps(x4, z0), x4.kmaps)          # = voxel_to_point(x4, z0).F @ W[:, :c4]^T
+    c4 = x4.F.shape[1]
+    x4.F = torch.nn.functional.dropout(x4.F, drop.p, drop.training, False)                # out of place: x4.F feeds t1's weight gradient
+    y1 = self.up1[0](x4)
+    y1 = ts.cat([y1, x3])
+    y1 = self.up1[1](y1)
+    y2 = self.up2[0](y1)
+    y2 = ts.cat([y2, x2])
+    y2 = self.up2[1](y2)
+    t2 = devoxelized_linear(lin.weight, c4, y2.F, *point_maps(y2, z0), y2.kmaps)
+    c2 = y2.F.shape[1]
+    y2.F = torch.nn.functional.dropout(y2.F, drop.p, drop.training, False)
+    y3 = self.up3[0](y2)
+    y3 = ts.cat([y3, x1])
+    y3 = self.up3[1](y3)
+    y4 = self.up4[0](y3)
+    y4 = ts.cat([y4, x0])
+    y4 = self.up4[1](y4)
+    t3 = devoxelized_linear(lin.weight, c4 + c2, y4.F, *point_maps(y4, z0), y4.kmaps)
+    out = t1 + t2 + t3
+    if lin.bias is not None:
+        out = out + lin.bias
+    target = batch_dict["targets"].F.long().cuda(non_blocking=True)
+    coords_xyz = batch_dict["lidar"].C[:, :3].float()
+    loss = self.criterion_losses(out, target, xyz=coords_xyz, offset=batch_dict["offset"])
+    value = loss.item()
+    return {"loss": loss}, {"loss": value}, {"loss": value}
+
+
+def _fuse_model_forward(m, undo):
+    if (type(m).__name__ == "MinkUNet" and not getattr(type(m), "_pcs_fused_class", False) and
+            _source_sha1(type(m).forward) == _MINKUNET_FORWARD_SHA1 and
+            all(hasattr(m, a) for a in ("stem", "stage1", "stage4", "up1", "up4", "classifier", "dropout", "criterion_losses",
+                                        "in_feature_dim", "pres", "vres"))):
+        _reclass(m, _minkunet_forward, None, undo)
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def _adopt(plan, bns):
     for st in plan.steps:
         if st[0] == "cbr":
             st[1].emit_bn_stats = True
+        if st[0] in ("cbr", "lbr"):
             bns.append(st[2])
     return plan.n_fused
 
 
-def fuse(model, criterion=True):
+def fuse(model, criterion=True, glue=True, forward=True):
     """Swap the forwards of the blocks this pass recognises (see the module docstring). Idempotent. Returns a dict of counts:
-    {"sequential": .., "residual": .., "conv_bn": .., "criterion": ..}."""
+    {"sequential": .., "residual": .., "conv_bn": .., "criterion": .., "glue": .., "forward": ..}."""
     if model.__dict__.get("_pcs_fused") is not None:
         return dict(model.__dict__["_pcs_fused"]["counts"])
-    counts = {"sequential": 0, "residual": 0, "conv_bn": 0, "criterion": 0}
+    counts = {"sequential": 0, "residual": 0, "conv_bn": 0, "criterion": 0, "glue": 0, "forward": 0}
     undo, bns, owned = [], [], set()
     mods = list(model.modules())
     for m in mods:
@@ -347,6 +580,11 @@ def fuse(model, criterion=True):
                 counts["conv_bn"] += _adopt(plan, bns)
         elif criterion and not isinstance(m, nn.Sequential):
             counts["criterion"] += _fuse_criterion(m, undo)
+    if bns and glue:
+        counts["glue"] = _fuse_glue(model)
+    if bns and forward:
+        for m in mods:
+            counts["forward"] += _fuse_model_forward(m, undo)
     handle = model.register_forward_pre_hook(_bump) if bns else None
     model.__dict__["_pcs_fused"] = {"counts": counts, "undo": undo, "hook": handle, "bns": bns}
     return dict(counts)

@@ -284,6 +284,27 @@ class _SkinnyLinearParts(Function):
         return (dw, db, None, None) + tuple(grads)
 
 
+def devoxelized_linear(weight, col, xf, idx, wts, cache):
+    """devoxelize(xf) @ W_i^T computed as devoxelize(xf @ W_i^T), W_i = weight[:, col : col + C_i] of an nn.Linear weight:
+    trilinear devoxelisation is linear over the voxel features (fixed per-point weights), so it commutes with the classifier --
+    the class scores are formed on the VOXELS (36 k / 329 k / 1.16 M rows of 256 / 128 / 96 channels -> num_class) and only
+    num_class channels per point are interpolated, instead of interpolating 480 channels per point and contracting them there
+    (2.7 GB of point features written, read by the classifier, and the same again as gradients in backward). Same function; the
+    fp32 rounding order differs. xf (V, C_i) voxel features, idx / wts (N, 8) the points' corner map. The bias is added on the
+    points by the caller: the weights of a point with missing corners do not sum to one. cache: dict that keeps the identity map
+    of this row count (pass the tensor's per-forward `kmaps`: built once per level and step, freed with the step)."""
+    from . import functional as F_
+    cin, cout = xf.shape[1], weight.shape[0]
+    w = weight[:, col:col + cin]
+    ok = (xf.is_cuda and xf.dim() == 2 and xf.dtype in (torch.float32, torch.bfloat16, torch.float16) and
+          xf.shape[0] >= 4096 and cin % 4 == 0 and cout % 4 == 0)
+    if ok:
+        v = _SkinnyLinear.apply(xf, w, None, cache, xf.dtype if xf.dtype != torch.float32 else None)
+    else:
+        v = torch.nn.functional.linear(xf.float(), w.float())
+    return F_.spdevoxelize(v.float(), idx, wts)
+
+
 class FusedLinear(nn.Linear):
     """nn.Linear (same parameters / state_dict keys) whose fp32 device path runs on the fused conv kernels when the
     row count dwarfs the feature sizes and the shapes are 16-byte granular; anything else is nn.Linear."""
@@ -306,27 +327,15 @@ class FusedLinear(nn.Linear):
             hd = torch.get_autocast_dtype("cuda")
         return _SkinnyLinear.apply(x, self.weight, self.bias, self._maps, hd)
 
-    def devoxelized_part(self, col, xf, idx, wts):
+    def devoxelized_part(self, col, xf, idx, wts, cache=None):
         """One term of forward(cat([devoxelize(x_i) for i], 1)) = sum_i devoxelize(x_i @ W_i^T) + b, W_i = the column
-        block [col, col + C_i) of the weight: trilinear devoxelisation is linear over the voxel features (fixed
-        per-point weights), so it commutes with the classifier -- the class scores are formed on the VOXELS (36 k /
-        329 k / 1.16 M rows of 256 / 128 / 96 channels -> num_class) and only num_class channels per point are
-        interpolated, instead of interpolating 480 channels per point and contracting them there (2.7 GB of point
-        features written, read by the classifier, and the same again as gradients in backward). Same function; the fp32
-        rounding order differs. xf (V, C_i) voxel features, idx / wts (N, 8) the points' corner map. The bias is added
-        on the points (`sum_devoxelized`): the weights of a point with missing corners do not sum to one."""
-        from . import functional as F_
-        if len(self._maps) > 8:
-            self._maps.clear()
-        cin = xf.shape[1]
-        w = self.weight[:, col:col + cin]
-        ok = (xf.is_cuda and xf.dim() == 2 and xf.dtype in (torch.float32, torch.bfloat16, torch.float16) and
-              xf.shape[0] >= 4096 and cin % 4 == 0 and self.out_features % 4 == 0)
-        if ok:
-            v = _SkinnyLinear.apply(xf, w, None, self._maps, xf.dtype if xf.dtype != torch.float32 else None)
-        else:
-            v = torch.nn.functional.linear(xf.float(), w.float())
-        return F_.spdevoxelize(v.float(), idx, wts)
+        block [col, col + C_i) of the weight (`devoxelized_linear`). cache: a per-forward dict for the identity map of this row
+        count (the tensor's `kmaps`); default: the module's own small cache."""
+        if cache is None:
+            if len(self._maps) > 8:
+                self._maps.clear()
+            cache = self._maps
+        return devoxelized_linear(self.weight, col, xf, idx, wts, cache)
 
     def sum_devoxelized(self, terms):
         y = terms[0]

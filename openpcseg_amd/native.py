@@ -62,6 +62,9 @@ SIGNATURES = {
     "pcs_denselize_fwd_csr_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_denselize_bwd_csr_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_denselize_bwd_f32": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "pcs_range_sample_fwd_f32": (c_int32, [_P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "pcs_range_sample_corners": (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "pcs_range_sample_bwd_csr_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_bn_num_partials": (c_int32, []),
     "pcs_bn_stats_f32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P]),
     "pcs_bn_finalize_f32": (c_int32, [_P, c_double, _P, c_int32, c_double, c_double, _P, _P, _P, _P]),
@@ -877,6 +880,41 @@ class HipBackend:
         _check(self.lib.pcs_denselize_bwd_f32(_ptr(gout), _ptr(count_map), _ptr(pxpy), n, b, c, h, w, _ptr(gfeat),
                                               _stream()), "pcs_denselize_bwd_f32")
         return gfeat
+
+    # -- range image -> points (RPVNet's range_to_point) ------------------------------------------------------
+    def range_sample_fwd(self, img, pxpy):
+        """(n, C) bilinear samples of img (B, C, H, W) at pxpy (n, 3) = (frame, x, y) -- grid_sample(bilinear, zeros, align_corners=False)
+        for every frame in one launch (R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:31-51)."""
+        img = _dev(img, "feature_map", torch.float32)
+        pxpy = _dev(pxpy, "pxpy", torch.float32)
+        b, c, h, w = img.shape
+        n = pxpy.shape[0]
+        out = torch.empty((n, c), dtype=torch.float32, device=img.device)
+        _check(self.lib.pcs_range_sample_fwd_f32(_ptr(img), _ptr(pxpy), n, b, c, h, w, _ptr(out), _stream()), "pcs_range_sample_fwd_f32")
+        return out
+
+    def _corner_csr(self, pxpy, b, h, w):
+        """(order, rowptr, wts) of the 4 n (point, corner) entries over the B H W pixels; cached on pxpy per resolution."""
+        def make():
+            n = pxpy.shape[0]
+            keys = torch.empty(4 * n, dtype=torch.int64, device=pxpy.device)
+            wts = torch.empty(4 * n, dtype=torch.float32, device=pxpy.device)
+            _check(self.lib.pcs_range_sample_corners(_ptr(pxpy), n, b, h, w, _ptr(keys), _ptr(wts), _stream()), "pcs_range_sample_corners")
+            vals, order = torch.sort(keys, stable=True)   # stable: a pixel's entries stay in (point, corner) order -> fixed summation order
+            rowptr = torch.searchsorted(vals, torch.arange(b * h * w + 1, device=pxpy.device, dtype=torch.int64))
+            return order.contiguous(), rowptr.contiguous(), wts
+        return _cached(pxpy, "_pcs_corner_csr", _cache_key(pxpy) + (b, h, w), make)
+
+    def range_sample_bwd(self, gout, pxpy, b, h, w):
+        """d img (B, C, H, W) of range_sample_fwd: atomic-free, every element written once."""
+        gout = _dev(gout, "grad_output", torch.float32)
+        pxpy = _dev(pxpy, "pxpy", torch.float32)
+        c = gout.shape[1]
+        order, rowptr, wts = self._corner_csr(pxpy, b, h, w)
+        gimg = torch.empty((b, c, h, w), dtype=torch.float32, device=gout.device)
+        _check(self.lib.pcs_range_sample_bwd_csr_f32(_ptr(gout), _ptr(order), _ptr(rowptr), _ptr(wts), b, c, h, w, _ptr(gimg),
+                                                     _stream()), "pcs_range_sample_bwd_csr_f32")
+        return gimg
 
     # -- fused BatchNorm (+residual, +ReLU) -------------------------------------------------------
     @staticmethod

@@ -1,9 +1,12 @@
 """`range_utils.nn.functional.{map_count, denselize}` of the reference's range_lib
 (RL = R:pcseg/model/segmentor/fusion/rpvnet/range_lib/; RL:range_utils/nn/functional/map_count.py:7-28,
-denselize.py:7-34; called from R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:73-91), on the HIP backend."""
+denselize.py:7-34; called from R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:73-91), on the HIP backend -- and the opposite
+direction, `range_to_point` (rpvnet.py:31-51: grid_sample per frame), as one launch each way."""
 import sys
 import types
 
+import torch
+from torch.amp import custom_bwd, custom_fwd
 from torch.autograd import Function
 
 from . import native
@@ -32,6 +35,48 @@ class _Denselize(Function):
 def denselize(feat, count_map, pxpy):
     """scatter-mean of point features (N,C) into a (B,C,H,W) range image."""
     return _Denselize.apply(feat, count_map, pxpy)
+
+
+class _RangeToPoint(Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)   # grid_sampler is an fp32 op under autocast
+    def forward(ctx, feature_map, pxpy):
+        feature_map = feature_map.contiguous()
+        pxpy = pxpy.contiguous()
+        ctx.for_backwards = (pxpy, tuple(feature_map.shape))
+        return native.backend().range_sample_fwd(feature_map, pxpy)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_out):
+        pxpy, (b, c, h, w) = ctx.for_backwards
+        return native.backend().range_sample_bwd(grad_out.float().contiguous(), pxpy, b, h, w), None
+
+
+def _frames_in_order(pxpy, b):
+    """True when the frame column is non-decreasing integers in [0, b): the reference's per-frame loop then returns the rows in
+    input order. One host read per pxpy tensor (the reference's boolean-mask indexing reads once per frame and call)."""
+    def check():
+        f = pxpy[:, 0]
+        ok = (f >= 0) & (f < b) & (f == torch.floor(f))
+        return bool((ok.all() & (f[1:] >= f[:-1]).all()).item())
+    return native._cached(pxpy, "_pcs_frames_sorted", native._cache_key(pxpy) + (b,), check)
+
+
+def range_to_point(feature_map, pxpy, grid_sample_mode="bilinear", fallback=None):
+    """(N, C) features of the points: bilinear samples of the (B, C, H, W) range feature map at pxpy (N, 3) = (frame, x, y) --
+    R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:31-51 without the loop over frames. Inputs the kernels do not serve (another
+    sampling mode, channel counts that are not a multiple of 4, rows whose frames are not grouped in ascending order -- the
+    reference would REORDER those --, host tensors) go to `fallback` (the reference's own function) when one is given."""
+    ok = (grid_sample_mode == "bilinear" and feature_map.is_cuda and feature_map.dim() == 4 and feature_map.shape[1] % 4 == 0 and
+          pxpy.dim() == 2 and pxpy.shape[1] == 3 and pxpy.is_floating_point() and pxpy.shape[0] > 0 and
+          _frames_in_order(pxpy, feature_map.shape[0]))
+    if not ok:
+        if fallback is None:
+            raise RuntimeError("openpcseg_amd.rangelib.range_to_point: unsupported input (mode %r, feature map %s, pxpy %s)" %
+                               (grid_sample_mode, tuple(feature_map.shape), tuple(pxpy.shape)))
+        return fallback(feature_map, pxpy, grid_sample_mode)
+    return _RangeToPoint.apply(feature_map, pxpy)
 
 
 def install_as_range_utils():

@@ -161,21 +161,21 @@ class MinkUNet(nn.Module):
         x3 = self.stage3(x2)
         x4 = self.stage4(x3)
         if commute:
-            t1 = lin.devoxelized_part(0, x4.F, *point_maps(x4, z0))
+            t1 = lin.devoxelized_part(0, x4.F, *point_maps(x4, z0), cache=x4.kmaps)
         else:
             z1 = voxel_to_point(x4, z0)
         x4.F = self._dropout(x4.F, commute)
         y1 = self.up1[1](self.up1[0](x4, cat_with=x3))  # torchsparse.cat([up(x4), x3]) fused into the BN apply pass
         y2 = self.up2[1](self.up2[0](y1, cat_with=x2))
         if commute:
-            t2 = lin.devoxelized_part(x4.F.shape[1], y2.F, *point_maps(y2, z0))
+            t2 = lin.devoxelized_part(x4.F.shape[1], y2.F, *point_maps(y2, z0), cache=y2.kmaps)
         else:
             z2 = voxel_to_point(y2, z1)
         y2.F = self._dropout(y2.F, commute)
         y3 = self.up3[1](self.up3[0](y2, cat_with=x1))
         y4 = self.up4[1](self.up4[0](y3, cat_with=x0))
         if commute:
-            t3 = lin.devoxelized_part(x4.F.shape[1] + y2.F.shape[1], y4.F, *point_maps(y4, z0))
+            t3 = lin.devoxelized_part(x4.F.shape[1] + y2.F.shape[1], y4.F, *point_maps(y4, z0), cache=y4.kmaps)
             return lin.sum_devoxelized([t1, t2, t3])
         z3 = voxel_to_point(y4, z2)
         if isinstance(lin, FusedLinear) and os.environ.get("PCS_CLASSIFIER_PARTS", "1") != "0":

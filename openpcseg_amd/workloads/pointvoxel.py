@@ -52,6 +52,27 @@ def initial_voxelize(z, init_res, after_res):
     return x
 
 
+def point_to_voxel(x, z):
+    """Mean of the point features of z in the voxels of x (utils.py:41-64); the point -> voxel map is cached on z per stride."""
+    af = z.additional_features
+    if af is None or af.get("idx_query") is None or af["idx_query"].get(x.s) is None:
+        cell = torch.cat([torch.floor(z.C[:, :3] / x.s[0]).int() * x.s[0], z.C[:, -1].int().view(-1, 1)], 1)
+        pc_hash = F.sphash(cell)
+        be = native.backend()
+        if hasattr(be, "level_table") and x.C.is_cuda:
+            idx_query = be.table_query(be.level_table(x.C), pc_hash) - 1   # the level's cached table (shared with its kernel maps)
+        else:
+            idx_query = F.sphashquery(pc_hash, F.sphash(x.C))
+        counts = F.spcount(idx_query.int(), x.C.shape[0])
+        af["idx_query"][x.s] = idx_query
+        af["counts"][x.s] = counts
+    else:
+        idx_query, counts = af["idx_query"][x.s], af["counts"][x.s]
+    out = SparseTensor(F.spvoxelize(z.F, idx_query, counts), x.C, x.s)
+    out.cmaps, out.kmaps = x.cmaps, x.kmaps
+    return out
+
+
 def point_maps(x, z, nearest=False):
     """(idx_query (N, 8), weights (N, 8)) of the points of z in the voxels of x; cached on z per stride (utils.py:69-105)."""
     s = x.s

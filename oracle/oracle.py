@@ -285,6 +285,54 @@ def denselize_bwd(gout, count_map, pxpy):
 
 
 # ---- cylinder front-end ---------------------------------------------------------
+def _range_corners(pxpy, h, w):
+    """Corner pixels and bilinear weights of torch's grid_sampler_2d (mode='bilinear', padding_mode='zeros', align_corners=False;
+    ATen GridSampler.h: grid_sampler_unnormalize + the nw / ne / sw / se weights), float32 like there -- what
+    R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:31-51 (`resample_grid_stacked`) calls per frame."""
+    x, y = pxpy[:, 1].astype(np.float32), pxpy[:, 2].astype(np.float32)
+    ix = ((x + np.float32(1)) * np.float32(w) - np.float32(1)) / np.float32(2)
+    iy = ((y + np.float32(1)) * np.float32(h) - np.float32(1)) / np.float32(2)
+    x0, y0 = np.floor(ix), np.floor(iy)
+    x1, y1 = x0 + 1, y0 + 1
+    wts = np.stack([(x1 - ix) * (y1 - iy), (ix - x0) * (y1 - iy), (x1 - ix) * (iy - y0), (ix - x0) * (iy - y0)], 1).astype(np.float32)
+    cx = np.stack([x0, x1, x0, x1], 1).astype(np.int64)
+    cy = np.stack([y0, y0, y1, y1], 1).astype(np.int64)
+    ok = (cx >= 0) & (cx < w) & (cy >= 0) & (cy < h)
+    return cx, cy, wts, ok
+
+
+def range_sample_fwd(img, pxpy):
+    """out (N, C): rows of frame f = pxpy[:, 0] sample img[f] (B, C, H, W) bilinearly; frames outside [0, B) give zeros (the
+    reference's per-frame masks never select them). Accumulated corner by corner in float32 like the ATen kernel."""
+    b, c, h, w = img.shape
+    n = pxpy.shape[0]
+    cx, cy, wts, ok = _range_corners(pxpy, h, w)
+    f = pxpy[:, 0]
+    fi = f.astype(np.int64)
+    fok = (f >= 0) & (fi < b) & (fi == f)
+    out = np.zeros((n, c), dtype=np.float32)
+    fi = np.where(fok, fi, 0)
+    for k in range(4):
+        m = ok[:, k] & fok
+        v = img[fi[m], :, cy[m, k], cx[m, k]].astype(np.float32)
+        out[m] = out[m] + v * wts[m, k][:, None]
+    return out
+
+
+def range_sample_bwd(gout, pxpy, shape):
+    """d img of range_sample_fwd (float64 accumulation: the summation order of a scatter is the implementation's)."""
+    b, c, h, w = shape
+    cx, cy, wts, ok = _range_corners(pxpy, h, w)
+    f = pxpy[:, 0]
+    fi = f.astype(np.int64)
+    fok = (f >= 0) & (fi < b) & (fi == f)
+    gimg = np.zeros((b, h, w, c), dtype=np.float64)
+    for k in range(4):
+        m = ok[:, k] & fok
+        np.add.at(gimg, (fi[m], cy[m, k], cx[m, k]), gout[m].astype(np.float64) * wts[m, k][:, None].astype(np.float64))
+    return np.ascontiguousarray(gimg.transpose(0, 3, 1, 2)).astype(np.float32)
+
+
 def cylinder_partition(points, space_min, space_max, grid_size):
     """R:pcseg/data/dataset/semantickitti/semantickitti_cylinder.py:19-22 (cart2polar) + :144-159 ->
     (xyz_pol (n,3) f32 [rho, phi_deg, z], point_coord (n,3) int64, point_feature (n, 8 + extras) f32)."""

@@ -44,7 +44,7 @@ MODEL_CFG["config_mk34"] = dict(MODEL_CFG["config2"], NUM_LAYER=[2, 3, 4, 6, 2, 
 # training-trajectory fixture (make_golden.py trajectory): MinkUNet-18 cr0.5, the optimizer of the shipped yaml
 # (R:tools/cfgs/voxel/semantic_kitti/minkunet_mk34_cr10.yaml:25-33: SGD, momentum 0.9, weight decay 1e-4, clip 10) at a fixed lr
 MODEL_CFG["trajectory"] = dict(MODEL_CFG["config2"], cr=0.5)
-TRAJ = dict(seeds=[11, 12], n_points=20000, steps=10, lr=0.02, momentum=0.9, weight_decay=1e-4, clip=10.0)
+TRAJ = dict(seeds=[11, 12], n_points=20000, steps=10, lr=0.002, momentum=0.9, weight_decay=1e-4, clip=10.0)
 BATCH_SEEDS = {"config2x2": [0, 4]}
 MODEL_PATH = {"config2x2": ("pcseg.model.segmentor.voxel.minkunet.minkunet", "MinkUNet"),
               "config_mk34": ("pcseg.model.segmentor.voxel.minkunet.minkunet", "MinkUNet"),
@@ -157,8 +157,13 @@ def to_device(cfg_name, batch, dev, SparseTensor):
 
 
 # ---- running a reference segmentor ------------------------------------------------------------------------------------
-def logits_hook(cfg_name, model, cap):
-    """The tensor the 1e-3 bound of north_star is about: per-point (config 4: per-voxel) logits before the loss."""
+def logits_hook(cfg_name, model, cap, via="classifier"):
+    """The tensor the 1e-3 bound of north_star is about: per-point (config 4: per-voxel) logits before the loss.
+    via="criterion": taken as the first argument of the criterion instead of the classifier's output -- the same tensor in the
+    reference's forward (`out = self.classifier(..); loss = self.criterion_losses(out, ..)`), and the one that exists when the
+    fused forward forms the class scores on the voxels (openpcseg_amd/block_fusion.py)."""
+    if via == "criterion" and cfg_name != "config4":
+        return model.criterion_losses.register_forward_pre_hook(lambda m, args: cap.__setitem__("logits", args[0].detach()))
     if cfg_name == "config4":
         return model.logits.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", o.F.detach()))
     return model.classifier.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", o.detach()))
@@ -174,10 +179,10 @@ def freeze_dropout(model):
     return model
 
 
-def run_train_step(cfg_name, model, batch):
+def run_train_step(cfg_name, model, batch, via="classifier"):
     """forward (train mode, batch statistics) + loss + backward; returns (logits ndarray, loss float)."""
     cap = {}
-    h = logits_hook(cfg_name, model, cap)
+    h = logits_hook(cfg_name, model, cap, via)
     try:
         ret = model(batch)
     finally:

@@ -472,6 +472,42 @@ def lovasz_cases():
     return out
 
 
+def range_sample_inputs():
+    """Two cases for `range_to_point`: (B, C, H, W) feature maps + per-point (frame, x, y) rows grouped by frame, x / y mostly inside
+    [-1, 1] with some outside (zero padding), some exactly on pixel centres and on the image border."""
+    cases = {}
+    for name, (seed, b, c, h, w, n) in {"a": (21, 2, 8, 16, 64, 3000), "b": (22, 3, 20, 8, 32, 2500)}.items():
+        rng = np.random.default_rng(seed)
+        img = rng.normal(size=(b, c, h, w)).astype(np.float32)
+        frames = np.sort(rng.integers(0, b, size=n)).astype(np.float32)
+        xy = rng.uniform(-1.08, 1.08, size=(n, 2)).astype(np.float32)
+        xy[:50] = np.float32(-1) + (np.float32(2) * rng.integers(0, w, size=(50, 1)).astype(np.float32) + 1) / np.float32(w) * np.array([[1, 0]], np.float32) \
+            + xy[:50] * np.array([[0, 1]], np.float32)                      # x exactly on pixel centres
+        xy[50:60] = np.array([[-1.0, -1.0], [1.0, 1.0], [-1.0, 1.0], [1.0, -1.0], [0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [-1.0, 0.0],
+                              [0.0, -1.0], [0.999999, -0.999999]], np.float32)
+        cases[name] = (img, np.concatenate([frames[:, None], xy], 1).astype(np.float32), rng.normal(size=(n, c)).astype(np.float32))
+    return cases
+
+
+def main_range_sample():
+    """`range_to_point(feature_map, pxpy)` of the reference (R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:31-51: grid_sample per
+    frame) run on CPU, forward and the gradient w.r.t. the feature map for a fixed output gradient."""
+    import_reference_torchsparse()
+    install_scatter_stub()
+    install_range_stub()
+    mod = import_reference_model("pcseg.model.segmentor.fusion.rpvnet.rpvnet")
+    g = {}
+    for name, (img, pxpy, gout) in range_sample_inputs().items():
+        ti = torch.from_numpy(img).requires_grad_(True)
+        out = mod.range_to_point(ti, torch.from_numpy(pxpy), "bilinear")
+        assert tuple(out.shape) == gout.shape
+        out.backward(torch.from_numpy(gout))
+        g[name + "_img"], g[name + "_pxpy"], g[name + "_gout"] = img, pxpy, gout
+        g[name + "_out"], g[name + "_gimg"] = out.detach().numpy().copy(), ti.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "range_sample_golden.npz"), **g)
+    print("wrote range_sample_golden.npz:", {k: v.shape for k, v in g.items() if k.endswith("_out")})
+
+
 def main_lovasz():
     """lovasz_softmax(probas, labels, ignore) of the reference (tools/utils/common/lovasz_losses.py, imported by path) on
     CPU float32, value and gradient w.r.t. probas."""
@@ -561,7 +597,11 @@ def main_trajectory():
     iterations in the order of R:train.py:355-371 -- zero_grad, forward, loss.backward, clip_grad_norm_, optimizer.step -- with the
     shipped optimizer (SGD momentum 0.9, weight decay 1e-4, clip 10; minkunet_mk34_cr10.yaml:25-33) at a fixed learning rate, on
     the reference's torchsparse + compiled CPU backend. Keeps the loss of every step and a fingerprint (float64 sum / abs-sum /
-    abs-max + eight samples) of every parameter and BatchNorm buffer after the last step."""
+    abs-max + eight samples) of every parameter and BatchNorm buffer after the last step.
+    The run is made TWICE: the second one (the "twin") sees the input features multiplied by (1 + 1e-7 N(0, 1)) -- a perturbation of
+    the size of one float32 rounding. How far the twin drifts from the first run is how reproducible the reference's OWN trajectory
+    is under rounding-level differences (the loss has kinks: ReLU gates, the Lovasz sort order), i.e. the floor for any other
+    arithmetic (MFMA summation order) -- the test bounds follow it where it exceeds the nominal 1e-4 / 1e-3."""
     import time
     import fullsize as fs
     from torch.nn.utils import clip_grad_norm_
@@ -570,40 +610,48 @@ def main_trajectory():
     T = fs.TRAJ
     dotted, cls = fs.MODEL_PATH["trajectory"]
     mod = import_reference_model(dotted)
-    torch.manual_seed(0)
     torch.set_num_threads(8)
-    model = getattr(mod, cls)(_AttrDict(fs.MODEL_CFG["trajectory"]), 20)
-    seeded_state(model)
-    model.train()
     b = make_batch(T["seeds"], n_points=T["n_points"])
     feats, coords, labels = b["lidar"].feats, b["lidar"].coords, b["targets"].feats
     g = {"crc_feats": np.array(fs.crc(feats.numpy())), "crc_coords": np.array(fs.crc(coords.numpy())),
          "crc_labels": np.array(fs.crc(labels.numpy()))}
-    opt = torch.optim.SGD(model.parameters(), lr=T["lr"], momentum=T["momentum"], weight_decay=T["weight_decay"])
-    orig = torch.Tensor.cuda
-    torch.Tensor.cuda = lambda self, *a, **k: self
-    losses, norms = [], []
-    t0 = time.time()
-    try:
+
+    def run(f, tag):
+        torch.manual_seed(0)
+        model = getattr(mod, cls)(_AttrDict(fs.MODEL_CFG["trajectory"]), 20)
+        seeded_state(model)
+        model.train()
+        opt = torch.optim.SGD(model.parameters(), lr=T["lr"], momentum=T["momentum"], weight_decay=T["weight_decay"])
+        losses, norms = [], []
+        t0 = time.time()
         for it in range(T["steps"]):
             model.train()
             opt.zero_grad()
-            batch = {"lidar": ts.SparseTensor(feats.clone(), coords), "targets": ts.SparseTensor(labels, coords), "offset": None}
+            batch = {"lidar": ts.SparseTensor(f.clone(), coords), "targets": ts.SparseTensor(labels, coords), "offset": None}
             ret = model(batch)
             loss = ret[0]["loss"].mean()
             loss.backward()
             norms.append(float(clip_grad_norm_(model.parameters(), T["clip"])))
             opt.step()
             losses.append(float(loss.detach()))
-            print("step %d loss %.6f grad norm %.4f (%.0f s)" % (it, losses[-1], norms[-1], time.time() - t0), flush=True)
+            print("%s step %d loss %.6f grad norm %.4f (%.0f s)" % (tag, it, losses[-1], norms[-1], time.time() - t0), flush=True)
+        state = [(n, t) for n, t in model.state_dict().items() if t.dtype.is_floating_point]
+        return np.array(losses, dtype=np.float64), np.array(norms, dtype=np.float64), fs.grad_fingerprint(state)
+
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        losses, norms, fp = run(feats, "main")
+        noise = torch.randn(feats.shape, generator=torch.Generator().manual_seed(7))
+        t_losses, t_norms, t_fp = run(feats * (1.0 + 1e-7 * noise), "twin")
     finally:
         torch.Tensor.cuda = orig
-    g["losses"], g["grad_norms"] = np.array(losses, dtype=np.float64), np.array(norms, dtype=np.float64)
-    state = [(n, t) for n, t in model.state_dict().items() if t.dtype.is_floating_point]
-    fp = fs.grad_fingerprint(state)
+    g["losses"], g["grad_norms"] = losses, norms
     g["state_names"], g["state_stats"], g["state_samples"] = fp["grad_names"], fp["grad_stats"], fp["grad_samples"]
+    g["twin_losses"], g["twin_grad_norms"] = t_losses, t_norms
+    g["twin_state_stats"], g["twin_state_samples"] = t_fp["grad_stats"], t_fp["grad_samples"]
     np.savez_compressed(os.path.join(OUT, "trajectory_golden.npz"), **g)
-    print("wrote trajectory_golden.npz: losses", losses)
+    print("wrote trajectory_golden.npz: losses", losses.tolist(), "\ntwin drift", np.abs(t_losses / losses - 1).tolist())
 
 
 def main_cylinder():
@@ -650,6 +698,8 @@ if __name__ == "__main__":
         main_full(sys.argv[1])
     elif len(sys.argv) > 1 and sys.argv[1] == "trajectory":
         main_trajectory()
+    elif len(sys.argv) > 1 and sys.argv[1] == "range_sample":
+        main_range_sample()
     elif len(sys.argv) > 1 and sys.argv[1] == "models":
         main_models()
     elif len(sys.argv) > 1 and sys.argv[1] == "quantize":

@@ -53,8 +53,8 @@ BOUNDS = {
     "config5/reference": (8e-4, 2e-5, 2e-4, 6e-4, 5e-4, 4e-3),       # 4.1e-4   7.8e-5 / 2.9e-4   2.3e-4 / 1.8e-3
     # [r5] the graph the headline metric is quoted on: MinkUNet-34 cr1.0 (NUM_LAYER [2,3,4,6,2,2,2,2]), one full frame (seed 6),
     # logit scale 318 (3x config 2's)
-    "config_mk34/reference": (1.5e-3, 3e-5, 1e-3, 4e-3, 8e-3, 2e-2),
-    "config_mk34/workload": (1.5e-3, 3e-5, 1e-3, 4e-3, 8e-3, 2e-2),
+    "config_mk34/reference": (8e-4, 1e-5, 2e-4, 3.6e-3, 2e-3, 5e-3),      # 3.9e-4   7.3e-5 / 1.8e-3   9.0e-4 / 2.6e-3 (+fuse: 4.1e-4, 9.0e-5 / 1.8e-3, 8.7e-4 / 2.5e-3)
+    "config_mk34/workload": (8e-4, 1e-5, 2e-4, 3.6e-3, 2e-3, 5e-3),
 }
 # the same reference sources after openpcseg_amd.fuse(model) (block fusion, openpcseg_amd/block_fusion.py): the bounds of the plain route
 for _k in ("config2", "config3", "config5", "config2x2", "config_mk34"):
@@ -138,8 +138,14 @@ def _reference_step_on_hip(cfg, fuse):
     model = fs.freeze_dropout(_reference_model(cfg).to(dev).train())
     if fuse:
         counts = openpcseg_amd.fuse(model)
-        assert counts["residual"] >= 16 and counts["criterion"] == 2, counts
-    logits, loss = fs.run_train_step(cfg, model, batch)
+        assert counts["residual"] >= 16 and counts["criterion"] == 2 and counts["glue"] >= 2, counts
+        assert counts["forward"] == (1 if "MinkUNet" in fs.MODEL_PATH[cfg][1] else 0), counts
+    try:
+        logits, loss = fs.run_train_step(cfg, model, batch, via="criterion" if fuse else "classifier")
+    finally:
+        if fuse:
+            from openpcseg_amd.block_fusion import restore_glue
+            restore_glue()
     m = fs.compare(g, logits, loss, fs.model_grads(model))
     m["loss_ref"] = float(g["loss"])
     name = cfg + ("/reference+fuse" if fuse else "/reference")
@@ -222,7 +228,8 @@ def test_fullsize_workload_minkunet34_on_hip(hip):
 # arg-max agreement with the fp32 reference 98.6 % / 99.7 % of the points
 AMP_BOUNDS = {torch.bfloat16: (0.30, 0.02, 0.12, 0.975), torch.float16: (0.05, 0.0025, 0.04, 0.99)}  # max / rms, mean / rms, grad, arg-max
 # [r5] MinkUNet-34 (the headline graph, 15 more residual blocks than config 2)
-AMP_BOUNDS_MK34 = {torch.bfloat16: (0.45, 0.03, 0.18, 0.97), torch.float16: (0.08, 0.004, 0.06, 0.985)}
+#   measured [r5] (bf16 / fp16): max 0.278 / 0.029 of the RMS, mean 0.0060 / 0.00073, worst gradient abs-sum 16.2 % / 8.9 %, arg-max 98.4 / 99.8 %
+AMP_BOUNDS_MK34 = {torch.bfloat16: (0.45, 0.012, 0.25, 0.97), torch.float16: (0.05, 0.0015, 0.14, 0.99)}
 
 
 @pytest.mark.gpu

