@@ -524,6 +524,10 @@ def main():
                     help="secondary `models` record: comma list of {minkunet18,spvcnn18,cylinder,rpvnet34,minkunet34}[:reference|workload], "
                          "'auto' (N = 1 default run: the reference's four segmentor sources unmodified on the HIP backend + the fused "
                          "MinkUNet-18 workload) or 'none'")
+    ap.add_argument("--device-input", action="store_true",
+                    help="the `device_input` record for THIS run's dtype: every timed step starts from the raw (120000, 4) scans in HBM "
+                         "(round / shift / sparse_quantize / collate of all frames on the device); the default fp32 run carries the bf16 one")
+    ap.add_argument("--no-device-input-line", action="store_true", help="skip the secondary `device_input` record")
     ap.add_argument("--verbose-json", action="store_true", help="print the long records (notes, clocks) instead of the compact line")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -571,8 +575,16 @@ def main():
     be = native.backend()
     from openpcseg_amd import functional as pcsF
 
-    def measure(amp, conv="fp32", wgrad="fp32"):
-        """One bench line: fresh model / optimizer (same seed), preheat, W warm-up steps, K timed steps."""
+    raw_dev = None
+
+    def measure(amp, conv="fp32", wgrad="fp32", device_input=False):
+        """One bench line: fresh model / optimizer (same seed), preheat, W warm-up steps, K timed steps.
+        device_input: every step starts from the RAW scans in HBM (dataset transform + voxel dedup + collate on the device,
+        workloads/synthetic.py::device_collate) instead of the pre-voxelised batch."""
+        nonlocal raw_dev
+        if device_input and raw_dev is None:
+            from openpcseg_amd.workloads.synthetic import make_raw_batch
+            raw_dev = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in make_raw_batch(seeds).items()}
         pcsF.set_conv_policy(conv)
         pcsF.set_wgrad_policy(wgrad)
         torch.manual_seed(0)
@@ -585,14 +597,20 @@ def main():
         amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(amp)
         scaler = torch.amp.GradScaler("cuda") if amp == "fp16" else None  # the reference scales fp16 losses (train.py)
 
+        def inputs():
+            if device_input:
+                from openpcseg_amd.workloads.synthetic import device_collate
+                return device_collate(raw_dev)
+            return fresh(batch)
+
         def step():
             opt.zero_grad(set_to_none=True)
             if amp is None:
-                out = model(fresh(batch))
+                out = model(inputs())
                 out["loss"].backward()
             else:
                 with torch.autocast("cuda", dtype=amp_dtype):
-                    out = model(fresh(batch))
+                    out = model(inputs())
                 if scaler is not None:
                     scaler.scale(out["loss"]).backward()
                     scaler.unscale_(opt)
@@ -655,6 +673,15 @@ def main():
     # third record: the fp32 step with BOTH fp32-grade split policies (forward / input-gradient convolutions and the weight gradient
     # of the wide layers with fp32 operands as three bf16 planes on the 16-bit MFMAs); opt-in arithmetic, never the headline value
     third = measure(None, conv="bf16x3", wgrad="bf16x3") if amp is None and not args.no_split_line else None
+    # SURVEY section 8 f1 with its number: the same step (bf16: the fastest step, where input work shows most) starting from the RAW
+    # scans resident in HBM -- dataset transform + voxel dedup + collate of the 12 frames on the device inside every timed step
+    dev_in = None
+    if args.device_input or (amp is None and world == 1 and not args.no_amp_line and not args.no_device_input_line):
+        d_amp = amp if args.device_input else "bf16"
+        base = head if d_amp == amp else second
+        di = measure(d_amp, device_input=True)
+        dev_in = {"dtype": d_amp or "f32", "value": di["value"], "ms_per_step": di["ms_per_step"],
+                  "input_ms_per_step": round(di["ms_per_step"] - base["ms_per_step"], 2), "loss": di["loss"]}
     models = None
     if world == 1 and args.models != "none" and (args.models != "auto" or amp is None):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -699,10 +726,22 @@ def main():
                                   "conv_tflops": r3.get("achieved"), "conv_frac_of_bf16_peak_over_6": r3.get("frac")}
             if args.verbose_json:
                 res["fp32_bf16x3"]["roofline"] = third["roofline"]
+        if dev_in is not None:
+            res["device_input"] = dev_in
         if models is not None:
             if not args.verbose_json and "error" not in models:
-                # [fp32, bf16] frames/s of one training step per model (ms per step and batch sizes: --verbose-json, bench_notes.json)
-                models = dict({"fmt": "[fp32,bf16] frames/s"}, **{k: [v.get("f32"), v.get("bf16")] for k, v in models.items()})
+                # frames/s of one training step per model (ms per step and batch sizes: --verbose-json, bench_notes.json)
+                short = {"fmt": "frames/s [ref f32,ref bf16,ref+fuse f32,ref+fuse bf16]; ref = the reference's source, +fuse = openpcseg_amd.fuse(model)"}
+                r1 = lambda v: None if v is None else round(v, 1)
+                for k, v in models.items():
+                    name, src = k.split("/")
+                    if src == "fused":
+                        short[k] = [r1(v.get("f32")), r1(v.get("bf16"))]
+                        continue
+                    row = short.setdefault(name, [None] * 4)
+                    o = 0 if src == "ref" else 2
+                    row[o], row[o + 1] = r1(v.get("f32")), r1(v.get("bf16"))
+                models = short
             res["models"] = models
         if world == 1 and not args.no_cpu_baseline and amp is None:
             res["cpu_baseline"] = cpu_baseline(compact=not args.verbose_json)

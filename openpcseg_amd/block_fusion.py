@@ -43,6 +43,12 @@ interchangeable both ways; `unfuse(model)` restores the original forwards):
     gradient x^T dy -- a (C_in, C_out) result contracted over ~2 M points, which hipBLASLt runs on a handful of workgroups (8.6 ms
     per SPVCNN step) -- on the split-reduction wgrad kernel, BatchNorm + ReLU as the fused passes.
 
+  * [dense layers] in a model that contains sparse convolutions, every remaining stock `nn.BatchNorm1d` / `nn.SyncBatchNorm` and
+    `nn.Linear` keeps its class name, parameters and state_dict keys but runs (N, C) device inputs of >= 4096 rows through the same
+    fused BatchNorm passes / the split-reduction weight gradient (Cylinder_TS normalises voxel features with plain BatchNorm1d after
+    every convolution, R:pcseg/model/segmentor/voxel/cylinder3d/cylinder_ts.py:103-124: torch's channels-last BatchNorm kernels are
+    30 of its 170 ms step); any other input takes the stock forward. Every plain `nn.CrossEntropyLoss` child -> the masked mean.
+
 Anything the pass does not recognise keeps its own forward; a module with forward hooks on a BatchNorm / ReLU that would be
 skipped is left alone. `install_as_torchsparse(fuse=True)` applies the pass automatically the first time a model is called.
 """
@@ -232,23 +238,46 @@ class _PointLinear(torch.autograd.Function):
 
 def _dense_step(lin, bn, act, x):
     """Linear -> BatchNorm -> [ReLU] on a plain (N, C) tensor through the fused passes; the modules themselves where they do not apply."""
-    ok = (x.dim() == 2 and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and x.shape[0] >= 4096 and
-          lin.in_features % 4 == 0 and lin.out_features % 4 == 0 and hasattr(native.backend(), "bn_apply") and
-          _quiet(lin) and _quiet(bn) and (act is None or _quiet(act)))
-    if not ok:
+    if not (_rows_ok(x) and _quiet(lin) and _quiet(bn) and (act is None or _quiet(act))):
         h = bn(lin(x))
         return act(h) if act is not None else h
-    h = _PointLinear.apply(x, lin.weight, lin.bias)
+    if lin.in_features % 4 == 0 and lin.out_features % 4 == 0:
+        h = _PointLinear.apply(x, lin.weight, lin.bias)
+    else:
+        h = lin(x)
+    return _dense_bn_apply(bn, h, act is not None)
+
+
+def _dense_bn_apply(bn, h, relu):
     if bn.training:
         if bn.__dict__.get("_pcs_bumped", False):
             bn.__dict__["_pcs_bumped"] = False
         else:
             bn.num_batches_tracked.add_(1)
-        return _FusedBN.apply(h, None, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act is not None,
+        return _FusedBN.apply(h, None, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu,
                               isinstance(bn, nn.SyncBatchNorm), None, None, None, None)
     inv = torch.rsqrt(bn.running_var.double() + bn.eps)
     stat = torch.cat([bn.running_mean.double(), inv]).contiguous()
-    return native.backend().bn_apply(h.contiguous(), None, stat, bn.weight, bn.bias, act is not None)
+    return native.backend().bn_apply(h.contiguous(), None, stat, bn.weight, bn.bias, relu)
+
+
+def _rows_ok(x):
+    return (isinstance(x, torch.Tensor) and x.dim() == 2 and x.is_cuda and x.shape[0] >= 4096 and
+            x.dtype in (torch.float32, torch.bfloat16, torch.float16) and hasattr(native.backend(), "bn_apply"))
+
+
+def _dense_bn_forward(self, x):
+    """forward of a stock nn.BatchNorm1d / nn.SyncBatchNorm re-classed by fuse(): (N, C) device rows through the fused passes."""
+    if not (_rows_ok(x) and _quiet(self)):
+        return self.__dict__["_pcs_orig_class"].forward(self, x)
+    return _dense_bn_apply(self, x, False)
+
+
+def _dense_linear_forward(self, x):
+    """forward of a stock nn.Linear re-classed by fuse(): tall (N, C_in) device inputs get the split-reduction weight gradient."""
+    if not (_rows_ok(x) and _quiet(self) and self.in_features % 4 == 0 and self.out_features % 4 == 0):
+        return self.__dict__["_pcs_orig_class"].forward(self, x)
+    return _PointLinear.apply(x, self.weight, self.bias)
 
 
 def _run_plan(seq, plan, x, residual=None, final_relu=False):
@@ -549,10 +578,10 @@ def _adopt(plan, bns):
 
 def fuse(model, criterion=True, glue=True, forward=True):
     """Swap the forwards of the blocks this pass recognises (see the module docstring). Idempotent. Returns a dict of counts:
-    {"sequential": .., "residual": .., "conv_bn": .., "criterion": .., "glue": .., "forward": ..}."""
+    {"sequential": .., "residual": .., "conv_bn": .., "criterion": .., "glue": .., "forward": .., "dense": ..}."""
     if model.__dict__.get("_pcs_fused") is not None:
         return dict(model.__dict__["_pcs_fused"]["counts"])
-    counts = {"sequential": 0, "residual": 0, "conv_bn": 0, "criterion": 0, "glue": 0, "forward": 0}
+    counts = {"sequential": 0, "residual": 0, "conv_bn": 0, "criterion": 0, "glue": 0, "forward": 0, "dense": 0}
     undo, bns, owned = [], [], set()
     mods = list(model.modules())
     for m in mods:
@@ -580,6 +609,31 @@ def fuse(model, criterion=True, glue=True, forward=True):
                 counts["conv_bn"] += _adopt(plan, bns)
         elif criterion and not isinstance(m, nn.Sequential):
             counts["criterion"] += _fuse_criterion(m, undo)
+    if bns:
+        # stock BatchNorm1d / SyncBatchNorm / Linear modules outside every recognised plan (Cylinder_TS's per-convolution BatchNorm1d on
+        # `.F`, the first / last layers of its point MLP, classifiers) and plain CrossEntropyLoss children
+        planned = set()
+        for m in mods:
+            pl = m.__dict__.get("_pcs_plan")
+            for p_ in (pl if isinstance(pl, tuple) else (pl,)):
+                if isinstance(p_, _Plan):
+                    planned.update(id(x) for st in p_.steps for x in st[1:] if isinstance(x, nn.Module))
+        for m in mods:
+            if id(m) in planned or getattr(type(m), "_pcs_fused_class", False):
+                continue
+            if _dense_bn(m) and type(m) in (nn.BatchNorm1d, nn.SyncBatchNorm):
+                _reclass(m, _dense_bn_forward, None, undo)
+                bns.append(m)
+                counts["dense"] += 1
+            elif type(m) is nn.Linear:
+                _reclass(m, _dense_linear_forward, None, undo)
+                counts["dense"] += 1
+            elif criterion:
+                for name, child in list(m._modules.items()):
+                    if type(child) is nn.CrossEntropyLoss and child.weight is None and child.reduction == "mean" and _quiet(child):
+                        m._modules[name] = _MaskedCE(child)
+                        undo.append(("submodule", m, name, child))
+                        counts["criterion"] += 1
     if bns and glue:
         counts["glue"] = _fuse_glue(model)
     if bns and forward:

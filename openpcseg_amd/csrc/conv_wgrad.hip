@@ -508,13 +508,17 @@ __device__ __forceinline__ void w3_split(float x, float y, uint32_t &hi, uint32_
   hi = __builtin_bit_cast(uint32_t, h); mid = __builtin_bit_cast(uint32_t, m); lo = __builtin_bit_cast(uint32_t, l);
 }
 
-template <typename ET, int NA, int NB>
-__global__ void __launch_bounds__(256, W3Mode<ET>::PLANES == 1 ? 3 : 2) wgrad3_kernel(Wgrad3Args w) {
+// NT / ROW [r5]: the THIN instance (NT = 64, ROW = 64) -- layers whose whole gradient block is one 64 x 64 tile (32 -> 32, 64 -> 64:
+// ten launches per MinkUNet-34 step, 2.5 ms on wgrad2's fp32 MFMAs under autocast) -- is the same kernel as ONE-wave workgroups with
+// a 64-half staged row: each wave stages and contracts its own split (no idle waves: of the 4-wave form's 2 x 2 blocks three would
+// not exist), 16 KB of LDS per workgroup, four times as many (shorter) splits to keep the CUs full.
+template <typename ET, int NA, int NB, int NT = 256, int ROW = W3_ROW>
+__global__ void __launch_bounds__(NT, NT == 256 ? (W3Mode<ET>::PLANES == 1 ? 3 : 2) : 4) wgrad3_kernel(Wgrad3Args w) {
   constexpr int PL = W3Mode<ET>::PLANES;
   using MT = typename W3Mode<ET>::MT;
   constexpr bool F32IN = std::is_same<ET, Fp32>::value;
   constexpr int NBUF = PL == 1 ? 2 : 1;  // halfs: two images (16 KB each), one barrier per batch; fp32: one 48 KB image
-  constexpr int IMG = PL * 2 * W3_PB * W3_ROW;  // halfs per image: [plane][A | B][pair][128]
+  constexpr int IMG = PL * 2 * W3_PB * ROW;  // halfs per image: [plane][A | B][pair][ROW]
   __shared__ __attribute__((aligned(16))) uint16_t lds[NBUF * IMG];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
@@ -540,21 +544,22 @@ __global__ void __launch_bounds__(256, W3Mode<ET>::PLANES == 1 ? 3 : 2) wgrad3_k
   // therefore moves the same 16-byte channel piece of BOTH rows of a pair couple: halfs are zipped with v_perm_b32, fp32
   // values are converted two at a time (v_cvt_pk_bf16_f32 packs (pair 2q, pair 2q + 1) into exactly that word).
   constexpr int CPP = F32IN ? 4 : 8;                 // channels per 16-byte piece
-  constexpr int PPR = W3_ROW / CPP;                  // pieces per staged row: 32 / 16
-  constexpr int PIECES = (W3_PB / 2) * PPR / 256;    // (couple, piece) items per thread and operand: 2 / 1
+  constexpr int PPR = ROW / CPP;                     // pieces per staged row: 32 / 16
+  constexpr int PIECES = (W3_PB / 2) * PPR / NT;     // (couple, piece) items per thread and operand: 2 / 1
+  static_assert(PIECES >= 1 && (W3_PB / 2) * PPR % NT == 0, "staging items must divide over the threads");
   uint32_t *ldw = reinterpret_cast<uint32_t *>(lds);
   constexpr int IMGW = IMG / 2;                      // words per image
-  constexpr int OPW = (W3_PB / 2) * W3_ROW;          // words per (plane, operand): 16 couples x 128 channels
+  constexpr int OPW = (W3_PB / 2) * ROW;             // words per (plane, operand): 16 couples x ROW channels
   // word position of channel ch of couple q: 16-channel chunk c sits at chunk c ^ ((q >> 2) & 3), so the four lane groups
   // of a fragment read (couples 4 g + j) hit four distinct 16-bank ranges
-  auto wpos = [](int q, int ch) { return q * W3_ROW + ((((ch >> 4) ^ (q >> 2)) & 7) << 4) + (ch & 15); };
+  auto wpos = [](int q, int ch) { return q * ROW + ((((ch >> 4) ^ (q >> 2)) & (ROW / 16 - 1)) << 4) + (ch & 15); };
   // the dependent chain pair -> row address -> row is cut in two: the pair indices run one batch ahead of the rows
   int2 prs[PIECES][2];
   uint4 ra[PIECES][2], rb[PIECES][2];
   auto fetch_pairs = [&](int p0) {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-      const int q = (tid + 256 * i) / PPR;
+      const int q = (tid + NT * i) / PPR;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         prs[i][h] = make_int2(-1, -1);
@@ -565,7 +570,7 @@ __global__ void __launch_bounds__(256, W3Mode<ET>::PLANES == 1 ? 3 : 2) wgrad3_k
   auto fetch_rows = [&]() {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-      const int c = ((tid + 256 * i) % PPR) * CPP;
+      const int c = ((tid + NT * i) % PPR) * CPP;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const bool pv = prs[i][h].x >= 0;
@@ -586,7 +591,7 @@ __global__ void __launch_bounds__(256, W3Mode<ET>::PLANES == 1 ? 3 : 2) wgrad3_k
   auto stage = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-      const int e = tid + 256 * i, q = e / PPR, c = (e % PPR) * CPP;
+      const int e = tid + NT * i, q = e / PPR, c = (e % PPR) * CPP;
       const int pos = wpos(q, c);
 #pragma unroll
       for (int op = 0; op < 2; ++op) {
@@ -617,7 +622,7 @@ __global__ void __launch_bounds__(256, W3Mode<ET>::PLANES == 1 ? 3 : 2) wgrad3_k
   auto frag = [&](int buf, int plane, int op, int ch) {
     const uint32_t *q = ldw + buf * IMGW + (plane * 2 + op) * OPW + wpos(4 * g, ch);
     uint4 f;
-    f.x = q[0 * W3_ROW]; f.y = q[1 * W3_ROW]; f.z = q[2 * W3_ROW]; f.w = q[3 * W3_ROW];
+    f.x = q[0 * ROW]; f.y = q[1 * ROW]; f.z = q[2 * ROW]; f.w = q[3 * ROW];
     return f;
   };
   auto compute = [&](int buf) {
@@ -706,7 +711,25 @@ int launch_wgrad3(const Wgrad3Args &w, int ns, hipStream_t st) {
   return PCS_EINVAL;
 }
 
-int wgrad_plan(const int32_t *koff_host, int K, int ca, int cb, int *pch_out) {
+// thin half-operand shapes: the whole gradient block is one <= 64 x 64 tile -> one-wave workgroups (wgrad3_kernel<.., 64, 64>)
+inline bool wgrad3_thin(int ca, int cb, int dtype) {
+  static const int on = getenv("PCS_WGRAD3_THIN") ? atoi(getenv("PCS_WGRAD3_THIN")) : 1;  // 0: wgrad2 as before (A/B)
+  return on && dtype != 0 && ca % 16 == 0 && cb % 16 == 0 && ca <= 64 && cb <= 64 && ca >= 32 && cb >= 32;
+}
+
+template <typename ET>
+int launch_wgrad3_thin(const Wgrad3Args &w, int ns, hipStream_t st) {
+  const dim3 grid((unsigned)ns, 1);
+  const int na = w.aw / 16, nb = w.bw / 16;
+#define PCS_W3T_CASE(A, B) if (na == A && nb == B) { hipLaunchKernelGGL((wgrad3_kernel<ET, A, B, 64, 64>), grid, dim3(64), 0, st, w); return check_launch("pcs_conv_wgrad(wgrad3 thin)"); }
+  PCS_W3T_CASE(4, 4) PCS_W3T_CASE(4, 3) PCS_W3T_CASE(4, 2) PCS_W3T_CASE(3, 4) PCS_W3T_CASE(3, 3) PCS_W3T_CASE(3, 2)
+  PCS_W3T_CASE(2, 4) PCS_W3T_CASE(2, 3) PCS_W3T_CASE(2, 2)
+#undef PCS_W3T_CASE
+  set_error("pcs_conv_wgrad(wgrad3 thin): unreachable");
+  return PCS_EINVAL;
+}
+
+int wgrad_plan(const int32_t *koff_host, int K, int ca, int cb, int *pch_out, bool thin = false) {
   // workgroup = 4 output blocks of one split; >= 64 pairs per split
   const int nbq = (wg_ngroups(ca) * wg_ngroups(cb) + 3) / 4;
   int64_t P = koff_host[K] - koff_host[0];
@@ -714,6 +737,7 @@ int wgrad_plan(const int32_t *koff_host, int K, int ca, int cb, int *pch_out) {
   // (256-channel layers), ~1536 otherwise (64..128 channels: +2..16 %; fewer, longer splits = less partial traffic)
   static const int tgt_env = getenv("PCS_WGRAD_TARGET") ? atoi(getenv("PCS_WGRAD_TARGET")) : 0;  // debug: workgroups per launch
   int64_t target = (tgt_env > 0 ? tgt_env : (nbq >= 4 ? 3072 : 1536)) / nbq;
+  if (thin) target *= 4;   // one-wave workgroups: as many waves in flight as the four-wave form
   if (target < K) target = K;
   int pch = (int)ceil_div(P > 0 ? P : 1, target);
   pch = (int)(ceil_div(pch, 32) * 32);
@@ -730,7 +754,11 @@ extern "C" size_t pcs_conv_wgrad_ws_bytes(const int32_t *koff_host, int32_t K, i
                                           int32_t cb) {
   if (!koff_host || K <= 0 || ca <= 0 || cb <= 0) return 0;
   int pch;
-  const int ns = wgrad_plan(koff_host, K, ca, cb, &pch);
+  int ns = wgrad_plan(koff_host, K, ca, cb, &pch);
+  if (wgrad3_thin(ca, cb, 1)) {   // the query does not know the operand type: room for the thin plan's (more, shorter) splits too
+    const int ns_thin = wgrad_plan(koff_host, K, ca, cb, &pch, true);
+    ns = ns_thin > ns ? ns_thin : ns;
+  }
   return (size_t)(ns > 0 ? ns : 1) * ca * cb * sizeof(float);
 }
 
@@ -746,7 +774,9 @@ static int conv_wgrad_any(const void *fa_v, int32_t ca, const void *fb_v, int32_
   }
   hipStream_t st = as_stream(stream);
   int pch;
-  const int ns = wgrad_plan(koff_host, K, ca, cb, &pch);
+  static const int use3_thin = getenv("PCS_WGRAD3") ? atoi(getenv("PCS_WGRAD3")) : 1;
+  const bool thin = use3_thin >= 1 && wgrad3_thin(ca, cb, dtype) && (((uintptr_t)fa_v | (uintptr_t)fb_v) & 15) == 0;
+  const int ns = wgrad_plan(koff_host, K, ca, cb, &pch, thin);
   const int64_t cc = (int64_t)ca * cb;
   if (ns == 0) {
     if (hipMemsetAsync(gW, 0, (size_t)K * cc * 4, st) != hipSuccess) { set_error("pcs_conv_wgrad_f32: memset failed"); return PCS_ELAUNCH; }
@@ -768,7 +798,14 @@ static int conv_wgrad_any(const void *fa_v, int32_t ca, const void *fb_v, int32_
   static const int use3 = getenv("PCS_WGRAD3") ? atoi(getenv("PCS_WGRAD3")) : 1;
   const int cgran = dtype == 0 ? 4 : 8;
   const bool want3 = dtype == 0 ? (use3 == 2 || force_split) : (use3 >= 1 && (use3 == 2 || wg_ngroups(ca) * wg_ngroups(cb) >= 4));
-  if (vec && want3 && ca % cgran == 0 && cb % cgran == 0) {
+  if (thin) {
+    Wgrad3Args w3;
+    w3.fa = fa_v; w3.fb = fb_v; w3.pairs = pairs; w3.koff = koff_dev; w3.partial = reinterpret_cast<float *>(ws);
+    w3.ca = ca; w3.cb = cb; w3.K = K; w3.a_col = a_col; w3.pch = pch;
+    w3.aw = wg_gwidth(ca); w3.bw = wg_gwidth(cb); w3.nag = 1; w3.nbg = 1; w3.nsb = 1;
+    int rc3 = dtype == 1 ? launch_wgrad3_thin<Bf16>(w3, ns, st) : launch_wgrad3_thin<Fp16>(w3, ns, st);
+    if (rc3) return rc3;
+  } else if (vec && want3 && ca % cgran == 0 && cb % cgran == 0) {
     Wgrad3Args w3;
     w3.fa = fa_v; w3.fb = fb_v; w3.pairs = pairs; w3.koff = koff_dev; w3.partial = reinterpret_cast<float *>(ws);
     w3.ca = ca; w3.cb = cb; w3.K = K; w3.a_col = a_col; w3.pch = pch;

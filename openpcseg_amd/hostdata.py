@@ -11,7 +11,7 @@ import torch
 
 from .sparse import SparseTensor
 
-__all__ = ["ravel_hash", "sparse_quantize", "sparse_collate", "sparse_collate_fn"]
+__all__ = ["ravel_hash", "sparse_quantize", "sparse_quantize_frames", "sparse_collate", "sparse_collate_fn"]
 
 
 def ravel_hash(x):
@@ -46,6 +46,30 @@ def sparse_quantize(coords, voxel_size=1, *, return_index=False, return_inverse=
     if return_inverse:
         outputs.append(inverse)
     return outputs[0] if len(outputs) == 1 else outputs
+
+
+def sparse_quantize_frames(coords, frames, num_frames):
+    """`sparse_quantize` (voxel size 1, integer coordinates) of EVERY frame of a batch plus `sparse_collate`'s batch column in one
+    device pass: coords (N, 3) int32 on the device, frames (N,) frame of each row, ascending.
+    Returns (voxels (M, 4) int32 [x, y, z, frame], index (M,) int64 -- the representative row of each voxel --, inverse (N,) int64).
+    Per frame exactly what TS:torchsparse/utils/quantize.py:24-46 returns for that frame's rows -- voxels ordered by ascending
+    ravel hash inside the frame's bounding box, first occurrence as representative -- and the frames concatenated in order like
+    TS:torchsparse/utils/collate.py:11-32. One stable radix sort and one host read (the voxel count sizes the outputs) for the
+    whole batch, where the per-frame form costs a sort, a scan and a host read per frame."""
+    from . import native
+    be = native.backend()
+    if not (isinstance(coords, torch.Tensor) and coords.is_cuda and coords.dim() == 2 and coords.shape[1] == 3):
+        raise RuntimeError("sparse_quantize_frames: coords must be an (N, 3) tensor on the HIP device")
+    coords = coords.int().contiguous()
+    f = frames.long()
+    # ravel_hash (quantize.py:15-21) = ((x - x0) ey + (y - y0)) ez + (z - z0) inside the frame's bounding box: ascending ravel hash IS
+    # ascending lexicographic (x, y, z) -- so one key with the frame on top and the BATCH's bounding box below orders every frame
+    # like its own ravel hash does, without any per-frame quantity (12-way atomic min / max over 1.4 M rows: 200 ms)
+    lo = coords.amin(0).long()
+    ext = coords.amax(0).long() - lo + 1
+    c = coords.long() - lo
+    key = ((f * ext[0] + c[:, 0]) * ext[1] + c[:, 1]) * ext[2] + c[:, 2]
+    return be.quantize_sorted_keys(key, coords, f)
 
 
 def sparse_collate(inputs):

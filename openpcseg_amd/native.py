@@ -1071,6 +1071,28 @@ class HipBackend:
         return vox, index, inverse
 
 
+    def quantize_sorted_keys(self, keys, coords, frames):
+        """Voxel dedup of a whole batch from ready-made keys (hostdata.sparse_quantize_frames): one stable sort, flags, scan,
+        emit -> (vox (m, 4) int32 [x, y, z, frame], index (m,), inverse (n,))."""
+        keys = _dev(keys, "keys", torch.int64)
+        coords = _dev(coords, "coords", torch.int32)
+        n = keys.numel()
+        dev = keys.device
+        if n == 0:
+            return (torch.empty((0, 4), dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int64, device=dev),
+                    torch.empty(0, dtype=torch.int64, device=dev))
+        skeys, perm = torch.sort(keys, stable=True)
+        flags = torch.empty(n, dtype=torch.int32, device=dev)
+        _check(self.lib.pcs_quantize_flags(_ptr(skeys), n, _ptr(flags), _stream()), "pcs_quantize_flags")
+        rank = torch.cumsum(flags, dim=0, dtype=torch.int64)
+        m = int(rank[-1].item())  # the one host read of the batch
+        vox = torch.empty((m, 3), dtype=torch.int32, device=dev)
+        index = torch.empty(m, dtype=torch.int64, device=dev)
+        inverse = torch.empty(n, dtype=torch.int64, device=dev)
+        _check(self.lib.pcs_quantize_emit(_ptr(flags), _ptr(rank), _ptr(perm), _ptr(coords), n, _ptr(vox), _ptr(index),
+                                          _ptr(inverse), _stream()), "pcs_quantize_emit")
+        return torch.cat([vox, frames[index].int()[:, None]], dim=1), index, inverse
+
     def unique_inverse_csr(self, keys):
         """keys (n,) int64 -> (uniq (m,) ascending, inverse (n,) int64, counts (m,) int32); the stable sort behind it is
         kept as the segmented-reduction CSR of `inverse` (cached on the returned tensor, so spvoxelize over it sorts

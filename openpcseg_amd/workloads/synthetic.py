@@ -9,7 +9,7 @@ round(xyz / voxel) -> shift to >= 0 -> sparse_quantize. Seed 0 gives 92 321 voxe
 import numpy as np
 import torch
 
-from ..hostdata import sparse_collate_fn, sparse_quantize
+from ..hostdata import sparse_collate_fn, sparse_quantize, sparse_quantize_frames
 from ..sparse import SparseTensor
 
 N_RINGS, N_AZ = 64, 1875
@@ -54,3 +54,35 @@ def make_batch(seeds, n_points=None, voxel_size=0.05, num_classes=20):
     batch = sparse_collate_fn(frames)
     batch["offset"] = torch.cumsum(torch.tensor([f["lidar"].coords.shape[0] for f in frames]), 0).int()
     return batch
+
+
+def make_raw_batch(seeds, n_points=None, num_classes=20):
+    """The batch BEFORE the dataset transform: raw scans (sum n_i, 4) fp32, their frame ids and per-point labels (host tensors; the
+    same scans and labels make_batch voxelises on the host)."""
+    pts = [make_scan(s, n_points) for s in seeds]
+    labels = [np.random.default_rng(s + 12345).integers(0, num_classes, size=p.shape[0]).astype(np.int64) for s, p in zip(seeds, pts)]
+    frames = np.concatenate([np.full(p.shape[0], i, dtype=np.int32) for i, p in enumerate(pts)])
+    return {"points": torch.from_numpy(np.concatenate(pts)), "frames": torch.from_numpy(frames),
+            "labels": torch.from_numpy(np.concatenate(labels)), "num_frames": len(seeds),
+            "offsets": [0] + np.cumsum([p.shape[0] for p in pts]).tolist()}   # host-side frame boundaries (known when the scans are uploaded)
+
+
+def device_collate(raw, voxel_size=0.05):
+    """Dataset transform + sparse_quantize + sparse_collate_fn of a raw batch resident in HBM, bit-exact
+    with voxelize_scan / make_batch on the host: round(xyz / voxel) -> shift every frame to >= 0
+    (R:pcseg/data/dataset/semantickitti/semantickitti_voxel.py:112-120) -> voxel dedup of all frames in one pass
+    (hostdata.sparse_quantize_frames) -> gathered features / labels with the batch column."""
+    pts, frames, labels, nf = raw["points"], raw["frames"], raw["labels"], raw["num_frames"]
+    # a TENSOR divisor: torch turns `tensor / python_float` into a multiplication by the reciprocal on the device, which is not
+    # NumPy's float32 division (the voxel a point falls into may differ by one)
+    v = torch.full((), voxel_size, dtype=torch.float32, device=pts.device)
+    pc = torch.round(pts[:, :3] / v).int()
+    off = raw["offsets"]
+    sizes = {off[i + 1] - off[i] for i in range(nf)}
+    if len(sizes) == 1:   # equal-length scans: one reduction for the per-frame minimum
+        n = sizes.pop()
+        pc = (pc.view(nf, n, 3) - pc.view(nf, n, 3).amin(1, keepdim=True)).view(-1, 3)
+    else:
+        pc = torch.cat([pc[off[i]:off[i + 1]] - pc[off[i]:off[i + 1]].amin(0, keepdim=True) for i in range(nf)])
+    vox, index, _ = sparse_quantize_frames(pc, frames, nf)
+    return {"lidar": SparseTensor(pts[index], vox), "targets": SparseTensor(labels[index], vox)}

@@ -598,10 +598,12 @@ def main_trajectory():
     shipped optimizer (SGD momentum 0.9, weight decay 1e-4, clip 10; minkunet_mk34_cr10.yaml:25-33) at a fixed learning rate, on
     the reference's torchsparse + compiled CPU backend. Keeps the loss of every step and a fingerprint (float64 sum / abs-sum /
     abs-max + eight samples) of every parameter and BatchNorm buffer after the last step.
-    The run is made TWICE: the second one (the "twin") sees the input features multiplied by (1 + 1e-7 N(0, 1)) -- a perturbation of
-    the size of one float32 rounding. How far the twin drifts from the first run is how reproducible the reference's OWN trajectory
-    is under rounding-level differences (the loss has kinks: ReLU gates, the Lovasz sort order), i.e. the floor for any other
-    arithmetic (MFMA summation order) -- the test bounds follow it where it exceeds the nominal 1e-4 / 1e-3."""
+    The run is repeated as TWINS: the same reference, same weights, input features multiplied by (1 + eps N(0, 1)) with
+    eps = 1e-6 (three seeds) -- the size of the difference between two correct fp32 implementations of one forward pass (the full-size
+    fixtures: logits agree to 1.4e-6 of their scale between the reference's CPU code and the MFMA kernels). How far the twins drift
+    from the first run and from each other is how reproducible the reference's OWN trajectory is at that level (the loss has kinks:
+    ReLU gates, the Lovasz sort order, and every step amplifies), i.e. the floor for any other summation order -- the test bounds
+    follow it where it exceeds the nominal 1e-4 / 1e-3. `make_golden.py trajectory twins` adds twins to an existing fixture."""
     import time
     import fullsize as fs
     from torch.nn.utils import clip_grad_norm_
@@ -638,20 +640,31 @@ def main_trajectory():
         state = [(n, t) for n, t in model.state_dict().items() if t.dtype.is_floating_point]
         return np.array(losses, dtype=np.float64), np.array(norms, dtype=np.float64), fs.grad_fingerprint(state)
 
+    path = os.path.join(OUT, "trajectory_golden.npz")
+    twins_only = len(sys.argv) > 2 and sys.argv[2] == "twins" and os.path.exists(path)
     orig = torch.Tensor.cuda
     torch.Tensor.cuda = lambda self, *a, **k: self
     try:
-        losses, norms, fp = run(feats, "main")
-        noise = torch.randn(feats.shape, generator=torch.Generator().manual_seed(7))
-        t_losses, t_norms, t_fp = run(feats * (1.0 + 1e-7 * noise), "twin")
+        if twins_only:
+            old = dict(np.load(path))
+            assert all(int(old[k]) == int(g[k]) for k in g), "the existing fixture was made from other inputs"
+            g = {k: v for k, v in old.items() if not k.startswith("twin")}
+            losses = g["losses"]
+        else:
+            losses, norms, fp = run(feats, "main")
+            g["losses"], g["grad_norms"] = losses, norms
+            g["state_names"], g["state_stats"], g["state_samples"] = fp["grad_names"], fp["grad_stats"], fp["grad_samples"]
+        eps, tl, ts_, tm = 1e-6, [], [], []
+        for seed in (7, 8, 9):
+            noise = torch.randn(feats.shape, generator=torch.Generator().manual_seed(seed))
+            t_losses, _, t_fp = run(feats * (1.0 + eps * noise), "twin%d" % seed)
+            tl.append(t_losses); ts_.append(t_fp["grad_stats"]); tm.append(t_fp["grad_samples"])
     finally:
         torch.Tensor.cuda = orig
-    g["losses"], g["grad_norms"] = losses, norms
-    g["state_names"], g["state_stats"], g["state_samples"] = fp["grad_names"], fp["grad_stats"], fp["grad_samples"]
-    g["twin_losses"], g["twin_grad_norms"] = t_losses, t_norms
-    g["twin_state_stats"], g["twin_state_samples"] = t_fp["grad_stats"], t_fp["grad_samples"]
-    np.savez_compressed(os.path.join(OUT, "trajectory_golden.npz"), **g)
-    print("wrote trajectory_golden.npz: losses", losses.tolist(), "\ntwin drift", np.abs(t_losses / losses - 1).tolist())
+    g["twin_eps"], g["twin_losses"] = np.array(eps), np.array(tl)                       # (3, steps)
+    g["twin_state_stats"], g["twin_state_samples"] = np.array(ts_), np.array(tm)        # (3, tensors, 3), (3, tensors, 8)
+    np.savez_compressed(path, **g)
+    print("wrote trajectory_golden.npz: losses", np.asarray(losses).tolist(), "\ntwin drift", np.abs(np.array(tl) / losses - 1).max(0).tolist())
 
 
 def main_cylinder():

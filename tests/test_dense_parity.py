@@ -355,7 +355,9 @@ def test_half_conv_forward_dense_map(hip, levels, dtype, stride, cin, cout, tile
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("stride,cin,cout", [(4, 128, 128), (8, 384, 256), (1, 128, 96), (2, 112, 56), (4, 336, 224),
-                                             (8, 672, 448)])
+                                             (8, 672, 448),
+                                             # [r5] one-tile gradient blocks: the one-wave instance of wgrad3 (csrc/conv_wgrad.hip, THIN)
+                                             (4, 64, 64), (2, 32, 32), (4, 32, 64), (4, 64, 32), (8, 64, 48)])
 def test_half_conv_backward_dense_map(hip, levels, dtype, stride, cin, cout):
     """dgrad on the half kernel (weights re-packed with transpose=True) and the fp32-accumulated weight gradient from
     half operands (pcs_conv_wgrad_h) vs orc_conv_bwd on the half-rounded operands."""

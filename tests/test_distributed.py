@@ -289,3 +289,76 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "refusing" in (bad.stderr + bad.stdout)
+
+
+# ---- block fusion of the reference's OWN blocks with the model file's SyncBatchNorm classes (openpcseg_amd/block_fusion.py) ---------
+def _fused_block_inputs():
+    from openpcseg_amd.workloads.synthetic import make_batch
+    b = make_batch([21, 22], n_points=1500)
+    torch.manual_seed(11)
+    return b["lidar"].C, torch.randn(b["lidar"].C.shape[0], 16)
+
+
+def _reference_residual_block(if_dist):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import make_golden as mg
+    import openpcseg_amd
+    from seeded import seeded_state
+    openpcseg_amd.install_reference_aliases()
+    mod = mg.import_reference_model("pcseg.model.segmentor.voxel.minkunet.minkunet")
+    blk = mod.ResidualBlock(16, 24, if_dist=if_dist)      # 16 -> 24 channels: the block with a downsample branch (1x1x1 conv + BN)
+    seeded_state(blk)
+    return blk.train()
+
+
+def _fused_block_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    _patch()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import openpcseg_amd
+    from openpcseg_amd.sparse import SparseTensor
+    coords, feats = _fused_block_inputs()
+    sel = coords[:, 3] == rank                           # whole frames per rank, like the DistributedSampler
+    blk = _reference_residual_block(if_dist=True)
+    counts = openpcseg_amd.fuse(blk)
+    assert counts["residual"] == 1 and counts["conv_bn"] == 3, counts
+    x = feats[sel].clone().requires_grad_(True)
+    y = blk(SparseTensor(x, coords[sel].contiguous())).F
+    (y * torch.arange(1, 25)).sum().backward()
+    q.put((rank, y.detach().numpy(), x.grad.numpy(), blk.net[1].weight.grad.numpy(), blk.net[4].running_var.numpy(),
+           int(blk.net[1].num_batches_tracked)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fused_reference_block_with_syncbatchnorm_matches_global_batch(oracle_backend):
+    """R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:83-129 with IF_DIST=True (the model file's SyncBatchNorm classes) after
+    `openpcseg_amd.fuse`, two ranks with one frame each over gloo == the same block with plain BatchNorm over both frames in one
+    process (the SyncBatchNorm contract): outputs, input gradients, parameter gradients (DDP would average
+    them: per-rank sums add up to the global gradient), running statistics."""
+    if not os.path.isdir("/root/reference") and not os.path.isdir(os.path.join(ROOT, "tests", "_refsrc")):
+        pytest.skip("reference sources not present")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fused_block_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    from openpcseg_amd.sparse import SparseTensor
+    coords, feats = _fused_block_inputs()
+    ref = _reference_residual_block(if_dist=False)        # plain BatchNorm1d, unfused, both frames at once
+    x = feats.clone().requires_grad_(True)
+    y = ref(SparseTensor(x, coords)).F
+    (y * torch.arange(1, 25)).sum().backward()
+    order = torch.cat([(coords[:, 3] == r).nonzero().squeeze(1) for r in range(2)])
+    assert np.allclose(np.concatenate([got[0][1], got[1][1]]), y.detach().numpy()[order], atol=2e-5)
+    assert np.allclose(np.concatenate([got[0][2], got[1][2]]), x.grad.numpy()[order], atol=2e-5)
+    assert np.allclose(got[0][3] + got[1][3], ref.net[1].weight.grad.numpy(), rtol=1e-4, atol=1e-5)
+    assert np.allclose(got[0][4], ref.net[4].running_var.numpy(), rtol=1e-5) and np.allclose(got[1][4], got[0][4])
+    assert got[0][5] == got[1][5] == int(ref.net[1].num_batches_tracked) == 1

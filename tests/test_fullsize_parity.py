@@ -57,8 +57,11 @@ BOUNDS = {
     "config_mk34/workload": (8e-4, 1e-5, 2e-4, 3.6e-3, 2e-3, 5e-3),
 }
 # the same reference sources after openpcseg_amd.fuse(model) (block fusion, openpcseg_amd/block_fusion.py): the bounds of the plain route
-for _k in ("config2", "config3", "config5", "config2x2", "config_mk34"):
+for _k in ("config2", "config3", "config4", "config2x2", "config_mk34"):
     BOUNDS[_k + "/reference+fuse"] = BOUNDS[_k + "/reference"]
+# config 5 after fuse: the point MLPs' BatchNorm runs on the fused passes (another summation order than torch's kernels), measured
+#                                                                  4.5e-4   1.9e-4 / 3.2e-4   5.1e-4 / 1.7e-3
+BOUNDS["config5/reference+fuse"] = (8e-4, 2e-5, 4e-4, 6e-4, 1e-3, 4e-3)
 _MEASURED = {}
 
 
@@ -138,7 +141,10 @@ def _reference_step_on_hip(cfg, fuse):
     model = fs.freeze_dropout(_reference_model(cfg).to(dev).train())
     if fuse:
         counts = openpcseg_amd.fuse(model)
-        assert counts["residual"] >= 16 and counts["criterion"] == 2 and counts["glue"] >= 2, counts
+        if cfg == "config4":   # Cylinder_TS: no Sequential / residual blocks of the MinkUNet kind -- its BatchNorm1d / Linear / loss modules
+            assert counts["dense"] >= 40 and counts["criterion"] == 3, counts
+        else:
+            assert counts["residual"] >= 16 and counts["criterion"] == 2 and counts["glue"] >= 2, counts
         assert counts["forward"] == (1 if "MinkUNet" in fs.MODEL_PATH[cfg][1] else 0), counts
     try:
         logits, loss = fs.run_train_step(cfg, model, batch, via="criterion" if fuse else "classifier")
@@ -162,7 +168,7 @@ def test_fullsize_reference_model_on_hip(cfg, hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["config2", "config3", "config5", "config2x2", "config_mk34"])
+@pytest.mark.parametrize("cfg", ["config2", "config3", "config4", "config5", "config2x2", "config_mk34"])
 def test_fullsize_reference_model_fused_on_hip(cfg, hip):
     """The same sources after `openpcseg_amd.fuse(model)` -- conv-epilogue BatchNorm statistics, BN + residual + ReLU in one pass,
     concat written by the apply pass, device Lovasz-softmax / masked-mean CE -- against the same fixtures with the same bounds."""

@@ -1091,3 +1091,29 @@ def test_weight_prep_sees_writes_behind_autograd(hip, amp):
     check("in-place under no_grad")
     F._WEIGHT_PREP.invalidate()
     check("explicit invalidate")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seeds,npts", [(list(range(12)), None), ([3, 4, 5], 20000), ([7], 5000)])
+def test_device_input_pipeline_matches_the_host_dataloader(hip, seeds, npts):
+    """SURVEY section 8 f1 with its number (bench.py's `device_input` record): raw (n, 4) scans resident in HBM -> dataset transform
+    (R:pcseg/data/dataset/semantickitti/semantickitti_voxel.py:112-120) + sparse_quantize of every frame + sparse_collate_fn in ONE
+    device pass (hostdata.sparse_quantize_frames: one sort, one host read per batch) -- bit-exact with the host path
+    (NumPy sparse_quantize per frame, TS:torchsparse/utils/quantize.py:24-46, + TS:torchsparse/utils/collate.py:11-59):
+    voxel coordinates incl. order and batch column, gathered features, gathered labels."""
+    from openpcseg_amd import hostdata
+    from openpcseg_amd.workloads import synthetic as syn
+    raw = syn.make_raw_batch(seeds, n_points=npts)
+    dev_raw = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in raw.items()}
+    d = syn.device_collate(dev_raw)
+    b = syn.make_batch(seeds, n_points=npts)
+    assert torch.equal(d["lidar"].C.cpu(), b["lidar"].C)
+    assert torch.equal(d["lidar"].F.cpu(), b["lidar"].F)
+    assert torch.equal(d["targets"].F.cpu(), b["targets"].F)
+    # the inverse map sends every point to the voxel that holds its cell
+    pc = torch.round(dev_raw["points"][:, :3] / torch.full((), 0.05, device=DEV)).int()
+    lo = torch.stack([pc[dev_raw["frames"] == i].min(0).values for i in range(raw["num_frames"])])
+    pc = pc - lo[dev_raw["frames"].long()]
+    vox, index, inverse = hostdata.sparse_quantize_frames(pc, dev_raw["frames"], raw["num_frames"])
+    assert torch.equal(vox[inverse][:, :3], pc) and torch.equal(vox[inverse][:, 3], dev_raw["frames"])
+    assert torch.equal(vox, d["lidar"].C)

@@ -12,11 +12,12 @@ BatchNorm buffer after the last one.
 
 Bounds. Nominal: every step's loss within 1e-4 relative, final weights within 1e-3 (abs-sum per tensor; sampled elements relative
 to the tensor's largest element). The loss of this model has kinks (ReLU gates, the Lovasz sort order), so a training trajectory
-amplifies rounding-level differences step by step -- for the REFERENCE ITSELF: the fixture holds a twin run of the reference whose
-input features were perturbed by 1e-7 relative (one float32 rounding), and its drift from the main run is the reproducibility of the
-reference's own trajectory. A bound is max(nominal, 4 x the twin's drift at that step / in that quantity): what no implementation
-with another summation order (MFMA tiles vs scalar loops) can beat, measured rather than assumed. The measured values of the three
-routes and the twin are appended to profiles/round5_fullsize_parity.json."""
+amplifies small differences step by step -- for the REFERENCE ITSELF: the fixture holds three twin runs of the reference whose input
+features were perturbed by 1e-6 relative (the size of the difference between two correct fp32 implementations of one forward pass:
+the full-size fixtures' logits agree to 1.4e-6 of their scale), and the spread of {main, twins} is the reproducibility of the
+reference's own trajectory at that level. A bound is max(nominal, 3 x the largest drift among the twins at that step / in that
+quantity): what an implementation with another summation order (MFMA tiles vs scalar loops) cannot be expected to beat, measured
+rather than assumed. The measured values of the three routes and the twins: profiles/round5_fullsize_parity.json."""
 import json
 import os
 import sys
@@ -115,9 +116,10 @@ def test_training_trajectory_on_hip(route, hip):
     m = {"loss_rel_err_max": float(loss_err.max()), "loss_rel_err_last": float(loss_err[-1]), "grad_norm_rel_err_max": float(norm_err.max()),
          "weights_abssum_rel_err_max": float(e_abs.max()), "weights_sample_err_rel_max": float(e_smp.max()),
          "worst_tensor": str(g["state_names"][int(np.argmax(e_abs))]), "losses": [round(float(v), 6) for v in losses]}
-    twin_loss = np.abs(g["twin_losses"] / g["losses"] - 1)
-    t_abs = np.abs(g["twin_state_stats"][:, 1] / rs[:, 1] - 1)
-    t_smp = np.abs(g["twin_state_samples"] - g["state_samples"]).max(1) / rs[:, 2]
+    tw = np.concatenate([g["twin_losses"], g["losses"][None]], 0)                    # (4, steps): twins + main
+    twin_loss = np.max([np.abs(tw[i] / tw[j] - 1) for i in range(len(tw)) for j in range(i)], axis=0)   # largest pairwise drift per step
+    t_abs = np.abs(g["twin_state_stats"][:, :, 1] / rs[None, :, 1] - 1).max(0)
+    t_smp = (np.abs(g["twin_state_samples"] - g["state_samples"][None]).max(2) / rs[None, :, 2]).max(0)
     m.update({"twin_loss_rel_drift": [float("%.3g" % v) for v in twin_loss], "loss_rel_err": [float("%.3g" % v) for v in loss_err],
               "twin_weights_abssum_drift_max": float(t_abs.max()), "twin_weights_sample_drift_max": float(t_smp.max())})
     print("\n[trajectory] %s: %s" % (route, json.dumps(m)))
@@ -125,7 +127,7 @@ def test_training_trajectory_on_hip(route, hip):
     if os.path.isdir(out):
         with open(os.path.join(out, "trajectory_%s.json" % route.replace("+", "_")), "w") as f:
             json.dump(m, f, indent=1)
-    assert (loss_err <= np.maximum(LOSS_REL, 4 * twin_loss)).all(), m
+    assert (loss_err <= np.maximum(LOSS_REL, 3 * twin_loss)).all(), m
     assert loss_err[:2].max() < LOSS_REL, m       # before the amplification sets in the nominal bound holds outright
-    assert m["weights_abssum_rel_err_max"] < max(WEIGHT_REL, 4 * float(t_abs.max())), m
-    assert m["weights_sample_err_rel_max"] < max(WEIGHT_REL, 4 * float(t_smp.max())), m
+    assert m["weights_abssum_rel_err_max"] < max(WEIGHT_REL, 3 * float(t_abs.max())), m
+    assert m["weights_sample_err_rel_max"] < max(WEIGHT_REL, 3 * float(t_smp.max())), m

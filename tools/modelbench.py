@@ -35,7 +35,7 @@ import torch  # noqa: E402
 FRAMES = {"minkunet18": 16, "spvcnn18": 16, "cylinder": 12, "rpvnet34": 4, "minkunet34": 12}
 CFG_OF = {"minkunet18": "config2", "spvcnn18": "config3", "cylinder": "config4", "rpvnet34": "config5", "minkunet34": "config2"}
 AUTO = ["minkunet34:reference", "minkunet34:fuse", "minkunet18:reference", "minkunet18:fuse", "minkunet18:workload",
-        "spvcnn18:reference", "spvcnn18:fuse", "cylinder:reference", "rpvnet34:reference", "rpvnet34:fuse"]
+        "spvcnn18:reference", "spvcnn18:fuse", "cylinder:reference", "cylinder:fuse", "rpvnet34:reference", "rpvnet34:fuse"]
 
 
 def _reference_model(name):
