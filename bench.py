@@ -39,7 +39,7 @@ from openpcseg_amd.workloads.synthetic import make_batch  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
-TRAFFIC_FILE = "round4_conv_traffic.json"
+TRAFFIC_FILE = "round5_conv_traffic.json"
 # what the counters say binds conv_os5h_kernel (profiles/round3_convh_pmc.md); filled in from the PMC passes of round 3
 HALF_BINDING_NOTE = ("vector-memory address path (TA / vector L1), not HBM and not the MFMA pipe: TA 65-81 % busy, MFMA pipe 10-19 %, "
                      "L2 hit 77-94 %, HBM 1.3-3 TB/s on the two reference shapes; 1.1-1.6 MFMAs per 16-byte operand load "

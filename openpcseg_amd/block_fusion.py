@@ -226,11 +226,14 @@ class _PointLinear(torch.autograd.Function):
                 _POINT_MAPS.clear()
             km = _identity_map(x.shape[0], x.device, _POINT_MAPS)
             be = native.backend()
+            xa, cin = x.contiguous(), x.shape[1]
+            if cin % 4:   # e.g. Cylinder_TS's first point layer, Linear(9, 64): zero columns bring the rows to 16-byte granularity
+                xa = torch.nn.functional.pad(xa, (0, (-cin) % 4))
             if hd is not None:
-                gw = be.conv_wgrad_h(x.contiguous().to(hd), dy.to(hd), km, 0)[0]
+                gw = be.conv_wgrad_h(xa.to(hd), dy.to(hd), km, 0)[0]
             else:
-                gw = be.conv_wgrad(x.contiguous().float(), dy.float(), km, 0)[0]
-            gw = gw.t().to(weight.dtype)
+                gw = be.conv_wgrad(xa.float(), dy.float(), km, 0)[0]
+            gw = gw[:cin].t().to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = dy.float().sum(0).to(weight.dtype)
         return gx, gw, gb
@@ -241,7 +244,7 @@ def _dense_step(lin, bn, act, x):
     if not (_rows_ok(x) and _quiet(lin) and _quiet(bn) and (act is None or _quiet(act))):
         h = bn(lin(x))
         return act(h) if act is not None else h
-    if lin.in_features % 4 == 0 and lin.out_features % 4 == 0:
+    if lin.out_features % 4 == 0:
         h = _PointLinear.apply(x, lin.weight, lin.bias)
     else:
         h = lin(x)
@@ -275,7 +278,7 @@ def _dense_bn_forward(self, x):
 
 def _dense_linear_forward(self, x):
     """forward of a stock nn.Linear re-classed by fuse(): tall (N, C_in) device inputs get the split-reduction weight gradient."""
-    if not (_rows_ok(x) and _quiet(self) and self.in_features % 4 == 0 and self.out_features % 4 == 0):
+    if not (_rows_ok(x) and _quiet(self) and self.out_features % 4 == 0):
         return self.__dict__["_pcs_orig_class"].forward(self, x)
     return _PointLinear.apply(x, self.weight, self.bias)
 

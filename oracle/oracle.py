@@ -249,6 +249,9 @@ def scatter_max_bwd(gout, arg, n):
 
 
 # ---- range_lib (RL = R:pcseg/model/segmentor/fusion/rpvnet/range_lib/) ------------------------------
+# PINNED [r5]: oracle/build_ref_rangelib.py executes the reference's own kernel text (RL:range_utils/src/*.cu) on the host;
+# tests/test_scatter_range.py compares these restatements (and the HIP kernels) with it. Rows outside the image are handled here
+# with upper-bound checks the reference lacks (undefined behaviour there): not part of the pinned domain.
 def map_count(pxpy, b, h, w):
     """RL:range_utils/src/map_count_gpu.cu:5-14 (+ upper-bound checks the reference lacks)."""
     pxpy = np.asarray(pxpy, dtype=np.int64)

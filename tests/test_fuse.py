@@ -306,3 +306,58 @@ def test_fused_spvcnn_and_rpvnet_on_hip(gold, env_hip):
         trm._run_cylinder(env_hip, gold)
     finally:
         fz.uninstall_auto_fuse()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout", [(9, 64), (32, 256), (256, 20), (100, 36)])
+def test_dense_linear_and_batchnorm_match_torch_on_hip(hip, cin, cout):
+    """The re-classed stock nn.Linear / nn.BatchNorm1d of a fused model ((N, C) rows of >= 4096 points: Cylinder_TS's point MLP and
+    per-convolution BatchNorm1d, the point_transforms of SPVCNN / RPVNet) against the stock modules: outputs, input / weight / bias
+    gradients, running statistics; and that the fused path is really taken."""
+    import openpcseg_amd
+    from openpcseg_amd import block_fusion as fz
+    from openpcseg_amd import modules as spnn
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.marker = spnn.Conv3d(4, 4, 1)        # a sparse model: fuse() only touches dense layers of models that have sparse convolutions
+            self.bn_in = torch.nn.BatchNorm1d(cin)
+            self.mlp = torch.nn.Sequential(torch.nn.Linear(cin, cout), torch.nn.BatchNorm1d(cout), torch.nn.ReLU(True))
+            self.head = torch.nn.Linear(cout, 20)
+            self.stem = torch.nn.Sequential(spnn.Conv3d(4, 8, 3), spnn.BatchNorm(8), spnn.ReLU(True))
+
+        def forward(self, x):
+            return self.head(self.mlp(self.bn_in(x)))
+
+    torch.manual_seed(3)
+    plain, fused = Net().cuda().train(), Net().cuda().train()
+    fused.load_state_dict(plain.state_dict())
+    counts = openpcseg_amd.fuse(fused)
+    assert counts["dense"] == 2 and counts["sequential"] == 2 and counts["conv_bn"] == 2, counts
+    x = torch.randn(30000, cin, device="cuda") * 2 + 0.5
+    calls = []
+    orig = fz._PointLinear.apply
+    fz._PointLinear.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        outs = []
+        for m in (plain, fused):
+            xi = x.clone().requires_grad_(True)
+            y = m(xi)
+            (y * torch.arange(1, 21, device="cuda")).sum().backward()
+            outs.append((y.detach(), xi.grad, {n: p.grad for n, p in m.named_parameters() if p.grad is not None},
+                         {n: b.clone() for n, b in m.named_buffers()}))
+    finally:
+        fz._PointLinear.apply = orig
+    assert len(calls) == 2
+    (y0, g0, p0, b0), (y1, g1, p1, b1) = outs
+    assert float((y0 - y1).abs().max()) <= 2e-5 * float(y0.abs().max())
+    assert float((g0 - g1).abs().max()) <= 1e-4 * float(g0.abs().max())
+    for n in p0:
+        assert float((p0[n] - p1[n]).abs().max()) <= 2e-4 * max(float(p0[n].abs().max()), 1e-3), n
+    for n in b0:
+        assert torch.allclose(b0[n].float(), b1[n].float(), rtol=1e-5, atol=1e-6), n
+    # small inputs and eval mode take the stock forward / the running statistics
+    small = torch.randn(100, cin, device="cuda")
+    assert torch.allclose(plain.eval()(small), fused.eval()(small), atol=1e-5)
+    assert torch.allclose(plain(x), fused(x), atol=2e-5 * float(y0.abs().max()))

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 : > $R/gpurun_out/conv_traffic_pmc.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  PCS_BENCH_PREHEAT=0 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --models none > /tmp/pmc_$c.log 2>&1
+  PCS_BENCH_PREHEAT=0 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-split-line --no-device-input-line --models none > /tmp/pmc_$c.log 2>&1
   f=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1)
   cp "$f" /tmp/pmc_$c.csv
   python $R/tools/pmc_summary.py "$f" conv_os >> $R/gpurun_out/conv_traffic_pmc.txt
