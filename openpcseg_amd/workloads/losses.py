@@ -52,7 +52,9 @@ def lovasz_softmax(probas, labels, ignore=None):
     n, nc = probas.shape
     valid = None
     if ignore is None:
-        cnt = torch.bincount(labels, minlength=nc)
+        # labels outside [0, nc) are invalid points here as well (what the HIP kernel does): neither counted nor given an error term
+        valid = (labels >= 0) & (labels < nc)
+        cnt = torch.bincount(torch.where(valid, labels, torch.full_like(labels, nc)), minlength=nc + 1)[:nc]
     else:
         # presence counts over the VALID points only: an out-of-range ignore label (255, -100, -1) must not be counted
         # into a clamped class (it would make that class "present" with no foreground point and add a max(err) term)
@@ -105,8 +107,10 @@ class _LovaszSoftmaxHip(torch.autograd.Function):
 
 
 def lovasz_softmax_device(probas, labels, ignore=None):
-    """Device tensors: the fused HIP form; host tensors (the oracle-backed CPU tests, the explicit CPU path): the torch form."""
-    if probas.is_cuda and os.environ.get("PCS_LOVASZ_TORCH", "0") != "1":
+    """Device tensors the kernel serves ((n, C <= 60) probabilities): the fused HIP form; anything else -- host tensors (the
+    oracle-backed CPU tests, the explicit CPU path), more than 60 classes -- the torch form of the same function."""
+    if (probas.is_cuda and probas.dim() == 2 and probas.shape[1] <= 60 and labels.dim() == 1 and
+            os.environ.get("PCS_LOVASZ_TORCH", "0") != "1"):
         return _LovaszSoftmaxHip.apply(probas, labels, ignore)
     return lovasz_softmax(probas, labels, ignore)
 

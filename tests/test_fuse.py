@@ -354,6 +354,8 @@ def test_dense_linear_and_batchnorm_match_torch_on_hip(hip, cin, cout):
     assert float((y0 - y1).abs().max()) <= 2e-5 * float(y0.abs().max())
     assert float((g0 - g1).abs().max()) <= 1e-4 * float(g0.abs().max())
     for n in p0:
+        if n in ("bn_in.bias", "mlp.0.bias"):   # a constant shift in front of a train-mode BatchNorm: gradient zero by construction (noise)
+            continue
         assert float((p0[n] - p1[n]).abs().max()) <= 2e-4 * max(float(p0[n].abs().max()), 1e-3), n
     for n in b0:
         assert torch.allclose(b0[n].float(), b1[n].float(), rtol=1e-5, atol=1e-6), n

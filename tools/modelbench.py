@@ -17,7 +17,7 @@ tests/_refsrc (bench plumbing: nothing under openpcseg_amd/ imports this file).
 
 source `fuse` = the reference's source after `openpcseg_amd.fuse(model)` (block fusion, openpcseg_amd/block_fusion.py): the record
 `<name>/ref+fuse`. Timing [r5]: clock pre-heat (windows of 5 steps until a window is no longer > 0.4 % faster than the one before,
-2..6 windows) and PCS_MB_STEPS (default 10) timed steps, like the headline.
+2..3 windows) and PCS_MB_STEPS (default 10) timed steps, like the headline.
 """
 import json
 import os
@@ -132,7 +132,7 @@ def _time_steps(step, steps, warmup):
     torch.cuda.synchronize()
     if os.environ.get("PCS_BENCH_PREHEAT", "1") != "0":   # the headline's clock pre-heat (bench.py::preheat), shortened
         prev = None
-        for wi in range(6):
+        for wi in range(3):
             t0 = time.perf_counter()
             for _ in range(5):
                 step()
