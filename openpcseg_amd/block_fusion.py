@@ -569,6 +569,17 @@ def _fuse_model_forward(m, undo):
     return 0
 
 
+def _unbump(module, args, output):
+    """Root forward hook: a fused BatchNorm that did NOT run in this forward (a branch not taken, a head used only in eval) gives
+    the count of `_bump` back, so the counters are exact whenever the forward has returned."""
+    st = module.__dict__.get("_pcs_fused")
+    if st is not None:
+        for b in st["bns"]:
+            if b.__dict__.get("_pcs_bumped", False):
+                b.num_batches_tracked.sub_(1)
+                b.__dict__["_pcs_bumped"] = False
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def _adopt(plan, bns):
     for st in plan.steps:
@@ -642,7 +653,7 @@ def fuse(model, criterion=True, glue=True, forward=True):
     if bns and forward:
         for m in mods:
             counts["forward"] += _fuse_model_forward(m, undo)
-    handle = model.register_forward_pre_hook(_bump) if bns else None
+    handle = (model.register_forward_pre_hook(_bump), model.register_forward_hook(_unbump)) if bns else None
     model.__dict__["_pcs_fused"] = {"counts": counts, "undo": undo, "hook": handle, "bns": bns}
     return dict(counts)
 
@@ -661,7 +672,8 @@ def unfuse(model):
         else:
             u[1]._modules[u[2]] = u[3]
     if st["hook"] is not None:
-        st["hook"].remove()
+        for h in st["hook"]:
+            h.remove()
     for b in st["bns"]:
         if b.__dict__.pop("_pcs_bumped", False):
             b.num_batches_tracked.sub_(1)

@@ -234,8 +234,8 @@ def test_fullsize_workload_minkunet34_on_hip(hip):
 # arg-max agreement with the fp32 reference 98.6 % / 99.7 % of the points
 AMP_BOUNDS = {torch.bfloat16: (0.30, 0.02, 0.12, 0.975), torch.float16: (0.05, 0.0025, 0.04, 0.99)}  # max / rms, mean / rms, grad, arg-max
 # [r5] MinkUNet-34 (the headline graph, 15 more residual blocks than config 2)
-#   measured [r5] (bf16 / fp16): max 0.278 / 0.029 of the RMS, mean 0.0060 / 0.00073, worst gradient abs-sum 16.2 % / 8.9 %, arg-max 98.4 / 99.8 %
-AMP_BOUNDS_MK34 = {torch.bfloat16: (0.45, 0.012, 0.25, 0.97), torch.float16: (0.05, 0.0015, 0.14, 0.99)}
+#   measured [r5] (bf16 / fp16): max 0.288 / 0.038 of the RMS, mean 0.0060 / 0.00073, worst gradient abs-sum 20.7 % / 7.5 %, arg-max 98.3 / 99.9 %
+AMP_BOUNDS_MK34 = {torch.bfloat16: (0.45, 0.012, 0.30, 0.97), torch.float16: (0.06, 0.0015, 0.14, 0.99)}
 
 
 @pytest.mark.gpu
