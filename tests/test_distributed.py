@@ -145,7 +145,7 @@ def test_bench_two_ranks_on_one_device():
     barrier + max-over-ranks timing, one JSON line from rank 0 with the whole-job frame count."""
     import json
     import subprocess
-    env = dict(os.environ, PCS_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, PCS_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", PCS_BENCH_PREHEAT_MIN_S="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--frames-per-gpu", "2", "--no-amp-line", "--no-split-line"]
@@ -259,7 +259,7 @@ def test_bench_two_ranks_over_rccl():
     import subprocess
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 visible GPUs (RCCL)")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PCS_BENCH_PREHEAT_MIN_S="0")
     env.pop("PCS_BENCH_ONE_DEVICE", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
