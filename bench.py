@@ -751,7 +751,7 @@ def main():
         if models is not None:
             if not args.verbose_json and "error" not in models:
                 # frames/s of one training step per model (ms per step and batch sizes: --verbose-json, bench_notes.json)
-                short = {"fmt": "frames/s [ref f32,ref bf16,ref+fuse f32,ref+fuse bf16]; ref = the reference's source, +fuse = openpcseg_amd.fuse(model)"}
+                short = {"fmt": "frames/s [ref f32,ref bf16,+fuse f32,+fuse bf16] (reference source; + openpcseg_amd.fuse)"}
                 r1 = lambda v: None if v is None else round(v, 1)
                 for k, v in models.items():
                     name, src = k.split("/")
