@@ -362,3 +362,96 @@ def test_fused_reference_block_with_syncbatchnorm_matches_global_batch(oracle_ba
     assert np.allclose(got[0][3] + got[1][3], ref.net[1].weight.grad.numpy(), rtol=1e-4, atol=1e-5)
     assert np.allclose(got[0][4], ref.net[4].running_var.numpy(), rtol=1e-5) and np.allclose(got[1][4], got[0][4])
     assert got[0][5] == got[1][5] == int(ref.net[1].num_batches_tracked) == 1
+
+
+# ---- the reference's whole MinkUNet (IF_DIST=True) under fuse + DDP over two ranks vs one process on the concatenated batch ---------
+_MK_DDP = dict(NAME="MinkUNet", IGNORE_LABEL=0, IN_FEATURE_DIM=4, BLOCK="ResBlock", NUM_LAYER=[1] * 8,
+               PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96], cr=0.25, DROPOUT_P=0.0, LABEL_SMOOTHING=0.0)
+
+
+def _ref_minkunet(if_dist):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import make_golden as mg
+    import openpcseg_amd
+    from seeded import seeded_state
+    openpcseg_amd.install_reference_aliases()
+    mod = mg.import_reference_model("pcseg.model.segmentor.voxel.minkunet.minkunet")
+    model = mod.MinkUNet(mg._AttrDict(dict(_MK_DDP, IF_DIST=if_dist)), 20)
+    seeded_state(model)
+    return model.train()
+
+
+def _ddp_frames():
+    from openpcseg_amd.workloads.synthetic import make_batch
+    return make_batch([31, 32], n_points=1200)
+
+
+def _fused_ddp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    _patch()
+    torch.Tensor.cuda = lambda self, *a, **k: self        # the reference's forward calls .cuda() on the targets
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import openpcseg_amd
+    from openpcseg_amd.sparse import SparseTensor
+    b = _ddp_frames()
+    sel = b["lidar"].C[:, 3] == rank                      # one whole frame per rank (DistributedSampler), batch index 0 on each rank
+    coords = b["lidar"].C[sel].clone()
+    coords[:, 3] = 0
+    model = _ref_minkunet(if_dist=True)
+    counts = openpcseg_amd.fuse(model)
+    assert counts["residual"] == 8 and counts["forward"] == 1
+    # DistributedDataParallel refuses host modules that hold SyncBatchNorm layers ("only work with GPU modules"), so its one data-path
+    # action -- averaging the gradients over the ranks -- is done by hand here; the GPU form is bench.py's / the RCCL tests'
+    ret = model({"lidar": SparseTensor(b["lidar"].F[sel].clone(), coords), "targets": SparseTensor(b["targets"].F[sel], coords), "offset": None})
+    ret[0]["loss"].backward()
+    for p in model.parameters():
+        if p.grad is not None:
+            dist.all_reduce(p.grad)
+            p.grad /= world
+    if rank == 0:
+        q.put(({n: p.grad.numpy().copy() for n, p in model.named_parameters() if p.grad is not None},
+               {n: t.numpy().copy() for n, t in model.named_buffers() if t.dtype.is_floating_point}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fused_reference_minkunet_under_ddp_matches_the_concatenated_batch(oracle_backend, monkeypatch):
+    """What `R:train.py:215-219` builds -- gradient averaging around the model, SyncBatchNorm inside (IF_DIST=True) -- with the model
+    fused by `openpcseg_amd.fuse`: two ranks with one frame each over gloo. Per-frame mean losses averaged over the ranks = the gradient of
+    0.5 (loss_0 + loss_1) with BatchNorm statistics over both frames: reproduced in ONE process by the unfused model with plain
+    BatchNorm on the two-frame batch, backpropagating the two per-frame losses. Running statistics agree as well."""
+    if not os.path.isdir("/root/reference") and not os.path.isdir(os.path.join(ROOT, "tests", "_refsrc")):
+        pytest.skip("reference sources not present")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fused_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    grads, bufs = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    from openpcseg_amd.sparse import SparseTensor
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    b = _ddp_frames()
+    ref = _ref_minkunet(if_dist=False)
+    crit = ref.criterion_losses
+    seen = {}
+    # the criterion is a per-frame mean on each rank: evaluate it per frame on the logits of the two-frame forward
+    crit.register_forward_pre_hook(lambda m, a: seen.__setitem__("logits", a[0]))
+    ref({"lidar": SparseTensor(b["lidar"].F.clone(), b["lidar"].C), "targets": SparseTensor(b["targets"].F, b["lidar"].C), "offset": None})
+    logits, tgt, fid = seen["logits"], b["targets"].F.long(), b["lidar"].C[:, 3]
+    loss = 0.5 * (crit(logits[fid == 0], tgt[fid == 0]) + crit(logits[fid == 1], tgt[fid == 1]))
+    loss.backward()
+    G = float(np.median([float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None]))
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        scale = max(float(p.grad.abs().max()), 1e-3 * G)
+        assert np.abs(grads[n] - p.grad.numpy()).max() <= 2e-3 * scale, n
+    for n, t in ref.named_buffers():
+        if t.dtype.is_floating_point:
+            assert np.allclose(bufs[n], t.numpy(), rtol=1e-4, atol=1e-6), n

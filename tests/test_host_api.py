@@ -402,3 +402,41 @@ def test_step_budget_tools(tmp_path):
     out = subprocess.run([_sys.executable, os.path.join(tools, "step_budget.py"), str(d), "4", "t"], check=True, capture_output=True, text=True).stdout
     assert "| conv fwd / dgrad (fused gather-GEMM-scatter) | 10 | 10.00 |" in out
     assert "| copies / fills (runtime) | 20 | 0.08 |" in out and "| BatchNorm" in out and "| **total** | **93** |" in out
+
+
+def test_sparse_quantize_frames_host_logic(monkeypatch):
+    """hostdata.sparse_quantize_frames / workloads.synthetic.device_collate: the key construction -- one
+    lexicographic key with the frame on top orders every frame like its own ravel hash -- against the per-frame NumPy path
+    (make_batch), with the backend's sort / flag / scan / emit pass restated in torch (the HIP pass itself: -m gpu,
+    test_device_input_pipeline_matches_the_host_dataloader). Equal-length, ragged and single-frame batches."""
+    import torch
+    from openpcseg_amd import native
+    from openpcseg_amd.workloads import synthetic as syn
+
+    class TorchPass:
+        def quantize_sorted_keys(self, keys, coords, frames):
+            skeys, perm = torch.sort(keys, stable=True)
+            flags = torch.ones_like(skeys)
+            flags[1:] = (skeys[1:] != skeys[:-1]).long()
+            rank = torch.cumsum(flags, 0)
+            index = perm[flags.bool()]
+            inverse = torch.empty_like(keys)
+            inverse[perm] = rank - 1
+            return torch.cat([coords[index], frames[index].int()[:, None]], 1), index, inverse
+
+    monkeypatch.setattr(native, "_BACKEND", TorchPass())
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))   # the entry point refuses host tensors: no CPU path
+    for seeds, npts in (([3, 4, 5], 6000), ([7], 3000)):
+        d = syn.device_collate(syn.make_raw_batch(seeds, n_points=npts))
+        b = syn.make_batch(seeds, n_points=npts)
+        assert torch.equal(d["lidar"].C, b["lidar"].C) and torch.equal(d["lidar"].F, b["lidar"].F)
+        assert torch.equal(d["targets"].F, b["targets"].F)
+    raw = syn.make_raw_batch([3, 4], n_points=4000)           # ragged: the second frame keeps 2 500 of its rows
+    keep = torch.cat([torch.arange(0, 4000), torch.arange(4000, 6500)])
+    rag = {"points": raw["points"][keep], "frames": raw["frames"][keep], "labels": raw["labels"][keep], "num_frames": 2,
+           "offsets": [0, 4000, 6500]}
+    d = syn.device_collate(rag)
+    from openpcseg_amd.hostdata import sparse_collate_fn
+    frames = [syn.voxelize_scan(rag["points"][a:b].numpy(), seed=0) for a, b in ((0, 4000), (4000, 6500))]
+    ref = sparse_collate_fn(frames)
+    assert torch.equal(d["lidar"].C, ref["lidar"].C) and torch.equal(d["lidar"].F, ref["lidar"].F)
