@@ -135,6 +135,31 @@ def main():
         add("range denselize bwd C=32, gather form", "pcs_denselize_bwd_f32", timed(lambda: be.denselize_bwd_gather(g32, cm, pxpy), reps),
             4 * 32 * (n + b * h * w_) + 12 * n, "reference dataflow, kept for A/B")
 
+    # ---- [r5] range image -> points (csrc/rangesample.hip) at RPVNet's shapes (4 frames of ~97 k points) ---------------------------
+    if not DRY:
+        nb = 4
+        npnt = min(n, 390000)
+        fpx = torch.cat([torch.sort(torch.randint(0, nb, (npnt,), generator=g)).values.float()[:, None],
+                         torch.rand(npnt, 2, generator=g) * 2 - 1], 1).to(dev).contiguous()
+        for c, hh, ww in ((56, 64, 2048), (168, 64, 2048), (224, 16, 512), (448, 4, 128)):
+            img = torch.randn(nb, c, hh, ww, device=dev)
+            gp = torch.randn(npnt, c, device=dev)
+            touched = min(nb * hh * ww, 4 * npnt)
+            add("range_to_point C=%d %dx%d" % (c, hh, ww), "pcs_range_sample_fwd_f32", timed(lambda: be.range_sample_fwd(img, fpx), reps),
+                4 * c * (npnt + touched) + 12 * npnt, "bilinear gather: 4 plane reads per (point, channel), mostly L2 hits")
+            be.range_sample_bwd(gp, fpx, nb, hh, ww)   # builds and caches the corner CSR
+            add("range_to_point bwd C=%d %dx%d" % (c, hh, ww), "pcs_range_sample_bwd_csr_f32",
+                timed(lambda: be.range_sample_bwd(gp, fpx, nb, hh, ww), reps), 4 * c * (npnt + nb * hh * ww) + 36 * npnt,
+                "atomic-free; corner CSR cached on pxpy (torch's grid_sampler_2d_backward: ~15 ms per call at C=168)")
+        # ---- [r5] device input pipeline: 12 raw scans -> voxelised, collated batch (hostdata.sparse_quantize_frames) -------------
+        from openpcseg_amd.workloads.synthetic import device_collate, make_raw_batch
+        raw = make_raw_batch(list(range(frames)))
+        raw = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in raw.items()}
+        npts = raw["points"].shape[0]
+        mv = device_collate(raw)["lidar"].C.shape[0]
+        add("device input: transform + quantize + collate, %d scans" % frames, "pcs_quantize_flags / _emit + one sort", timed(lambda: device_collate(raw), reps),
+            16 * npts + 8 * npts + 12 * npts + (16 + 16 + 8) * mv, "raw points in, (voxels, features, labels) out; bound by the radix sort's passes")
+
     # ---- fused BatchNorm -------------------------------------------------------------------------------------
     for c in (32, 96, 256):
         rows_n = m if c < 256 else m // 8
