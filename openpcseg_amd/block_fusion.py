@@ -30,7 +30,8 @@ interchangeable both ways; `unfuse(model)` restores the original forwards):
     re-bound, in the MODEL module's namespace, to this package's equivalents (workloads/pointvoxel.py: unique + query + count from
     one stable sort, the whole trilinear corner map in one kernel, the level's cached hash table) -- only when their source text
     is byte-identical to the reference's (SHA-1 below), i.e. when it is known exactly what they compute;
-    likewise `range_to_point` of rpvnet.py:31-51 (a python loop of `F.grid_sample` per frame, whose torch backward -- channel
+    likewise `point_to_range` (rpvnet.py:73-91: its `torch.Tensor([w-1, h-1]).cuda()` is a device synchronisation per call) and
+    `range_to_point` of rpvnet.py:31-51 (a python loop of `F.grid_sample` per frame, whose torch backward -- channel
     loops of float atomics into NCHW planes -- is 25 % of an RPVNet step) -> `rangelib.range_to_point` (csrc/rangesample.hip);
   * [forward] a model whose class is named MinkUNet and whose `forward` source is byte-identical to
     R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:385-434 runs, in training mode, the same graph with the classifier applied
@@ -447,6 +448,7 @@ _MINKUNET_FORWARD_SHA1 = "e5ef7d830c649b15021924421d95424e7a0501c8"
 # R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:31-51: range_to_point = resample_grid_stacked = grid_sample per frame
 _RANGE_TO_POINT_SHA1 = {"range_to_point": "84c1b2d60560e333892da86ed6372b6a55585c61",
                         "resample_grid_stacked": "c0f10770b7114ddf6cd1193e721fea602d6b905f"}
+_POINT_TO_RANGE_SHA1 = "749449227dbd17dc3db119ac55bef79a4e68ac59"   # rpvnet.py:73-91
 
 
 def _source_sha1(fn):
@@ -505,6 +507,13 @@ def _fuse_glue(model):
                 all(_source_sha1(ns.__dict__.get(k)) == v for k, v in _RANGE_TO_POINT_SHA1.items())):
             setattr(ns, "range_to_point", _range_to_point_via(r2p))
             _GLUE_ORIG[(modname, "range_to_point")] = r2p
+            n += 1
+        p2r = ns.__dict__.get("point_to_range")
+        if (inspect.isfunction(p2r) and not getattr(p2r, "__module__", "").startswith("openpcseg_amd") and
+                _source_sha1(p2r) == _POINT_TO_RANGE_SHA1):
+            from .rangelib import point_to_range
+            setattr(ns, "point_to_range", point_to_range)   # no host-to-device copy (= device synchronisation) per call
+            _GLUE_ORIG[(modname, "point_to_range")] = p2r
             n += 1
     return n
 

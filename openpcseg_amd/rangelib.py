@@ -79,6 +79,20 @@ def range_to_point(feature_map, pxpy, grid_sample_mode="bilinear", fallback=None
     return _RangeToPoint.apply(feature_map, pxpy)
 
 
+def point_to_range(pf, pxpy, b, h, w):
+    """(B, C, H, W) range feature map from point features: R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:73-91 -- pixel of a point =
+    trunc((p + 1) / 2 * (size - 1)) per axis, then map_count + denselize -- without its `torch.Tensor([w-1, h-1]).cuda()` (a pageable
+    host-to-device copy: a full device synchronisation, four times per RPVNet step). Same float32 arithmetic per element (the reference
+    broadcasts a (2,) float32 tensor, here each column meets its python scalar), so the integer pixels are identical. The integer
+    coordinates are cached on the pxpy tensor per resolution: forward, backward and the next call on the same tensor share one pixel CSR."""
+    def make():
+        px = (pxpy[:, 1] + 1) / 2 * float(w - 1)
+        py = (pxpy[:, 2] + 1) / 2 * float(h - 1)
+        return torch.stack([pxpy[:, 0], px, py], dim=1).int().contiguous()
+    int_pxpy = native._cached(pxpy, "_pcs_int_pxpy_%dx%d" % (h, w), native._cache_key(pxpy), make)
+    return denselize(pf, map_count(int_pxpy, b, h, w), int_pxpy)
+
+
 def install_as_range_utils():
     fn = types.ModuleType("range_utils.nn.functional")
     fn.map_count, fn.denselize = map_count, denselize

@@ -219,3 +219,32 @@ def test_kmap_entry_reads_like_the_reference_list(golden, oracle_backend):
     nbmaps, nbsizes, sizes = entry
     assert np.array_equal(nbmaps.numpy(), golden["kmap_k3s1_nbmaps"]) and np.array_equal(nbsizes.numpy(), golden["kmap_k3s1_nbsizes"])
     assert sizes == (c.shape[0], c.shape[0]) and entry[0] is nbmaps and entry[-1] == sizes and entry[1] is nbsizes
+
+
+def test_point_to_range_matches_the_reference_function(oracle_backend, monkeypatch):
+    """rangelib.point_to_range (no host-to-device copy per call) against the reference's own `point_to_range`
+    (R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:73-91) run on CPU over the same backend: identical integer pixels -> identical maps."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    from stage_reference import reference_root
+    if reference_root() is None:
+        pytest.skip("reference sources not present")
+    import make_golden as mg
+    import openpcseg_amd
+    from openpcseg_amd import rangelib
+    openpcseg_amd.install_reference_aliases()
+    mod = mg.import_reference_model("pcseg.model.segmentor.fusion.rpvnet.rpvnet")
+    mod.rnf = sys.modules["range_utils.nn.functional"]
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    rng = np.random.default_rng(5)
+    n, b, c = 4000, 2, 8
+    pxpy = torch.from_numpy(np.concatenate([np.sort(rng.integers(0, b, n))[:, None].astype(np.float32),
+                                            rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)], 1))
+    pxpy[:6, 1:] = torch.tensor([[-1.0, -1.0], [1.0, 1.0], [0.0, 0.0], [1.0, -1.0], [0.999999, 0.5], [-0.999999, -0.5]])
+    pf = torch.from_numpy(rng.normal(size=(n, c)).astype(np.float32))
+    for h, w in ((64, 2048), (16, 512), (4, 128)):
+        ref = mod.point_to_range(pf, pxpy, b, h, w)
+        got = rangelib.point_to_range(pf, pxpy, b, h, w)
+        assert got.shape == (b, c, h, w) and torch.equal(got, ref), (h, w)
