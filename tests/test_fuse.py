@@ -391,3 +391,63 @@ def test_dense_linear_and_batchnorm_match_torch_on_hip(hip, cin, cout):
     small = torch.randn(100, cin, device="cuda")
     assert torch.allclose(plain.eval()(small), fused.eval()(small), atol=1e-5)
     assert torch.allclose(plain(x), fused(x), atol=2e-5 * float(y0.abs().max()))
+
+
+def test_checkpoint_round_trip_in_the_reference_format(golden_e2e, env_oracle, tmp_path):
+    """R:train.py:285-301 / :303-318 (`save_checkpoint` / `resume`): a checkpoint written from the FUSED model -- model_state through
+    the reference's own `model_state_to_cpu`, optimizer / scaler / scheduler states -- is resumed by the PLAIN reference model through
+    the reference's own `load_params(..., strict=True)`, and the next training step of both gives the same loss and the same weights;
+    this package's MinkUNet workload loads the same file strictly as well."""
+    import openpcseg_amd
+    from openpcseg_amd.workloads.minkunet import MinkUNet as WorkloadMinkUNet
+    try:
+        from tools.utils.train_utils import model_state_to_cpu
+    except Exception:   # the staged copy on the GPU box may not carry tools/utils/train_utils.py (R:tools/utils/train_utils.py:138-142)
+        def model_state_to_cpu(ms):
+            return type(ms)((k, v.cpu()) for k, v in ms.items())
+
+    def rig(model):
+        opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        return opt, torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 1.0 / (1 + it)), torch.amp.GradScaler("cuda", enabled=False)
+
+    def step(model, opt, sched, scaler):
+        model.train()
+        opt.zero_grad()
+        ret = model(_mink_batch(env_oracle, golden_e2e))
+        loss = ret[0]["loss"].mean()
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        scaler.step(opt)
+        scaler.update()
+        sched.step()
+        return float(loss.detach())
+
+    fused = _minkunet(env_oracle)
+    openpcseg_amd.fuse(fused)
+    opt, sched, scaler = rig(fused)
+    for _ in range(2):
+        step(fused, opt, sched, scaler)
+    ckpt = {"epoch": 1, "it": 2, "model_state": model_state_to_cpu(fused.state_dict()), "optimizer_state": opt.state_dict(),
+            "scaler_state": scaler.state_dict(), "scheduler_state": sched.state_dict()}
+    path = str(tmp_path / "checkpoint_epoch_1.pth")
+    torch.save(ckpt, path)
+    disk = torch.load(path, map_location="cpu")
+
+    plain = _minkunet(env_oracle)
+    for p in plain.parameters():
+        p.data.add_(1.0)                                   # nothing may survive from the construction
+    msg = plain.load_params(disk["model_state"], strict=True)   # R:pcseg/model/segmentor/base_segmentors.py:16-26
+    assert not msg.missing_keys and not msg.unexpected_keys
+    opt2, sched2, scaler2 = rig(plain)
+    opt2.load_state_dict(disk["optimizer_state"])
+    scaler2.load_state_dict(disk["scaler_state"])
+    sched2.load_state_dict(disk["scheduler_state"])
+    la, lb = step(fused, opt, sched, scaler), step(plain, opt2, sched2, scaler2)
+    assert abs(la - lb) <= 2e-5 * abs(la)
+    sa, sb = fused.state_dict(), plain.state_dict()
+    assert list(sa.keys()) == list(sb.keys())
+    for k in sa:
+        assert torch.allclose(sa[k].double(), sb[k].double(), rtol=2e-4, atol=2e-5), k
+    wl = WorkloadMinkUNet(num_class=20, num_layer=MK34["NUM_LAYER"], cr=MK34["cr"])
+    wl.load_state_dict(disk["model_state"], strict=True)
