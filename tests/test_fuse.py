@@ -309,17 +309,23 @@ def test_fused_equals_plain_step_on_hip(golden_e2e, env_hip):
 
 
 @pytest.mark.gpu
-def test_fused_equals_plain_step_on_hip_bf16(golden_e2e, env_hip):
-    """Under autocast both routes store bf16 activations; the fused passes round once where torch rounds per op."""
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_fused_equals_plain_step_on_hip_bf16(golden_e2e, env_hip, dtype):
+    """Under autocast (the reference's `--amp`: fp16; bf16 as well) both routes store 16-bit activations; the fused passes round once
+    where torch rounds per op. Compared with each other and with the reference's fp32 logits."""
     import openpcseg_amd
     plain, fused = _minkunet(env_hip), _minkunet(env_hip)
     openpcseg_amd.fuse(fused)
-    a = _step(plain, _mink_batch(env_hip, golden_e2e), torch.bfloat16)
-    b = _step(fused, _mink_batch(env_hip, golden_e2e), torch.bfloat16)
+    a = _step(plain, _mink_batch(env_hip, golden_e2e), dtype)
+    b = _step(fused, _mink_batch(env_hip, golden_e2e), dtype)
     rms = float(np.sqrt((a[0].astype(np.float64) ** 2).mean()))
-    assert np.abs(a[0] - b[0]).max() < 0.35 * rms and np.abs(a[0] - b[0]).mean() < 0.03 * rms
+    k = 1.0 if dtype == torch.bfloat16 else 0.25          # fp16 keeps three more mantissa bits
+    assert np.abs(a[0] - b[0]).max() < 0.35 * k * rms and np.abs(a[0] - b[0]).mean() < 0.03 * k * rms
     assert (a[0].argmax(1) == b[0].argmax(1)).mean() > 0.95
     assert abs(a[1] - b[1]) < 0.03 * abs(a[1])
+    ref = golden_e2e["logits"]
+    assert np.abs(b[0] - ref).mean() < 0.03 * k * rms and np.isfinite(b[1])
+    assert all(torch.isfinite(g).all() for g in b[2].values())
 
 
 @pytest.mark.gpu
