@@ -33,6 +33,8 @@ interchangeable both ways; `unfuse(model)` restores the original forwards):
     likewise `point_to_range` (rpvnet.py:73-91: its `torch.Tensor([w-1, h-1]).cuda()` is a device synchronisation per call) and
     `range_to_point` of rpvnet.py:31-51 (a python loop of `F.grid_sample` per frame, whose torch backward -- channel
     loops of float atomics into NCHW planes -- is 25 % of an RPVNet step) -> `rangelib.range_to_point` (csrc/rangesample.hip);
+  * [forward] SPVCNN (spvcnn.py:399-456, SHA-1 of its source): the classifier over `cat([z1.F, z2.F, z3.F])` as three column blocks
+    of the Linear, without the (N, 480) concatenation;
   * [forward] a model whose class is named MinkUNet and whose `forward` source is byte-identical to
     R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:385-434 runs, in training mode, the same graph with the classifier applied
     on the voxels before the trilinear interpolation (`fused.devoxelized_linear`: interpolation and the Linear commute; the
@@ -207,11 +209,13 @@ class _PointLinear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         from .functional import _amp_dtype
         hd = _amp_dtype(x)
-        ctx.save_for_backward(x, weight)
-        ctx.hd, ctx.has_bias = hd, bias is not None
+        ctx.hd, ctx.has_bias, ctx.in_dtype = hd, bias is not None, x.dtype
         if hd is None:
+            ctx.save_for_backward(x, weight)
             return torch.nn.functional.linear(x.float(), weight.float(), bias.float() if bias is not None else None)
-        return torch.nn.functional.linear(x.to(hd), weight.to(hd), bias.to(hd) if bias is not None else None)
+        xh = x.to(hd)   # kept for the weight gradient: one conversion of the (N, C_in) rows instead of one per direction
+        ctx.save_for_backward(xh, weight)
+        return torch.nn.functional.linear(xh, weight.to(hd), bias.to(hd) if bias is not None else None)
 
     @staticmethod
     def backward(ctx, dy):
@@ -221,7 +225,7 @@ class _PointLinear(torch.autograd.Function):
         hd = ctx.hd
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = (dy.float().matmul(weight.float()) if hd is None else dy.to(hd).matmul(weight.to(hd))).to(x.dtype)
+            gx = (dy.float().matmul(weight.float()) if hd is None else dy.to(hd).matmul(weight.to(hd))).to(ctx.in_dtype)
         if ctx.needs_input_grad[1]:
             if len(_POINT_MAPS) > 4:
                 _POINT_MAPS.clear()
@@ -445,6 +449,7 @@ _GLUE_SHA1 = {"initial_voxelize": "d86d7900a8d70be1746f57eb311959ae0e23770a",
               "voxel_to_point": "ab9c4461fe068ac54a5105b96b90072206bb1f82",
               "point_to_voxel": "546ed12789757812f69502843a6d5bd4216130af"}
 _MINKUNET_FORWARD_SHA1 = "e5ef7d830c649b15021924421d95424e7a0501c8"
+_SPVCNN_FORWARD_SHA1 = "905bca0f3105c02f8d55f691f6d266f5a8558d98"     # R:pcseg/model/segmentor/fusion/spvcnn/spvcnn.py:399-456
 # R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:31-51: range_to_point = resample_grid_stacked = grid_sample per frame
 _RANGE_TO_POINT_SHA1 = {"range_to_point": "84c1b2d60560e333892da86ed6372b6a55585c61",
                         "resample_grid_stacked": "c0f10770b7114ddf6cd1193e721fea602d6b905f"}
@@ -568,7 +573,77 @@ def _minkunet_forward(self, batch_dict, return_logit=False, return_tta=False):
     return {"loss": loss}, {"loss": value}, {"loss": value}
 
 
+def _spvcnn_forward(self, batch_dict, return_logit=False, return_tta=False):
+    """Training-mode forward of the reference's SPVCNN (R:pcseg/model/segmentor/fusion/spvcnn/spvcnn.py:399-456), line by line, with
+    ONE change: `classifier(torch.cat([z1.F, z2.F, z3.F], 1))` is evaluated as the sum of the three column blocks of the Linear
+    (`fused._SkinnyLinearParts`): the (N, 480) concatenation of 1.9 M point rows -- 3.7 GB written and read back, and sliced again in
+    backward -- is never built. Eval mode, other `multi_scale` settings and hooked classifiers take the reference's forward."""
+    from . import sparse as ts
+    from .fused import _SkinnyLinearParts
+    from .workloads.pointvoxel import initial_voxelize, point_to_voxel, voxel_to_point
+    lin = self.classifier[0] if isinstance(self.classifier, nn.Sequential) and len(self.classifier) == 1 else None
+    x = batch_dict["lidar"]
+    if not (self.training and isinstance(lin, nn.Linear) and x.F.is_cuda and getattr(self, "multi_scale", None) == "concat" and
+            _quiet(lin) and _quiet(self.classifier) and lin.out_features % 4 == 0 and hasattr(native.backend(), "corner_map") and
+            os.environ.get("PCS_CLASSIFIER_PARTS", "1") != "0"):
+        return self.__dict__["_pcs_orig_class"].forward(self, batch_dict, return_logit, return_tta)
+    x.F = x.F[:, :self.in_feature_dim]
+    z = ts.PointTensor(x.F, x.C.float())
+    x0 = initial_voxelize(z, self.pres, self.vres)
+    x0 = self.stem(x0)
+    z0 = voxel_to_point(x0, z, nearest=False)
+    x1 = point_to_voxel(x0, z0)
+    x1 = self.stage1(x1)
+    x2 = self.stage2(x1)
+    x3 = self.stage3(x2)
+    x4 = self.stage4(x3)
+    z1 = voxel_to_point(x4, z0)
+    z1.F = z1.F + self.point_transforms[0](z0.F)
+    y1 = point_to_voxel(x4, z1)
+    y1.F = self.dropout(y1.F)
+    y1 = self.up1[0](y1)
+    y1 = ts.cat([y1, x3])
+    y1 = self.up1[1](y1)
+    y2 = self.up2[0](y1)
+    y2 = ts.cat([y2, x2])
+    y2 = self.up2[1](y2)
+    z2 = voxel_to_point(y2, z1)
+    z2.F = z2.F + self.point_transforms[1](z1.F)
+    y3 = point_to_voxel(y2, z2)
+    y3.F = self.dropout(y3.F)
+    y3 = self.up3[0](y3)
+    y3 = ts.cat([y3, x1])
+    y3 = self.up3[1](y3)
+    y4 = self.up4[0](y3)
+    y4 = ts.cat([y4, x0])
+    y4 = self.up4[1](y4)
+    z3 = voxel_to_point(y4, z2)
+    z3.F = z3.F + self.point_transforms[2](z2.F)
+    parts = [z1.F, z2.F, z3.F]
+    if (all(p.dim() == 2 and p.shape[1] % 4 == 0 and p.dtype in (torch.float32, torch.bfloat16, torch.float16) for p in parts) and
+            parts[0].shape[0] >= 4096 and sum(p.shape[1] for p in parts) == lin.in_features):
+        hd = next((p.dtype for p in parts if p.dtype != torch.float32), None)
+        if hd is None and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16):
+            hd = torch.get_autocast_dtype("cuda")
+        if len(_POINT_MAPS) > 4:
+            _POINT_MAPS.clear()
+        out = _SkinnyLinearParts.apply(lin.weight, lin.bias, _POINT_MAPS, hd, *parts)
+    else:
+        out = self.classifier(torch.cat(parts, dim=1))
+    target = batch_dict["targets"].F.long().cuda(non_blocking=True)
+    coords_xyz = batch_dict["lidar"].C[:, :3].float()
+    loss = self.criterion_losses(out, target, xyz=coords_xyz, offset=batch_dict["offset"])
+    value = loss.item()
+    return {"loss": loss}, {"loss": value}, {"loss": value}
+
+
 def _fuse_model_forward(m, undo):
+    if (type(m).__name__ == "SPVCNN" and not getattr(type(m), "_pcs_fused_class", False) and
+            _source_sha1(type(m).forward) == _SPVCNN_FORWARD_SHA1 and
+            all(hasattr(m, a) for a in ("stem", "stage1", "stage4", "up1", "up4", "classifier", "dropout", "criterion_losses",
+                                        "point_transforms", "in_feature_dim", "pres", "vres", "multi_scale"))):
+        _reclass(m, _spvcnn_forward, None, undo)
+        return 1
     if (type(m).__name__ == "MinkUNet" and not getattr(type(m), "_pcs_fused_class", False) and
             _source_sha1(type(m).forward) == _MINKUNET_FORWARD_SHA1 and
             all(hasattr(m, a) for a in ("stem", "stage1", "stage4", "up1", "up4", "classifier", "dropout", "criterion_losses",

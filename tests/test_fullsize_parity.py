@@ -145,7 +145,7 @@ def _reference_step_on_hip(cfg, fuse):
             assert counts["dense"] >= 40 and counts["criterion"] == 3, counts
         else:
             assert counts["residual"] >= 16 and counts["criterion"] == 2 and counts["glue"] >= 2, counts
-        assert counts["forward"] == (1 if "MinkUNet" in fs.MODEL_PATH[cfg][1] else 0), counts
+        assert counts["forward"] == (1 if fs.MODEL_PATH[cfg][1] in ("MinkUNet", "SPVCNN") else 0), counts
     try:
         logits, loss = fs.run_train_step(cfg, model, batch, via="criterion" if fuse else "classifier")
     finally:
