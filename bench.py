@@ -407,16 +407,17 @@ def preheat(step, distributed, dev, window=10, max_windows=40):
     least three windows, at most `max_windows`); with several ranks the decision is shared so that every rank runs the
     same number of steps.
     The K timed steps that follow are full, unmodified steps. PCS_BENCH_PREHEAT=0 skips this.
-    [r5] The FIRST record measured in a process additionally holds the load for at least PCS_BENCH_PREHEAT_MIN_S seconds (default 20):
-    one box of the pool ran its first ~10 s at a constant 1.08x slower rate per launch (a plateau, not a ramp: three equal windows
-    ended the pre-heat after 4 s) and every later record of the same process at full speed."""
+    [r5] The FIRST record measured in a process additionally holds the load for at least PCS_BENCH_PREHEAT_MIN_S seconds (default 60):
+    boxes of the pool ran the first 10 ... 40 s of a fresh process at a constant 1.08-1.2x slower rate per launch (a plateau, not a
+    ramp: three equal windows ended the pre-heat after 4 s) and every later record of the same process at full speed
+    (profiles/round5_bench_first_record_slow_state.log, round5_bench_second_box_long_slow_state.log)."""
     if os.environ.get("PCS_BENCH_PREHEAT", "1") == "0":
         return
-    min_s = 0.0 if _PREHEATED["done"] else float(os.environ.get("PCS_BENCH_PREHEAT_MIN_S", "20"))
+    min_s = 0.0 if _PREHEATED["done"] else float(os.environ.get("PCS_BENCH_PREHEAT_MIN_S", "60"))
     _PREHEATED["done"] = True
     t_start = time.perf_counter()
-    prev = None
-    for wi in range(max_windows):
+    prev, wi = None, 0
+    while True:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(window):
@@ -425,12 +426,14 @@ def preheat(step, distributed, dev, window=10, max_windows=40):
         cur = (time.perf_counter() - t0) / window
         if os.environ.get("PCS_BENCH_PREHEAT_LOG") == "1":
             print("preheat window: %.1f ms/step" % (cur * 1e3), file=sys.stderr, flush=True)
-        go = 1 if (wi < 2 or cur < 0.996 * prev or time.perf_counter() - t_start < min_s) else 0
+        held = time.perf_counter() - t_start >= min_s          # the minimum hold counts in seconds, not in windows
+        improving = wi < 2 or cur < 0.996 * prev
+        go = 1 if (not held or (improving and wi + 1 < max_windows)) else 0
         if distributed:
             flag = torch.tensor([go], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             go = int(flag.item())
-        prev = cur
+        prev, wi = cur, wi + 1
         if not go:
             break
 
@@ -639,6 +642,18 @@ def main():
             if distributed:
                 dist.barrier()
             torch.cuda.synchronize()
+            base_dt = None
+            if device_input:
+                # the same model from the pre-voxelised batch, back to back with the timed device-input steps: the difference of the
+                # two is the input work, measured in one thermal / clock state (two separately measured records differ by +-1 ms and,
+                # on a box still ramping, by far more)
+                t0 = time.perf_counter()
+                device_input = False
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                base_dt = time.perf_counter() - t0
+                device_input = True
             meter.enabled = True
             with ClockSampler(dev_index) as clocks:
                 t0 = time.perf_counter()
@@ -666,7 +681,8 @@ def main():
         pcsF.set_wgrad_policy("fp32")
         frames = args.frames_per_gpu * world * args.steps
         return {"value": round(frames / dt, 3), "ms_per_step": round(dt / args.steps * 1e3, 2),
-                "loss": round(float(loss.detach()), 4), "roofline": roof, "comm": comm}
+                "loss": round(float(loss.detach()), 4), "roofline": roof, "comm": comm,
+                "base_ms_per_step": None if base_dt is None else round(base_dt / args.steps * 1e3, 2)}
 
     def workload(amp):
         return ("MinkUNet-34 cr1.0 train step (fwd + CE/Lovasz + bwd + SGD), SemanticKITTI-shape synthetic scans "
@@ -699,7 +715,7 @@ def main():
             device_collate(raw_dev)
         torch.cuda.synchronize()
         dev_in = {"dtype": d_amp or "f32", "value": di["value"], "ms_per_step": di["ms_per_step"],
-                  "input_ms_per_step": round(di["ms_per_step"] - base["ms_per_step"], 2),   # difference of two separately measured steps
+                  "input_ms_per_step": round(di["ms_per_step"] - di["base_ms_per_step"], 2),   # vs the same model from the pre-voxelised batch, back to back
                   "collate_ms": round((time.perf_counter() - t0) / 20 * 1e3, 2),              # the device pass alone, 12 frames
                   "loss": di["loss"]}
     models = None
