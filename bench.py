@@ -533,9 +533,9 @@ def main():
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-pytorch-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--models", default="auto",
-                    help="secondary `models` record: comma list of {minkunet18,spvcnn18,cylinder,rpvnet34,minkunet34}[:reference|workload], "
-                         "'auto' (N = 1 default run: the reference's four segmentor sources unmodified on the HIP backend + the fused "
-                         "MinkUNet-18 workload) or 'none'")
+                    help="secondary `models` record: comma list of {minkunet18,spvcnn18,cylinder,rpvnet34,minkunet34}[:reference|fuse|workload], "
+                         "'auto' (N = 1 default run: the reference's segmentor sources on the HIP backend, unmodified and after "
+                         "openpcseg_amd.fuse, + the fused MinkUNet-18 workload) or 'none'")
     ap.add_argument("--device-input", action="store_true",
                     help="the `device_input` record for THIS run's dtype: every timed step starts from the raw (120000, 4) scans in HBM "
                          "(round / shift / sparse_quantize / collate of all frames on the device); the default fp32 run carries the bf16 one")
