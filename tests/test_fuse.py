@@ -457,3 +457,37 @@ def test_checkpoint_round_trip_in_the_reference_format(golden_e2e, env_oracle, t
         assert torch.allclose(sa[k].double(), sb[k].double(), rtol=2e-4, atol=2e-5), k
     wl = WorkloadMinkUNet(num_class=20, num_layer=MK34["NUM_LAYER"], cr=MK34["cr"])
     wl.load_state_dict(disk["model_state"], strict=True)
+
+
+def test_bottleneck_block_is_recognised_too(golden_e2e, env_oracle):
+    """R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:132-186 (the `Bottleneck` block, the default of `BLOCK` when a config does not
+    name one): 1x1x1 -> k3 -> 1x1x1 convolutions with BatchNorms and no inner ReLU, `relu(net(x) + downsample(x))`. Fused vs plain on
+    the same weights: output, input gradient, every parameter gradient, BatchNorm buffers."""
+    import openpcseg_amd
+    from openpcseg_amd.sparse import SparseTensor
+    from seeded import seeded_state
+    _, mod = _load("pcseg.model.segmentor.voxel.minkunet.minkunet")
+    coords = env_oracle.t(golden_e2e["coords"])
+    torch.manual_seed(2)
+    feats = torch.randn(coords.shape[0], 16)
+    outs = []
+    for fuse in (False, True):
+        blk = mod.Bottleneck(16, 8)          # 16 -> 8 x 4 = 32 channels: the variant with a downsample branch
+        seeded_state(blk)
+        blk.train()
+        if fuse:
+            counts = openpcseg_amd.fuse(blk)
+            assert counts["residual"] == 1 and counts["conv_bn"] == 4, counts
+        x = feats.clone().requires_grad_(True)
+        y = blk(SparseTensor(x, coords)).F
+        (y * torch.arange(1, 33)).sum().backward()
+        outs.append((y.detach(), x.grad, {n: p.grad for n, p in blk.named_parameters() if p.grad is not None},
+                     {n: b.clone() for n, b in blk.named_buffers()}))
+    (y0, g0, p0, b0), (y1, g1, p1, b1) = outs
+    assert torch.allclose(y0, y1, atol=2e-5 * float(y0.abs().max()))
+    assert torch.allclose(g0, g1, atol=1e-4 * float(g0.abs().max()))
+    G = float(np.median([float(v.abs().max()) for v in p0.values()]))
+    for n in p0:
+        assert float((p0[n] - p1[n]).abs().max()) <= 2e-3 * max(float(p0[n].abs().max()), 1e-3 * G), n
+    for n in b0:
+        assert torch.allclose(b0[n].float(), b1[n].float(), rtol=1e-5, atol=1e-6), n
