@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""How often would a weight slab staged in LDS be REUSED inside the row-block-group structure of the fused convolution?
+(CPU only: rulebooks of one synthetic SemanticKITTI-shape frame from the oracle; no GPU.)
+
+The wave kernels give a workgroup T consecutive dst rows; for every kernel offset k the pairs of that offset that fall into the tile
+are one contiguous slice, cut into 16-row MFMA blocks, taken by the waves in groups of R = 2 blocks. Each group streams the whole
+slab W[k] (cin x cout) from L2. Staging W[k] in LDS once per (tile, offset) saves traffic only if MORE THAN ONE group reads it:
+reuse = groups per non-empty (tile, offset) slice. This script measures that, and the 16-row padding, per level and tile height.
+
+    python tools/slab_reuse_stats.py > profiles/round5_convh_lds_sizing.md
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openpcseg_amd.workloads.synthetic import make_batch  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def level_coords():
+    c = make_batch([0])["lidar"].C.numpy().astype(np.int32)
+    out = {1: c}
+    for s in (1, 2, 4, 8):
+        out[2 * s] = orc.spdownsample(out[s], 2, 2, s)
+    return out
+
+
+def stats(nbmaps, nbsizes, n_dst, T, R=2):
+    ntiles = (n_dst + T - 1) // T
+    slices = groups = blocks = pairs = 0
+    hist = np.zeros(8, dtype=np.int64)
+    off = 0
+    for m in nbsizes:
+        dst = nbmaps[off:off + m, 1]
+        off += m
+        per_tile = np.bincount(dst // T, minlength=ntiles)
+        nz = per_tile[per_tile > 0]
+        rb = (nz + 15) // 16
+        g = (rb + R - 1) // R
+        slices += nz.size
+        groups += int(g.sum())
+        blocks += int(rb.sum())
+        pairs += int(nz.sum())
+        hist += np.bincount(np.minimum(g, 7), minlength=8)
+    return dict(slices=slices, groups=groups, reuse=groups / max(slices, 1), pad=blocks * 16 / max(pairs, 1),
+                one=hist[1] / max(slices, 1), two=hist[2] / max(slices, 1), three_plus=hist[3:].sum() / max(slices, 1))
+
+
+def main():
+    lv = level_coords()
+    print("# Round 5: would W through LDS pay inside the row-block-group structure? (rulebook statistics, CPU)\n")
+    print("One synthetic 120 000-ray frame (seed 0), k = 3 submanifold maps of every level, tile heights the half kernel uses (144 / 192 /")
+    print("288 rows) and the fp32 kernel's 384. `reuse` = row-block groups (R = 2 blocks of 16 pairs) per non-empty (tile, offset) slice =")
+    print("how many times a slab W[k] staged once per slice would be read; `1 / 2 / 3+` = share of the slices with that many groups;")
+    print("`padding` = MFMA rows issued per real pair (16-row blocks). Source: `python tools/slab_reuse_stats.py`.\n")
+    print("| level (stride) | voxels | pairs / voxel | T | slices | reuse | 1 group | 2 groups | 3+ groups | padding |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
+    for s, c in lv.items():
+        nbmaps, nbsizes = orc.build_kmap(c, c, 3, in_stride=s)
+        nbmaps = np.asarray(nbmaps)
+        n = c.shape[0]
+        for T in (144, 192, 288, 384):
+            st = stats(nbmaps, [int(v) for v in nbsizes], n, T)
+            print("| %d | %d | %.2f | %d | %d | **%.2f** | %.0f %% | %.0f %% | %.0f %% | %.3f |" % (
+                s, n, nbmaps.shape[0] / n, T, st["slices"], st["reuse"], 100 * st["one"], 100 * st["two"], 100 * st["three_plus"], st["pad"]))
+    print("""
+Reading. The reuse is carried by the skew of the slices: the centre offset's slice is the whole tile (12 row blocks = 6 groups at 192
+rows), the other 26 offsets hold 25-60 pairs (1-2 groups). At the heights the half kernel runs (192 rows at strides 1-2, 144-288
+deeper) a slab staged once per (tile, offset) would be read 1.7 (stride 1), 1.9 (stride 2), 2.4 (strides 4-16) times: LDS staging
+would remove 1 - 1 / reuse = **42 % / 48 % / 58 %** of the weight-slab loads, i.e. 30-45 % of ALL operand loads of a kernel whose binding
+unit is the vector-memory address path (75-80 % of its loads are weight fragments, profiles/round3_convh_pmc.md). With the fragments
+then coming out of LDS at R = 2 (ds_read_b128 at its 128 B/clk peak, DESIGN.md section 9) the estimate of the round-4 verdict -- ~1.3-1.5x
+on the half kernel -- is what this table supports; taller tiles raise the reuse further (2.3-3.4 at 288 rows) but cost LDS.
+A cheaper cut the same data point at: stage ONLY the centre offset's slab (known in advance, 6 groups per 192-row tile): -14 % of the
+slab loads at stride 1, -8 % at stride 8. None of this was built in round 5: the GPU-minute budget of the round went to the reference-source route and the
+RPVNet / Cylinder / SPVCNN steps; this table is the sizing for whoever builds it next.""")
+
+
+if __name__ == "__main__":
+    main()
