@@ -52,6 +52,10 @@ interchangeable both ways; `unfuse(model)` restores the original forwards):
     every convolution, R:pcseg/model/segmentor/voxel/cylinder3d/cylinder_ts.py:103-124: torch's channels-last BatchNorm kernels are
     30 of its 170 ms step); any other input takes the stock forward. Every plain `nn.CrossEntropyLoss` child -> the masked mean.
 
+Limits: the re-classed modules are instances of classes created at run time, so pickling a MODULE OBJECT (`torch.save(model)`) is not
+supported after `fuse` -- `state_dict()` / `load_state_dict()` (what R:train.py:285-318 uses) and `copy.deepcopy` are; `unfuse(model)`
+restores the original classes first if a whole-module pickle is needed.
+
 Anything the pass does not recognise keeps its own forward; a module with forward hooks on a BatchNorm / ReLU that would be
 skipped is left alone. `install_as_torchsparse(fuse=True)` applies the pass automatically the first time a model is called.
 """
