@@ -396,6 +396,34 @@ def cpu_baseline(compact=True):
     return ref
 
 
+LINE_LIMIT = 1950   # the driver keeps the last 2 000 characters of the line: a longer one would lose its HEAD (metric, value)
+
+
+def fit_line(res, limit=LINE_LIMIT):
+    """The compact JSON line, trimmed to `limit` characters if a record grew unexpectedly (a long worker error text, more model rows):
+    text first (labels, samples, notes), then whole secondary records from the least to the most important; the headline keys, `roofline`
+    and `cpu_baseline`'s numbers are never touched. Returns the line; `res` is trimmed in place."""
+    def line():
+        return json.dumps(res, separators=(",", ":"))
+
+    def drop(path):
+        d = res
+        for k in path[:-1]:
+            d = d.get(k) if isinstance(d, dict) else None
+            if d is None:
+                return
+        if isinstance(d, dict):
+            d.pop(path[-1], None)
+    for path in (("models", "fmt"), ("cpu_baseline", "pytorch", "sample"), ("cpu_baseline", "sample"), ("config", "notes"),
+                 ("models", "minkunet18/fused"), ("cpu_baseline", "pytorch"), ("fp32_bf16x3",), ("models",), ("device_input",),
+                 ("amp_bf16", "roofline"), ("comm",), ("amp_bf16",)):
+        if len(line()) <= limit:
+            break
+        drop(path)
+        res["trimmed"] = True
+    return line()
+
+
 _PREHEATED = {"done": False}
 
 
@@ -781,7 +809,7 @@ def main():
             res["models"] = models
         if world == 1 and not args.no_cpu_baseline and amp is None:
             res["cpu_baseline"] = cpu_baseline(compact=not args.verbose_json)
-        print(json.dumps(res, separators=(",", ":")), flush=True)
+        print(json.dumps(res, separators=(",", ":")) if args.verbose_json else fit_line(res), flush=True)
     if distributed:
         dist.destroy_process_group()
 

@@ -292,6 +292,33 @@ def test_comm_overlap_summary_on_synthetic_trace():
     assert bench.comm_overlap_summary([events[0]])["rccl_kernels"] == 0
 
 
+def test_bench_line_fits_the_drivers_tail():
+    """bench.py's compact line must stay under the 2 000 characters the driver keeps (it keeps the TAIL: a longer line loses metric /
+    value). The committed line fits untouched; an over-long one is trimmed text first, secondary records next, headline keys never."""
+    import copy
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    log = os.path.join(ROOT, "profiles", "round5_bench.log")
+    if not os.path.exists(log):
+        pytest.skip("no committed bench line")
+    raw = [l for l in open(log).read().splitlines() if l.startswith("{")][-1]
+    res = json.loads(raw)
+    keep = copy.deepcopy(res)
+    line = bench.fit_line(res)
+    assert json.loads(line) == keep and "trimmed" not in res and len(line) <= bench.LINE_LIMIT    # untouched
+    big = copy.deepcopy(keep)
+    big["cpu_baseline"]["sample"] = "worker failed: " + "x" * 400
+    big["models"].update({"model%d" % i: [1.0, 2.0, 3.0, 4.0] for i in range(20)})
+    line = bench.fit_line(big)
+    out = json.loads(line)
+    assert len(line) <= bench.LINE_LIMIT and out["trimmed"] is True
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "roofline"):
+        assert out[k] == keep[k]
+    assert out["cpu_baseline"]["value"] == keep["cpu_baseline"]["value"] and out["cpu_baseline"]["kind"] == "reference"
+    assert out["amp_bf16"]["value"] == keep["amp_bf16"]["value"]          # numbers survive; labels and the long lists went first
+
+
 def test_arithmetic_policies_are_opt_in():
     """The fp32 library path computes in fp32 MFMA arithmetic unless a caller selects a split policy explicitly."""
     from openpcseg_amd import functional as F
