@@ -644,6 +644,30 @@ def main_trajectory():
     twins_only = len(sys.argv) > 2 and sys.argv[2] == "twins" and os.path.exists(path)
     orig = torch.Tensor.cuda
     torch.Tensor.cuda = lambda self, *a, **k: self
+    if len(sys.argv) > 2 and sys.argv[2] == "threads":
+        # `make_golden.py trajectory threads`: the SAME reference run on the SAME inputs, only torch's intra-op thread count changed
+        # (8 in the fixture): what the reference's own GEMM blocking / OpenMP reduction order does to its trajectory. Nothing is
+        # written to the fixture; the drift per step goes to profiles/round5_trajectory_thread_drift.json.
+        import json
+        old = np.load(path)
+        assert all(int(old[k]) == int(g[k]) for k in g), "the existing fixture was made from other inputs"
+        rec = {"about": "reference trajectory (make_golden.py trajectory) re-run with other intra-op thread counts, same inputs, same "
+                        "weights, no perturbation; drift = |loss / fixture loss - 1| per step, weights = abs-sum per tensor, relative",
+               "fixture_threads": 8, "fixture_losses": [float(v) for v in old["losses"]], "runs": {}}
+        try:
+            for nt in (1, 3):
+                torch.set_num_threads(nt)
+                l, n_, fp = run(feats, "threads%d" % nt)
+                rec["runs"][str(nt)] = {
+                    "losses": [float(v) for v in l], "loss_rel_drift": [float("%.3g" % v) for v in np.abs(l / old["losses"] - 1)],
+                    "grad_norm_rel_drift_max": float(np.abs(n_ / old["grad_norms"] - 1).max()),
+                    "weights_abssum_rel_drift_max": float(np.abs(fp["grad_stats"][:, 1] / old["state_stats"][:, 1] - 1).max())}
+        finally:
+            torch.Tensor.cuda = orig
+        with open(os.path.join(os.path.dirname(os.path.dirname(OUT)), "profiles", "round5_trajectory_thread_drift.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+        print(json.dumps(rec["runs"], indent=1))
+        return
     try:
         if twins_only:
             old = dict(np.load(path))

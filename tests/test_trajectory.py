@@ -17,7 +17,10 @@ features were perturbed by 1e-6 relative (the size of the difference between two
 the full-size fixtures' logits agree to 1.4e-6 of their scale), and the spread of {main, twins} is the reproducibility of the
 reference's own trajectory at that level. A bound is max(nominal, 3 x the largest drift among the twins at that step / in that
 quantity): what an implementation with another summation order (MFMA tiles vs scalar loops) cannot be expected to beat, measured
-rather than assumed. The measured values of the three routes and the twins: profiles/round5_fullsize_parity.json."""
+rather than assumed. The measured values of the three routes and the twins: profiles/round5_fullsize_parity.json.
+The unperturbed form of the same measurement (`make_golden.py trajectory threads`, profiles/round5_trajectory_thread_drift.json): the
+reference with 1 or 3 intra-op threads instead of 8, same inputs, drifts from its own fixture by 1.2e-3 in the last loss and 3.5e-3 ...
+4.5e-3 in the final weights."""
 import json
 import os
 import sys
