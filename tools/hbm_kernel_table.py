@@ -18,7 +18,7 @@ from openpcseg_amd.workloads.synthetic import make_batch  # noqa: E402
 PEAK = 8000.0  # GB/s, MI355X HBM3E (MI355X_MICROARCH.md)
 
 
-DRY = os.environ.get("PCS_TABLE_DRYRUN") == "1"  # CPU dry run of this script on the oracle backend (checks the calls only)
+DRY = os.environ.get("PCS_TABLE_DRYRUN") == "1"  # CPU dry run of this script on the pure-PyTorch CPU backend (checks the calls only)
 
 
 def timed(fn, reps):
@@ -42,8 +42,8 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     dev = torch.device("cpu" if DRY else "cuda:0")
     if DRY:
-        from oracle.adapter import OracleBackend
-        native._BACKEND = OracleBackend()
+        from openpcseg_amd.cpu_fallback import TorchCpuBackend   # the package's explicit pure-PyTorch CPU backend
+        native._BACKEND = TorchCpuBackend()
     be = native.backend()
     batch = make_batch(list(range(frames)))
     vox = batch["lidar"].C.to(dev).int().contiguous()      # (M,4) voxel coords, one row per voxel
@@ -65,7 +65,7 @@ def main():
     add("sphash + offsets (K=27)", "pcs_kernel_hash", timed(lambda: be.kernel_hash(vox, offs), reps), 16 * m + 8 * 27 * m)
     keys = be.hash(vox)
     q = be.hash(pts_vox)
-    if not DRY:  # the oracle has no persistent table object
+    if not DRY:  # the CPU backend has no persistent table object
         add("hash table build", "pcs_hashtable_build", timed(lambda: be.table_build(keys), reps), 16 * m,
             "12 B/slot table, load <= 0.5")
         table = be.table_build(keys)

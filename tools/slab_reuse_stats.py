@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """How often would a weight slab staged in LDS be REUSED inside the row-block-group structure of the fused convolution?
-(CPU only: rulebooks of one synthetic SemanticKITTI-shape frame from the oracle; no GPU.)
+(CPU only: rulebooks of one synthetic SemanticKITTI-shape frame from the package's explicit pure-PyTorch CPU backend,
+openpcseg_amd/cpu_fallback.py; no GPU.)
 
 The wave kernels give a workgroup T consecutive dst rows; for every kernel offset k the pairs of that offset that fall into the tile
 are one contiguous slice, cut into 16-row MFMA blocks, taken by the waves in groups of R = 2 blocks. Each group streams the whole
@@ -15,16 +16,25 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openpcseg_amd.cpu_fallback import TorchCpuBackend  # noqa: E402
+from openpcseg_amd.sparse import get_kernel_offsets  # noqa: E402
 from openpcseg_amd.workloads.synthetic import make_batch  # noqa: E402
-from oracle import oracle as orc  # noqa: E402
+
+BE = TorchCpuBackend()
 
 
 def level_coords():
-    c = make_batch([0])["lidar"].C.numpy().astype(np.int32)
+    c = make_batch([0])["lidar"].C.int()
     out = {1: c}
     for s in (1, 2, 4, 8):
-        out[2 * s] = orc.spdownsample(out[s], 2, 2, s)
+        out[2 * s] = BE.downsample(out[s], (2 * s,) * 3)     # k = 2, stride 2 at tensor stride s: the truncation branch
     return out
+
+
+def kmap_k3(c, s):
+    """k = 3 submanifold rulebook of one level: (pairs (P, 2) [src, dst] offset-major / dst ascending, sizes per offset)."""
+    km = BE.build_kmap(c, c, get_kernel_offsets(3, s))
+    return km.pairs.numpy(), km.nbsizes.tolist()
 
 
 def stats(nbmaps, nbsizes, n_dst, T, R=2):
@@ -58,8 +68,7 @@ def main():
     print("| level (stride) | voxels | pairs / voxel | T | slices | reuse | 1 group | 2 groups | 3+ groups | padding |")
     print("|---|---|---|---|---|---|---|---|---|---|")
     for s, c in lv.items():
-        nbmaps, nbsizes = orc.build_kmap(c, c, 3, in_stride=s)
-        nbmaps = np.asarray(nbmaps)
+        nbmaps, nbsizes = kmap_k3(c, s)
         n = c.shape[0]
         for T in (144, 192, 288, 384):
             st = stats(nbmaps, [int(v) for v in nbsizes], n, T)
