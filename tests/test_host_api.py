@@ -48,6 +48,16 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "pcs_oracle" not in src, f
+    # the measurement / analysis tools are not checkers either: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+    # worker may touch oracle/ (bench.py: inside _cpu_baseline_worker only)
+    for f in sorted(os.listdir(os.path.join(ROOT, "tools"))):
+        if f.endswith((".py", ".sh")):
+            src = open(os.path.join(ROOT, "tools", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M) and "pcs_oracle" not in src, f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    body = bench[bench.index("def _cpu_baseline_worker"):]
+    body = body[:body.index("\ndef ", 1)]
+    assert len(re.findall(r"^\s*(?:from|import)\s+oracle\b", bench, re.M)) == len(re.findall(r"^\s*(?:from|import)\s+oracle\b", body, re.M)) > 0
 
 
 def test_reference_import_names():
