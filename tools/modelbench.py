@@ -150,6 +150,10 @@ def _time_steps(step, steps, warmup):
 
 def bench_one(name, source, dtype, dev, steps=10, warmup=2, want_step=False):
     n_frames = int(os.environ.get("PCS_MB_FRAMES", FRAMES[name]))
+    # `fuse` re-binds the glue helpers in the MODEL FILE's namespace (process-wide): put the reference's own functions back before
+    # every entry, so that a `reference` entry measured after a `fuse` entry of the same file (minkunet18 after minkunet34) is unmodified
+    from openpcseg_amd.block_fusion import restore_glue
+    restore_glue()
     if source == "workload":
         from seeded import seeded_state
         from openpcseg_amd.workloads.minkunet import MK18_LAYERS, MK34_LAYERS, MinkUNet
