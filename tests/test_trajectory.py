@@ -38,6 +38,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden", "trajectory_golden.npz")
 LOSS_REL, WEIGHT_REL = 1e-4, 1e-3
 
 
+@pytest.fixture(autouse=True)
+def _glue_back():
+    """`fuse` re-binds the glue helpers of the model FILE process-wide: the reference's own functions go back after every test."""
+    yield
+    from openpcseg_amd.block_fusion import restore_glue
+    restore_glue()
+
+
 def _fixture():
     if not os.path.exists(GOLDEN):
         pytest.skip("trajectory_golden.npz not generated")
