@@ -1,7 +1,13 @@
-"""The reference's native module surface `torchsparse.backend` (the `*_cuda` half of
-TS:torchsparse/backend/pybind_cuda.cpp:18-39) on top of the C ABI, so that code written against the
-reference's low-level functions (e.g. its own nn/functional/*.py) keeps working. Same argument
-order, ownership and result conventions as the reference (boundary B-B)."""
+"""The reference's native module surface `torchsparse.backend`: all 20 names of
+TS:torchsparse/backend/pybind_cuda.cpp:18-39 -- the `*_cuda` half on top of the C ABI, the `*_cpu` half
+(TS:torchsparse/backend/pybind_cpu.cpp:12-23) on this package's pure-PyTorch CPU path (cpu_fallback.py, BASELINE
+config 1) -- so that code written against the reference's low-level functions (its own nn/functional/*.py, run
+unmodified by tests/test_backend_shim.py on both device types) keeps working. Same argument order, ownership and
+result conventions as the reference (boundary B-B).
+
+This is a COMPATIBILITY surface, not the fast path: the reference's (nbmaps, nbsizes-on-the-host) calling convention
+costs a host read, a sort and three small host-to-device copies per convolution call (`_as_kmap`). The fast path is
+openpcseg_amd.functional / `install_as_torchsparse()`, which keeps the native maps."""
 import torch
 
 from . import native
@@ -85,3 +91,82 @@ def convolution_backward_cuda(in_feat, grad_in_feat, grad_out_feat, kernel, grad
     kw = _as_kmap(neighbor_map, neighbor_offset, in_feat.shape[0], grad_out_feat.shape[0], 1)
     grad_kernel.resize_as_(kernel).copy_(be.conv_wgrad(in_feat.contiguous(), grad_out_feat.contiguous(), kw,
                                                        1 if transpose else 0))
+
+
+# ---- the `*_cpu` half (TS:torchsparse/backend/pybind_cpu.cpp:12-23): host tensors, pure PyTorch -------------------------------
+def _cpu_be():
+    from .cpu_fallback import TorchCpuBackend
+    return TorchCpuBackend()
+
+
+def hash_cpu(idx):
+    return _cpu_be().hash(idx)
+
+
+def kernel_hash_cpu(idx, kernel_offset):
+    return _cpu_be().kernel_hash(idx, kernel_offset)
+
+
+def hash_query_cpu(hash_query, hash_target, idx_target):
+    """-> idx_target[position] + 1, or 0 when the query hash is absent (TS:torchsparse/backend/others/query_cpu.cpp: the first of
+    equal targets wins)."""
+    pos = _cpu_be().hash_query(hash_query, hash_target)
+    if idx_target.numel() == 0:
+        return torch.zeros_like(pos)
+    vals = idx_target[pos.clamp(min=0)] + 1
+    return torch.where(pos >= 0, vals, torch.zeros_like(vals))
+
+
+def count_cpu(idx, s):
+    return _cpu_be().count(idx, s)
+
+
+def voxelize_forward_cpu(inputs, idx, counts):
+    return _cpu_be().voxelize_fwd(inputs, idx, counts)
+
+
+def voxelize_backward_cpu(top_grad, idx, counts, n):
+    return _cpu_be().voxelize_bwd(top_grad, idx, counts, n)
+
+
+def devoxelize_forward_cpu(feat, indices, weight):
+    return _cpu_be().devoxelize_fwd(feat, indices, weight)
+
+
+def devoxelize_backward_cpu(top_grad, indices, weight, n):
+    """The gradient of devoxelize_forward (the reference's own CPU twin is broken here -- SURVEY.md section 8c: it indexes
+    top_grad by the voxel index; authority = TS:torchsparse/backend/devoxelize/devoxelize_cuda.cu:37-57)."""
+    return _cpu_be().devoxelize_bwd(top_grad, indices, weight, n)
+
+
+def _offset_slices(neighbor_offset):
+    a = 0
+    for k, n in enumerate(int(v) for v in neighbor_offset.tolist()):
+        yield k, a, a + n
+        a += n
+
+
+def convolution_forward_cpu(in_feat, out_feat, kernel, neighbor_map, neighbor_offset, transpose):
+    """out_feat (zeros from the caller) accumulates per offset `out[o] += in[i] @ W[k]` (convolution_cpu.cpp:38-91 =
+    TS:torchsparse/nn/functional/conv.py:67-79)."""
+    if in_feat.size(1) != kernel.size(1):
+        raise ValueError("Input feature size and kernel size mismatch")
+    nm = neighbor_map.long()
+    ci, co = (1, 0) if transpose else (0, 1)
+    for k, a, b in _offset_slices(neighbor_offset):
+        if b > a:
+            out_feat.index_add_(0, nm[a:b, co], in_feat[nm[a:b, ci]] @ kernel[k])
+
+
+def convolution_backward_cpu(in_feat, grad_in_feat, grad_out_feat, kernel, grad_kernel, neighbor_map, neighbor_offset, transpose):
+    """grad_in_feat / grad_kernel are resized + overwritten like convolution_cpu.cpp:93-183."""
+    nm = neighbor_map.long()
+    ci, co = (1, 0) if transpose else (0, 1)
+    grad_in_feat.resize_as_(in_feat).zero_()
+    grad_kernel.resize_as_(kernel).zero_()
+    for k, a, b in _offset_slices(neighbor_offset):
+        if b > a:
+            i, o = nm[a:b, ci], nm[a:b, co]
+            g = grad_out_feat[o]
+            grad_in_feat.index_add_(0, i, g @ kernel[k].t())
+            grad_kernel[k] = in_feat[i].t() @ g

@@ -19,7 +19,8 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-
 # per-file additions. The wave kernels: no SLP vectorisation -- it packs the 48 accumulate adds of the ticket-ordered commit
 # into v_pk_add_f32 at the price of two register moves each, inside the one serial chain of a workgroup
 EXTRA_FLAGS = {"conv_wave5.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"],
-               "conv_wave5h.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"]}
+               "conv_wave5h.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"],
+               "conv_wave6h.hip": ["-fno-slp-vectorize", "-Wno-array-bounds"]}
 
 
 def sources():

@@ -52,7 +52,7 @@ def install_as_torchsparse(force=False, fuse=False):
     tensor = _module("torchsparse.tensor", SparseTensor=sparse.SparseTensor,
                      PointTensor=sparse.PointTensor)
     operators = _module("torchsparse.operators", cat=sparse.cat)
-    b_names = [n for n in dir(backend_shim) if n.endswith("_cuda")]
+    b_names = [n for n in dir(backend_shim) if n.endswith("_cuda") or n.endswith("_cpu")]   # the 20 names of pybind_cuda.cpp:18-39
     backend = _module("torchsparse.backend", **{n: getattr(backend_shim, n) for n in b_names})
     top = _module("torchsparse", SparseTensor=sparse.SparseTensor, PointTensor=sparse.PointTensor,
                   cat=sparse.cat, nn=nn_mod, utils=utils, tensor=tensor, operators=operators, backend=backend,

@@ -14,6 +14,10 @@
 #ifndef PCS_ABLATE5
 #define PCS_ABLATE5 0  /* wave5: 2 no MFMA, 3 no operand loads in the channel loop, 5 no W loads, 6 no A loads */
 #endif
+#ifndef PCS_ABLATEH
+#define PCS_ABLATEH 0  /* wave5h, timing only (results are wrong): 1 weight fragments loaded at a group's first step only, 2 no weight
+                          loads, 3 no ticket / commit, 4 = 2 + 3, 5 no A loads, 6 weight fragments read out of LDS without a fill */
+#endif
 #ifndef PCS_ALIAS
 #define PCS_ALIAS 0    /* wave5: 1 every offset reads W[0], 2 A rows read sequentially instead of gathered */
 #endif

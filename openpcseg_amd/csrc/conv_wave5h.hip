@@ -22,7 +22,15 @@
 
 using namespace pcs;
 
+namespace pcs {
+int launch_conv_wave6h(const ConvArgsH &a, int dtype, hipStream_t st);  // conv_wave6h.hip
+bool conv6h_applies(int cin, int cout, int K);
+int conv6h_mode();
+}
+
 namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // native vector: loads from LDS address-space pointers
 
 #if PCS_TRACE
 __device__ long long *g_convh_trace;   // [block][wave][8], as conv_wave5.hip: t_entry, t_start, t_end, loop, ticket, commit, groups, t_exit
@@ -173,11 +181,30 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
   };
   auto load_frag = [&](Frag &f, const Ctx &cx, int s) {
     const int aoff = TAIL ? s * 64 - (s == NS - 1 ? tail_back : 0) : s * 64;
+#if PCS_ABLATEH == 5
+#pragma unroll
+    for (int r = 0; r < R; ++r) asm volatile("" : "+v"(f.a[r].x), "+v"(f.a[r].y), "+v"(f.a[r].z), "+v"(f.a[r].w));
+    (void)aoff;
+#else
 #pragma unroll
     for (int r = 0; r < R; ++r) f.a[r] = *reinterpret_cast<const uint4 *>(cx.srow[r] + aoff);
+#endif
+    const bool ldb = PCS_ABLATEH == 1 ? s == 0 : true;   /* ablation 1, timing only: the weight fragments of a group's first step serve all its steps */
+#if PCS_ABLATEH == 2 || PCS_ABLATEH == 4   /* timing only: no weight loads at all */
+#pragma unroll
+    for (int t = 0; t < NCTT; ++t) asm volatile("" : "+v"(f.b[t].x), "+v"(f.b[t].y), "+v"(f.b[t].z), "+v"(f.b[t].w));
+#elif PCS_ABLATEH == 6   /* timing only: weight fragments out of LDS (whatever the tile holds), no fill */
 #pragma unroll
     for (int t = 0; t < NCTT; ++t)
-      f.b[t] = *reinterpret_cast<const uint4 *>(cx.Wk + ((size_t)btile[t] * NS + s) * 1024);
+      f.b[t] = __builtin_bit_cast(uint4, *(__attribute__((address_space(3))) const u32x4 *)(size_t)(acc_lds + (unsigned)((btile[t] * NS + s) * 1024 + lane * 16)));
+#else
+    if (ldb) {
+#pragma unroll
+      for (int t = 0; t < NCTT; ++t)
+        f.b[t] = *reinterpret_cast<const uint4 *>(cx.Wk + ((size_t)btile[t] * NS + s) * 1024);
+    }
+#endif
+    (void)ldb;
   };
   auto locate = [&](int grp, int &i_hint, int *pidx, unsigned &vmask, int &nr) {
     int rb0, e;
@@ -220,6 +247,10 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
   int i = 0;
   Ctx cur;
   Frag f0, f1;
+#if PCS_ABLATEH
+  for (int r = 0; r < R; ++r) f0.a[r] = f1.a[r] = make_uint4(0u, 0u, 0u, 0u);
+  for (int t = 0; t < NCTT; ++t) f0.b[t] = f1.b[t] = make_uint4(0u, 0u, 0u, 0u);
+#endif
   if (wid < total_grp) {
     int pidx[R]; unsigned vm; int nr;
     locate(wid, i, pidx, vm, nr);
@@ -315,6 +346,13 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(doff[r][j]));
 #endif
+#if PCS_ABLATEH == 3 || PCS_ABLATEH == 4   /* timing only: no ticket, no commit */
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int t = 0; t < NCTT; ++t) asm volatile("" ::"v"(acc[r][t]));
+    PCS_T(const long long tr_c = wall_clock64();)
+#else
     if (lane == 0) {
       while (__hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != grp)
         __builtin_amdgcn_s_sleep(1);
@@ -449,6 +487,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
     __builtin_amdgcn_s_setprio(0);
 #endif
 #endif
+#endif  // PCS_ABLATEH 3 / 4
     PCS_T(const long long tr_d = wall_clock64(); tr_loop += tr_b - tr_a; tr_ticket += tr_c - tr_b; tr_commit += tr_d - tr_c; ++tr_groups;)
     cur = nxt;
     i = in;
@@ -619,5 +658,6 @@ extern "C" int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t ci
   // 96 / 128-column tiles of >= 64-channel layers whose tile fits beside the operand ring: the column-parallel ring kernel
   // (conv_ring6h.hip: every weight slab enters the CU once per tile, gathered rows once per column tile)
   if (conv_ring_applies(cin, cout, K, tile_rows, nullptr)) return launch_conv_ring6h(a, dtype, as_stream(stream));
+  if (conv6h_mode() && conv6h_applies(cin, cout, K)) return launch_conv_wave6h(a, dtype, as_stream(stream));  // weight-stationary kernel
   return dtype == 1 ? launch_h<Bf16>(a, as_stream(stream)) : launch_h<Fp16>(a, as_stream(stream));
 }

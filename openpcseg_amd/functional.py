@@ -234,6 +234,11 @@ class _WeightPrep:
     `vector_to_parameters`, multi-tensor optimizers writing through raw pointers). Inside a pass a copy is additionally refreshed
     when the parameter's version counter or storage address changed. A training step pays the one launch it always paid
     (the optimizer made everything stale anyway); inference pays one ~0.1 ms launch per forward. `invalidate()` forces a refresh.
+    What the pass rule does NOT see: a SECOND model written through `.data` after the first model's pass began and run before any
+    copy of the first is asked for twice (an EMA / teacher copy updated by hand and evaluated in the same iteration). Every
+    `torch.optim.Optimizer.step` ends the pass through a global post-step hook (registered below), which covers the usual EMA
+    order (student step, then teacher update, then teacher forward); a hand-written update with no optimizer in between must
+    call `openpcseg_amd.functional.invalidate_prepared_weights()`.
     Only leaf fp32 (K, A, B) device parameters are cached; anything else (padded copies, 2-D weights, other backends) takes the
     per-call path. PCS_WEIGHT_PREP=0 switches the cache off (A/B)."""
 
@@ -290,6 +295,18 @@ class _WeightPrep:
 
 
 _WEIGHT_PREP = _WeightPrep()
+
+
+def invalidate_prepared_weights():
+    """Every prepared weight copy is rebuilt at its next use (see _WeightPrep)."""
+    _WEIGHT_PREP.invalidate()
+
+
+try:   # an optimizer step ends the pass: whatever is run next re-prepares from the live weights
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_step
+    _reg_post_step(lambda opt, args, kwargs: _WEIGHT_PREP.invalidate())
+except ImportError:   # older torch: the pass rule and the version counters alone
+    pass
 
 
 class _SparseConv(Function):

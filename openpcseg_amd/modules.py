@@ -50,16 +50,15 @@ class Conv3d(nn.Module):
             self.bias.data.uniform_(-std, std)
 
     def extra_repr(self):
-        s = "{in_channels}, {out_channels}, kernel_size={kernel_size}"
-        if self.stride != (1,) * len(self.stride):
-            s += ", stride={stride}"
+        parts = ["%d -> %d" % (self.in_channels, self.out_channels), "k=%s" % (tuple(self.kernel_size),)]
+        if any(v != 1 for v in self.stride):
+            parts.append("stride=%s" % (tuple(self.stride),))
         if self.dilation != 1:
-            s += ", dilation={dilation}"
-        if self.bias is None:
-            s += ", bias=False"
+            parts.append("dilation=%s" % (self.dilation,))
+        parts.append("bias" if self.bias is not None else "no bias")
         if self.transposed:
-            s += ", transposed=True"
-        return s.format(**self.__dict__)
+            parts.append("transposed")
+        return ", ".join(parts)
 
     def forward(self, input):
         if self.emit_bn_stats and self.training:

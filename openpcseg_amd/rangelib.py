@@ -68,8 +68,12 @@ def range_to_point(feature_map, pxpy, grid_sample_mode="bilinear", fallback=None
     R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:31-51 without the loop over frames. Inputs the kernels do not serve (another
     sampling mode, channel counts that are not a multiple of 4, rows whose frames are not grouped in ascending order -- the
     reference would REORDER those --, host tensors) go to `fallback` (the reference's own function) when one is given."""
+    # the kernels take float32 (any float16 / bfloat16 input only under CUDA autocast, whose custom_fwd casts to float32)
+    f32 = (feature_map.dtype == torch.float32 and pxpy.dtype == torch.float32) or (
+        torch.is_autocast_enabled("cuda") and feature_map.dtype in (torch.float32, torch.float16, torch.bfloat16) and
+        pxpy.dtype in (torch.float32, torch.float16, torch.bfloat16))
     ok = (grid_sample_mode == "bilinear" and feature_map.is_cuda and feature_map.dim() == 4 and feature_map.shape[1] % 4 == 0 and
-          pxpy.dim() == 2 and pxpy.shape[1] == 3 and pxpy.is_floating_point() and pxpy.shape[0] > 0 and
+          pxpy.dim() == 2 and pxpy.shape[1] == 3 and pxpy.is_floating_point() and pxpy.shape[0] > 0 and f32 and
           _frames_in_order(pxpy, feature_map.shape[0]))
     if not ok:
         if fallback is None:
@@ -86,9 +90,10 @@ def point_to_range(pf, pxpy, b, h, w):
     broadcasts a (2,) float32 tensor, here each column meets its python scalar), so the integer pixels are identical. The integer
     coordinates are cached on the pxpy tensor per resolution: forward, backward and the next call on the same tensor share one pixel CSR."""
     def make():
-        px = (pxpy[:, 1] + 1) / 2 * float(w - 1)
-        py = (pxpy[:, 2] + 1) / 2 * float(h - 1)
-        return torch.stack([pxpy[:, 0], px, py], dim=1).int().contiguous()
+        p32 = pxpy.float() if pxpy.dtype in (torch.float16, torch.bfloat16) else pxpy   # the reference's float32 factor promotes halfs
+        px = (p32[:, 1] + 1) / 2 * float(w - 1)
+        py = (p32[:, 2] + 1) / 2 * float(h - 1)
+        return torch.stack([p32[:, 0], px, py], dim=1).int().contiguous()
     int_pxpy = native._cached(pxpy, "_pcs_int_pxpy_%dx%d" % (h, w), native._cache_key(pxpy), make)
     return denselize(pf, map_count(int_pxpy, b, h, w), int_pxpy)
 

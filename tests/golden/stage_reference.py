@@ -30,6 +30,33 @@ def reference_root():
     return None
 
 
+TS_ZIP = os.path.join(REF, "package", "torchsparse.zip")
+TS_FUNCTIONAL = ["hash", "query", "count", "voxelize", "devoxelize", "conv"]   # TS:torchsparse/nn/functional/<name>.py
+
+
+def functional_source(name):
+    """Source text of the reference's torchsparse/nn/functional/<name>.py: from the reference's zip where it exists, else from
+    the staged copy (tests/_refsrc/ts_functional/, git-ignored, travels to the GPU box). None when neither is there."""
+    if os.path.isfile(TS_ZIP) and os.environ.get("PCS_REFSRC") != "staged":
+        import zipfile
+        with zipfile.ZipFile(TS_ZIP) as z:
+            return z.read("torchsparse/torchsparse/nn/functional/%s.py" % name).decode()
+    p = os.path.join(DST, "ts_functional", name + ".py")
+    return open(p).read() if os.path.isfile(p) else None
+
+
+def stage_functional():
+    if not os.path.isfile(TS_ZIP):
+        return
+    import zipfile
+    d = os.path.join(DST, "ts_functional")
+    os.makedirs(d, exist_ok=True)
+    with zipfile.ZipFile(TS_ZIP) as z:
+        for name in TS_FUNCTIONAL:
+            with open(os.path.join(d, name + ".py"), "wb") as f:
+                f.write(z.read("torchsparse/torchsparse/nn/functional/%s.py" % name))
+
+
 def stage(verbose=False):
     if not os.path.isdir(os.path.join(REF, "pcseg")):
         return None
@@ -57,6 +84,7 @@ def stage(verbose=False):
         shutil.copyfile(f, dst)
         if verbose:
             print("staged", rel)
+    stage_functional()
     return DST
 
 

@@ -141,6 +141,35 @@ def test_fuse_recognises_the_reference_blocks(env_oracle):
     assert list(model.state_dict().keys()) == keys
 
 
+def test_forward_is_not_swapped_when_the_glue_is_not_the_references(env_oracle):
+    """The replacement forwards call this package's point <-> voxel helpers: a model file whose helper was edited (or
+    `fuse(glue=False)`) keeps its own forward -- and the edited helper is what runs."""
+    import sys
+    import openpcseg_amd
+    from openpcseg_amd import block_fusion as fz
+    model = _minkunet(env_oracle)
+    ns = sys.modules[type(model).__module__]
+    calls = []
+    orig = ns.initial_voxelize
+
+    def initial_voxelize(z, init_res, after_res):   # a fork's edit: same result, different source text
+        calls.append(1)
+        return orig(z, init_res, after_res)
+    ns.initial_voxelize = initial_voxelize
+    try:
+        counts = openpcseg_amd.fuse(model)
+        assert counts["forward"] == 0 and counts["glue"] == 1          # voxel_to_point alone was re-bound
+        assert type(model).forward is type(model).__mro__[0].forward and not getattr(type(model), "_pcs_fused_class", False)
+        assert ns.initial_voxelize is initial_voxelize
+    finally:
+        fz.unfuse(model)
+        fz.restore_glue()
+        ns.initial_voxelize = orig
+    counts = openpcseg_amd.fuse(model, glue=False)
+    assert counts["forward"] == 0 and counts["glue"] == 0
+    fz.unfuse(model)
+
+
 def test_fused_reference_minkunet_matches_the_reference_golden(golden_e2e, env_oracle):
     import openpcseg_amd
     model = _minkunet(env_oracle)

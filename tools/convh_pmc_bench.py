@@ -23,7 +23,10 @@ def main():
         levels.append(F.spdownsample(levels[-1], 2, 2, ts))
         ts *= 2
     be = native.backend()
-    for level, cin, cout in ((0, 96, 96), (3, 256, 256)):
+    shapes = ((0, 96, 96), (3, 256, 256))
+    if os.environ.get("PCS_PMC_SHAPES"):   # "level cin cout;level cin cout"
+        shapes = tuple(tuple(int(v) for v in sp.split()) for sp in os.environ["PCS_PMC_SHAPES"].split(";"))
+    for level, cin, cout in shapes:
         c = levels[level]
         entry = F.build_kernel_map(c, c, (3, 3, 3), (2 ** level,) * 3, (1, 1, 1))
         n, p = c.shape[0], entry.fwd.num_pairs
