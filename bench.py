@@ -39,7 +39,7 @@ from openpcseg_amd.workloads.synthetic import make_batch  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
-TRAFFIC_FILE = "round5_conv_traffic.json"
+TRAFFIC_FILE = "round6_conv_traffic.json"
 # what the counters say binds conv_os5h_kernel (profiles/round3_convh_pmc.md); filled in from the PMC passes of round 3
 HALF_BINDING_NOTE = ("vector-memory address path (TA / vector L1), not HBM and not the MFMA pipe: TA 65-81 % busy, MFMA pipe 10-19 %, "
                      "L2 hit 77-94 %, HBM 1.3-3 TB/s on the two reference shapes; 1.1-1.6 MFMAs per 16-byte operand load "
@@ -133,7 +133,7 @@ class ConvMeter:
             # 16-bit MFMA is 16x the fp32 rate: the fused conv is priced on its ALGORITHMIC bytes (each feature row once,
             # weights once, rulebook once) against HBM; mfma_tflops is the same launches against the MFMA roof
             gbs = abytes / (ms * 1e-3) / 1e9
-            return dict({"kernel": "conv_os5h_kernel (pcs_conv_gather_gemm_h: fwd + dgrad, %s)" % amp, "bound": "hbm",
+            return dict({"kernel": "conv_os6h_kernel + conv_os5h_kernel (pcs_conv_gather_gemm_h: fwd + dgrad, %s)" % amp, "bound": "hbm",
                          "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                          "traffic": traffic, "traffic_note": note, "mfma_tflops": round(tflops, 1),
                          "mfma_frac_of_dense_bf16_peak": round(tflops / PEAK_BF16_MFMA_TFLOPS, 4),
@@ -637,13 +637,25 @@ def main():
         amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(amp)
         scaler = torch.amp.GradScaler("cuda") if amp == "fp16" else None  # the reference scales fp16 losses (train.py)
 
+        pipe = None
+        if device_input:
+            # collate of the next batch on a side stream during the step (a DataLoader's prefetch): the voxel-count host read of
+            # device_collate no longer drains the launch queue inside the step (round 5: 7.0 ms per step on the driver's box)
+            from openpcseg_amd.workloads.synthetic import DeviceInputPrefetcher
+            pipe = DeviceInputPrefetcher(lambda i: raw_dev)
+
         def inputs():
             if device_input:
-                from openpcseg_amd.workloads.synthetic import device_collate
-                return device_collate(raw_dev)
+                return pipe.next()
             return fresh(batch)
 
         def step():
+            loss = step_body()
+            if device_input:
+                pipe.prefetch()
+            return loss
+
+        def step_body():
             opt.zero_grad(set_to_none=True)
             if amp is None:
                 out = model(inputs())

@@ -8,6 +8,12 @@
 
 using namespace pcs;
 
+namespace pcs {
+bool conv6h_applies(int cin, int cout, int K);       // conv_wave6h.hip
+bool conv6h_is_chunked(int cin, int cout);
+int conv6h_mode();
+}
+
 namespace {
 
 int device_cus() {
@@ -50,7 +56,7 @@ extern "C" int pcs_transpose_kab_f32(const float *src, int32_t K, int32_t A, int
 
 // Bumped whenever a fused-conv kernel, its launch shape picker or its epilogue changes: measurements keyed to kernels
 // (profiles/*_conv_traffic.json) carry the revision they were taken on and bench.py refuses a stale one.
-extern "C" const char *pcs_conv_kernel_revision(void) { return "r5.0"; }
+extern "C" const char *pcs_conv_kernel_revision(void) { return "r6.0"; }
 
 extern "C" int32_t pcs_conv_tile_rows(int32_t cin, int32_t cout) {
   (void)cin;
@@ -118,6 +124,10 @@ extern "C" int32_t pcs_conv_pick_tile_rows_dt(int64_t n_dst, int64_t n_pairs, in
     // workgroup -- two (or more) 4-wave workgroups per CU beat one tall 8-wave workgroup except on the >= 256-channel
     // deep levels, where the tall tile's lower padding and W reuse win (224 / 288 rows)
     if (cin >= 256 && cout >= 256) {
+      // the weight-stationary kernel's chunked instances (conv_wave6h.hip) want two 4-wave workgroups per CU: 1.06-1.18x on 384
+      // channels and on the small stride-16 level; 256 -> 256 on a big level stays on conv_os5h's tall 8-wave tile (0.97x)
+      if (conv6h_mode() && conv6h_applies(cin, cout, K) && conv6h_is_chunked(cin, cout) && (cin > 256 || cout > 256 || n_dst <= 65536))
+        return 144;
       const int64_t ncol = ceil_div(cout, 16 * nctt);
       return launch_cost(n_dst, 288, ncol, ppr, K) <= launch_cost(n_dst, 224, ncol, ppr, K) ? 288 : 224;
     }

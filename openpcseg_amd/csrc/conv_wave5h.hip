@@ -25,6 +25,7 @@ using namespace pcs;
 namespace pcs {
 int launch_conv_wave6h(const ConvArgsH &a, int dtype, hipStream_t st);  // conv_wave6h.hip
 bool conv6h_applies(int cin, int cout, int K);
+bool conv6h_is_chunked(int cin, int cout);
 int conv6h_mode();
 }
 
@@ -658,6 +659,8 @@ extern "C" int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t ci
   // 96 / 128-column tiles of >= 64-channel layers whose tile fits beside the operand ring: the column-parallel ring kernel
   // (conv_ring6h.hip: every weight slab enters the CU once per tile, gathered rows once per column tile)
   if (conv_ring_applies(cin, cout, K, tile_rows, nullptr)) return launch_conv_ring6h(a, dtype, as_stream(stream));
-  if (conv6h_mode() && conv6h_applies(cin, cout, K)) return launch_conv_wave6h(a, dtype, as_stream(stream));  // weight-stationary kernel
+  // the weight-stationary kernel (conv_wave6h.hip); its chunked-contraction instances only on 4-wave workgroups (<= 160-row tiles)
+  if (conv6h_mode() && conv6h_applies(cin, cout, K) && (!conv6h_is_chunked(cin, cout) || tile_rows <= 160))
+    return launch_conv_wave6h(a, dtype, as_stream(stream));
   return dtype == 1 ? launch_h<Bf16>(a, as_stream(stream)) : launch_h<Fp16>(a, as_stream(stream));
 }

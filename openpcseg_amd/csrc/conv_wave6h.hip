@@ -35,6 +35,7 @@ using namespace pcs;
 namespace pcs {
 int launch_conv_wave6h(const ConvArgsH &a, int dtype, hipStream_t st);
 bool conv6h_applies(int cin, int cout, int K);
+bool conv6h_is_chunked(int cin, int cout);
 int conv6h_mode();
 }
 
@@ -126,9 +127,13 @@ __device__ __forceinline__ void half_tile_epilogue8(float *acc_l, int ACS, int r
   }
 }
 
-template <typename HT, int NCTT, int NS, int RS, int NW, int MINW>
+// KC > 1: the contraction is cut into KC chunks of NS steps (cin = 32 NS KC): every (offset, chunk) is a slice of its own -- its
+// NS x NCTT weight fragments fit the registers where NS KC x NCTT do not (256 / 384 input channels) -- and commits its partial
+// sums; the gathered rows of a sub-group are fetched chunk by chunk, each element once.
+template <typename HT, int NCTT, int NS, int RS, int NW, int MINW, int KC = 1>
 __global__ void __launch_bounds__(64 * NW, MINW) conv_os6h_kernel(ConvArgsH a) {
   using C = Conv6hCfg<NCTT, NW>;
+  constexpr int NST = NS * KC;   // steps of the whole contraction (the stride of the prepared weights)
   static_assert(NCTT % 2 == 0, "even number of 16-column tiles");
   const int T = a.tile_rows;
   WS_T(const long long tr_entry = __builtin_readcyclecounter(); long long tr_issue = 0, tr_mfma = 0, tr_ticket = 0, tr_commit = 0;)
@@ -170,8 +175,8 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os6h_kernel(ConvArgsH a) {
     for (int i = tid; i < n4; i += C::NT) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid == 0) *commit = 0;
   }
-  const int nsg_v = (((m_v + 15) >> 4) + RS - 1) / RS;   // sub-groups of slice k
-  int incl_v = nsg_v;                                    // inclusive prefix over the offsets
+  const int nsg_v = (((m_v + 15) >> 4) + RS - 1) / RS;   // sub-groups of slice k (per contraction chunk)
+  int incl_v = KC * nsg_v;                               // inclusive prefix over the offsets
 #pragma unroll
   for (int o = 1; o < 32; o <<= 1) {   // K <= 32
     const int t = __shfl_up(incl_v, o, 64);
@@ -188,19 +193,24 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os6h_kernel(ConvArgsH a) {
   for (int t = 0; t < NCTT; ++t) btile[t] = (gt0 + t < a.nt16) ? t : 0;
 
   // position in the stream: sub-group G = sub-group j of slice (= offset) e; m pairs from pair s0. All wave-uniform (SGPRs).
-  struct Pos { int G, e, j, nsg, m, s0; };
+  struct Pos { int G, e, j, nsg, m, s0, c; };   // c: contraction chunk
   auto locate = [&](Pos &p, int G) {
     const unsigned long long later = __ballot(incl_v > G);   // the first offset whose inclusive prefix passes G holds it
     const int e = (int)__builtin_ctzll(later | (1ULL << 63));
     p.G = G; p.e = e;
     p.nsg = __builtin_amdgcn_readlane(nsg_v, e);
-    p.j = G - (__builtin_amdgcn_readlane(incl_v, e) - p.nsg);
+    p.j = G - (__builtin_amdgcn_readlane(incl_v, e) - KC * p.nsg);
+    p.c = 0;
+    if (KC > 1) {
+      while (p.j >= p.nsg) { p.j -= p.nsg; ++p.c; }   // chunk-major inside the slice: all sub-groups of chunk 0, then chunk 1 ...
+    }
     p.m = __builtin_amdgcn_readlane(m_v, e);
     p.s0 = __builtin_amdgcn_readlane(s0_v, e);
   };
   auto advance = [&](Pos &p) {  // past the tile's last sub-group the position stays (its loads are repeated, harmless)
     if (p.G + 1 >= total) return;
     if (p.j + 1 < p.nsg) { ++p.G; ++p.j; return; }
+    if (KC > 1 && p.c + 1 < KC) { ++p.G; p.j = 0; ++p.c; return; }
     locate(p, p.G + 1);
   };
   struct Ctx {
@@ -219,13 +229,13 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os6h_kernel(ConvArgsH a) {
 #pragma unroll
     for (int r = 0; r < RS; ++r) {
       const int rk = (p.j * RS + r) * 16 + l15;
-      cx.srow[r] = a.src + ((int64_t)(a.src_col ? pr[r].y : pr[r].x) * a.cin + 8 * g) * 2;
+      cx.srow[r] = a.src + ((int64_t)(a.src_col ? pr[r].y : pr[r].x) * a.cin + 32 * NS * p.c + 8 * g) * 2;
       cx.dloc[r] = rk < p.m ? (int)((a.src_col ? pr[r].x : pr[r].y) - row0) : T;
     }
     const int left = ((p.m + 15) >> 4) - p.j * RS;
     cx.nr = left < RS ? left : RS;
   };
-  auto wk_of = [&](const Pos &p) { return a.Wp + (((int64_t)p.e * a.nt16 + gt0) * NS) * 1024 + lane * 16; };
+  auto wk_of = [&](const Pos &p) { return a.Wp + (((int64_t)p.e * a.nt16 + gt0) * NST + NS * p.c) * 1024 + lane * 16; };
   struct AFrag { uint4 v[NS][RS]; };
   auto load_a = [&](AFrag &f, const Ctx &cx) {
 #pragma unroll
@@ -242,7 +252,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os6h_kernel(ConvArgsH a) {
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
-      for (int t = 0; t < NCTT; ++t) B[s][t] = *reinterpret_cast<const uint4 *>(wk + ((size_t)btile[t] * NS + s) * 1024);
+      for (int t = 0; t < NCTT; ++t) B[s][t] = *reinterpret_cast<const uint4 *>(wk + ((size_t)btile[t] * NST + s) * 1024);
   };
   AFrag A0, A1;
 #pragma unroll
@@ -251,7 +261,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os6h_kernel(ConvArgsH a) {
     for (int r = 0; r < RS; ++r) A0.v[s][r] = A1.v[s][r] = make_uint4(0u, 0u, 0u, 0u);
 
   Pos pc, pn;
-  pc.G = 0; pc.e = 0; pc.j = 0; pc.nsg = 1; pc.m = 1; pc.s0 = 0;
+  pc.G = 0; pc.e = 0; pc.j = 0; pc.nsg = 1; pc.m = 1; pc.s0 = 0; pc.c = 0;
   pn = pc;
   Ctx cur;
   int2 prn[RS];
@@ -297,7 +307,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os6h_kernel(ConvArgsH a) {
     Ctx nxt;
     make_ctx(nxt, pn, prn);
     load_a(An, nxt);
-    const bool reload = pn.e != pc.e;  // the next sub-group belongs to another offset (wave-uniform)
+    const bool reload = pn.e != pc.e || pn.c != pc.c;  // the next sub-group belongs to another offset / chunk (wave-uniform)
 
     f32x4 acc[RS][NCTT];
 #pragma unroll
@@ -446,13 +456,13 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os6h_kernel(ConvArgsH a) {
 #endif
 }
 
-template <typename HT, int NCTT, int NS, int RS, int NW>
+template <typename HT, int NCTT, int NS, int RS, int NW, int KC = 1>
 int launch6h(const ConvArgsH &a, hipStream_t st) {
   using C = Conv6hCfg<NCTT, NW>;
   const int64_t nblocks = a.order ? ceil_div(a.ntiles, 8) * 8 * a.ncoltiles : a.ntiles * a.ncoltiles;
   if (nblocks <= 0) return PCS_OK;
   if (nblocks > 0x7FFFFFFF) { set_error("pcs_conv_h: grid too large"); return PCS_EUNSUPPORTED; }
-  auto kern = conv_os6h_kernel<HT, NCTT, NS, RS, NW, 2>;
+  auto kern = conv_os6h_kernel<HT, NCTT, NS, RS, NW, 2, KC>;
   const size_t lds = C::lds_bytes(a.tile_rows);
   if (lds > kMaxDynLds) { set_error("pcs_conv_h: tile_rows too large for this column tile"); return PCS_EUNSUPPORTED; }
   static bool attr_set = false;
@@ -473,8 +483,12 @@ constexpr Ws6Shape kWs6Shapes[] = {{6, 3, 2}, {6, 4, 1}, {8, 3, 1}, {8, 4, 1}, {
 inline int conv6h_rs(int nctt, int ns) {
   for (const auto &e : kWs6Shapes)
     if (e.nctt == nctt && e.ns == ns) return e.rs;
+  if (nctt == 8 && (ns == 8 || ns == 12 || ns == 6)) return 1;   // chunked contractions (KC = 2 / 3 / 2)
+  if (nctt == 6 && ns == 6) return 2;
+  if (nctt == 6 && ns == 8) return 1;
   return 0;
 }
+inline bool conv6h_chunked(int nctt, int ns) { return ns > 4; }
 int g_ws_mode = -1, g_ws_rs = 0;  // debug / A-B overrides (pcs_debug_convh_ws); -1 / 0 = environment / default
 
 template <typename HT, int NW>
@@ -485,6 +499,12 @@ int dispatch6h(const ConvArgsH &a, int nctt, int rs, hipStream_t st) {
   PCS_C6H(6, 2, 2) PCS_C6H(2, 2, 2) PCS_C6H(2, 1, 2) PCS_C6H(4, 1, 2) PCS_C6H(6, 1, 2) PCS_C6H(8, 1, 2)
   PCS_C6H(6, 4, 1) PCS_C6H(8, 3, 1)
 #undef PCS_C6H
+  // chunked contractions: 256 / 384 / 192 input channels on 128-column tiles, 192 / 256 on 96-column tiles
+  if (nctt == 8 && a.ns == 8) return launch6h<HT, 8, 4, 1, NW, 2>(a, st);
+  if (nctt == 8 && a.ns == 12) return launch6h<HT, 8, 4, 1, NW, 3>(a, st);
+  if (nctt == 8 && a.ns == 6) return launch6h<HT, 8, 3, 1, NW, 2>(a, st);
+  if (nctt == 6 && a.ns == 6) return launch6h<HT, 6, 3, 2, NW, 2>(a, st);
+  if (nctt == 6 && a.ns == 8) return launch6h<HT, 6, 4, 1, NW, 2>(a, st);
   set_error("pcs_conv_gather_gemm_h(wave6h): no instance for this shape");
   return PCS_EUNSUPPORTED;
 }
@@ -497,9 +517,12 @@ bool conv6h_applies(int cin, int cout, int K) {
   if (!convh_applies(cin, cout, K) || cin % 32) return false;
   const int nctt = conv_nctt(cout), ns = cin / 32;
   if (conv6h_rs(nctt, ns) == 0) return false;
-  if (conv6h_mode() >= 2) return true;
+  if (conv6h_mode() >= 2 || conv6h_chunked(nctt, ns)) return true;
   // measured on the 12-frame bench maps (profiles/round6_convh_ws.md): 1.2-1.3x on the 64 ... 128-channel layers; the thin
   // shapes (<= 2 weight fragments per step and tile, or one step) stay on conv_wave5h.hip
+  // chunked contractions (192 ... 384 input channels): 1.06-1.26x on 4-wave workgroups (tiles <= 160 rows, two per CU), 0.6-0.8x on
+  // the 8-wave ones -- the entry point (conv_wave5h.hip) sends only tiles of <= 160 rows here, the picker (conv.hip) asks for 144
+  // rows where that pays (everything but 256 -> 256 on the big stride-8 level: 0.97x)
   if (K <= 8) return ns * nctt >= 16 && ns >= 3;   // k = 2 strided / transposed maps: one pair per row and offset
   return ns * nctt >= 8 && ns >= 2 && !(nctt == 8 && ns == 2);
 }
@@ -517,6 +540,8 @@ int launch_conv_wave6h(const ConvArgsH &a0, int dtype, hipStream_t st) {
 
 // 0: conv_wave5h.hip for everything; 1 (default): the shapes of conv6h_applies() that measured faster (policy below);
 // 2: every shape conv6h_applies() serves (A/B)
+bool conv6h_is_chunked(int cin, int cout) { return cin % 32 == 0 && conv6h_chunked(conv_nctt(cout), cin / 32); }
+
 int conv6h_mode() {
   static const int ws = getenv("PCS_CONVH_WS") ? atoi(getenv("PCS_CONVH_WS")) : 1;
   return g_ws_mode >= 0 ? g_ws_mode : ws;

@@ -192,14 +192,23 @@ def _cache_key(t):
 _cache_key.uncached = 0
 
 
+# Memo bookkeeping for measurement tools: `epoch` is bumped by the caller once per step (tools/modelbench.py); a hit on a memo made
+# in an earlier epoch (`cross`) means a step reused work of a previous step through a tensor object that outlived it.
+CACHE_STATS = {"hit": 0, "miss": 0, "cross": 0, "epoch": 0}
+
+
 def _cached(holder, name, key, make):
-    """holder.<name> = (key, value) memo; rebuilt when the key differs. Tensors that refuse attributes just recompute."""
+    """holder.<name> = (key, value[, epoch]) memo; rebuilt when the key differs. Tensors that refuse attributes just recompute."""
     hit = getattr(holder, name, None)
     if hit is not None and hit[0] == key:
+        CACHE_STATS["hit"] += 1
+        if len(hit) > 2 and hit[2] != CACHE_STATS["epoch"]:
+            CACHE_STATS["cross"] += 1
         return hit[1]
+    CACHE_STATS["miss"] += 1
     value = make()
     try:
-        setattr(holder, name, (key, value))
+        setattr(holder, name, (key, value, CACHE_STATS["epoch"]))
     except AttributeError:
         pass
     return value

@@ -50,24 +50,65 @@ class _RangeToPoint(Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, grad_out):
         pxpy, (b, c, h, w) = ctx.for_backwards
+        if _PENDING:
+            verify_pending()
         return native.backend().range_sample_bwd(grad_out.float().contiguous(), pxpy, b, h, w), None
 
 
+# The kernels return the rows in INPUT order; the reference's per-frame loop (rpvnet.py:36-50) returns them grouped by ascending
+# frame, which is the same thing exactly when the frame column is non-decreasing integers in [0, b) -- what a collated batch is.
+# Round 5 read that flag back with `.item()`: one device synchronisation per new pxpy tensor, i.e. per training step. Now the flag
+# is computed on the device, copied to pinned host memory behind the kernels, and VERIFIED LATER (at the next call of this module,
+# in backward, or by `verify_pending()`): a violation raises instead of returning rows in an order the reference would not.
+_PENDING = []       # (event, pinned flag, shape) of checks whose copy has not been looked at yet
+_FLAG_POOL = []
+
+
+def verify_pending(block=False):
+    """Look at the frame-order checks whose result has arrived (block=True: wait for all of them). Raises RuntimeError when a
+    `range_to_point` input had its frames out of order: its result was in input order, the reference's is grouped by frame."""
+    keep, bad = [], None
+    for ev, flag, shape in _PENDING:
+        if block:
+            ev.synchronize()
+        if ev.query():
+            if not bool(flag.item()):
+                bad = shape
+            _FLAG_POOL.append(flag)
+        else:
+            keep.append((ev, flag, shape))
+    _PENDING[:] = keep
+    if bad is not None:
+        raise RuntimeError("openpcseg_amd.rangelib.range_to_point: a pxpy tensor %s had its frame column out of order (not non-decreasing "
+                           "integers in [0, B)); the fused kernels returned its rows in input order, the reference regroups them by "
+                           "frame. Sort the points by frame, or call the reference's function for such inputs." % (bad,))
+
+
 def _frames_in_order(pxpy, b):
-    """True when the frame column is non-decreasing integers in [0, b): the reference's per-frame loop then returns the rows in
-    input order. One host read per pxpy tensor (the reference's boolean-mask indexing reads once per frame and call)."""
+    """True when the frame column is non-decreasing integers in [0, b). Device tensors: assumed, and verified asynchronously
+    (see above); host tensors: checked at once."""
     def check():
         f = pxpy[:, 0]
-        ok = (f >= 0) & (f < b) & (f == torch.floor(f))
-        return bool((ok.all() & (f[1:] >= f[:-1]).all()).item())
+        ok = ((f >= 0) & (f < b) & (f == torch.floor(f))).all() & (f[1:] >= f[:-1]).all()
+        if not pxpy.is_cuda:
+            return bool(ok.item())
+        flag = _FLAG_POOL.pop() if _FLAG_POOL else torch.empty((), dtype=torch.bool).pin_memory()
+        flag.copy_(ok, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _PENDING.append((ev, flag, tuple(pxpy.shape)))
+        return True
+    if _PENDING:
+        verify_pending()
     return native._cached(pxpy, "_pcs_frames_sorted", native._cache_key(pxpy) + (b,), check)
 
 
 def range_to_point(feature_map, pxpy, grid_sample_mode="bilinear", fallback=None):
     """(N, C) features of the points: bilinear samples of the (B, C, H, W) range feature map at pxpy (N, 3) = (frame, x, y) --
     R:pcseg/model/segmentor/fusion/rpvnet/rpvnet.py:31-51 without the loop over frames. Inputs the kernels do not serve (another
-    sampling mode, channel counts that are not a multiple of 4, rows whose frames are not grouped in ascending order -- the
-    reference would REORDER those --, host tensors) go to `fallback` (the reference's own function) when one is given."""
+    sampling mode, channel counts that are not a multiple of 4, host tensors) go to `fallback` (the reference's own function) when
+    one is given. Rows whose frames are not grouped in ascending order -- the reference would REORDER those -- are detected on the
+    device without a host read and raise at the next `verify_pending()` point (see `_frames_in_order`)."""
     # the kernels take float32 (any float16 / bfloat16 input only under CUDA autocast, whose custom_fwd casts to float32)
     f32 = (feature_map.dtype == torch.float32 and pxpy.dtype == torch.float32) or (
         torch.is_autocast_enabled("cuda") and feature_map.dtype in (torch.float32, torch.float16, torch.bfloat16) and

@@ -96,8 +96,12 @@ def _make_lidar_batch(n_frames, dev, elongation=False, range_view=False):
     f, l = feats.to(dev), labels.to(dev)
 
     def fresh():
-        d = {"lidar": SparseTensor(f, c), "targets": SparseTensor(l, c), "offset": None}
-        d.update(out)
+        # NEW tensor objects every step (views of the resident data): the memos this package hangs on caller tensors (pixel / corner
+        # CSRs, integer pxpy, frame-order flags: native._cached) must be rebuilt every step like in real training, where every
+        # batch is a new tensor -- round 5 handed the same objects to every step and never paid them after the first
+        cc = c.view_as(c)
+        d = {"lidar": SparseTensor(f.view_as(f), cc), "targets": SparseTensor(l.view_as(l), cc), "offset": None}
+        d.update({k: v.view_as(v) for k, v in out.items()})
         return d
     return fresh, int(c.shape[0])
 
@@ -123,7 +127,7 @@ def _cylinder_batch(n_frames, dev):
         ds.point_cloud_dataset.append({"labels": labels, "xyzret": pts, "path": "synthetic%d" % seed})
     b = mod.SemkittiCylinderDataset.collate_batch([ds.get_single_sample(i) for i in range(n_frames)])
     keep = {k: b[k].to(dev) for k in ("point_feature", "point_coord", "voxel_coord", "voxel_label", "point_label", "offset")}
-    return (lambda: dict(keep)), int(keep["voxel_coord"].shape[0])
+    return (lambda: {k: v.view_as(v) for k, v in keep.items()}), int(keep["voxel_coord"].shape[0])   # new tensor objects per step
 
 
 def _time_steps(step, steps, warmup):
@@ -175,7 +179,10 @@ def bench_one(name, source, dtype, dev, steps=10, warmup=2, want_step=False):
     opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-4, nesterov=True)
     amp = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(dtype)
 
+    from openpcseg_amd import native
+
     def step():
+        native.CACHE_STATS["epoch"] += 1   # memos made from here on belong to this step
         opt.zero_grad(set_to_none=True)
         if amp is None:
             ret = model(fresh())
@@ -188,7 +195,13 @@ def bench_one(name, source, dtype, dev, steps=10, warmup=2, want_step=False):
         return ret["loss"]
     if want_step:
         return step
+    native.CACHE_STATS["cross"] = 0
     sec = _time_steps(step, steps, warmup)
+    cross = native.CACHE_STATS["cross"]
+    if cross and os.environ.get("PCS_MB_ALLOW_CROSS_STEP_MEMOS", "0") != "1":
+        # a timed step reused a memo an earlier step left on a caller tensor (round 5: the range-image CSRs of RPVNet): not what a
+        # training loop with a new batch per step pays
+        raise RuntimeError("modelbench %s/%s: %d cross-step memo hits in the timed region" % (name, source, cross))
     loss = float(step().detach())
     if not np.isfinite(loss):
         raise RuntimeError("non-finite loss")
