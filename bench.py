@@ -638,20 +638,25 @@ def main():
         scaler = torch.amp.GradScaler("cuda") if amp == "fp16" else None  # the reference scales fp16 losses (train.py)
 
         pipe = None
-        if device_input:
-            # collate of the next batch on a side stream during the step (a DataLoader's prefetch): the voxel-count host read of
-            # device_collate no longer drains the launch queue inside the step (round 5: 7.0 ms per step on the driver's box)
+        if device_input and os.environ.get("PCS_BENCH_DI_PREFETCH", "0") == "1":
+            # opt-in: collate of the next batch on a side stream during the step (workloads/synthetic.py::DeviceInputPrefetcher).
+            # Measured [r6, profiles/round6_device_input_ab.txt]: 3.0 ms per step against 1.5 ms for the collate inside the step --
+            # the side stream's sort kernels slow the step's own more than the host read they hide -- so the record times the
+            # in-step form
             from openpcseg_amd.workloads.synthetic import DeviceInputPrefetcher
             pipe = DeviceInputPrefetcher(lambda i: raw_dev)
 
         def inputs():
             if device_input:
-                return pipe.next()
+                if pipe is not None:
+                    return pipe.next()
+                from openpcseg_amd.workloads.synthetic import device_collate
+                return device_collate(raw_dev)
             return fresh(batch)
 
         def step():
             loss = step_body()
-            if device_input:
+            if device_input and pipe is not None:
                 pipe.prefetch()
             return loss
 
@@ -682,17 +687,23 @@ def main():
             if distributed:
                 dist.barrier()
             torch.cuda.synchronize()
-            base_dt = None
+            base_dt = dev_dt = None
             if device_input:
-                # the same model from the pre-voxelised batch, back to back with the timed device-input steps: the difference of the
-                # two is the input work, measured in one thermal / clock state (two separately measured records differ by +-1 ms and,
-                # on a box still ramping, by far more)
-                t0 = time.perf_counter()
-                device_input = False
-                for _ in range(args.steps):
-                    step()
-                torch.cuda.synchronize()
-                base_dt = time.perf_counter() - t0
+                # the same model from the pre-voxelised batch and from the raw scans in ALTERNATING blocks of K steps (three of each);
+                # the record is the difference of the two medians. Round 5 timed one block of each back to back: at K = 5 a block's
+                # time moves by +-1 ms per step from block to block (the driver's run read 7.0 ms where the builder's read 1.9-2.9)
+                blocks = {False: [], True: []}
+                for _ in range(3):
+                    for flag in (False, True):
+                        device_input = flag
+                        step()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(args.steps):
+                            step()
+                        torch.cuda.synchronize()
+                        blocks[flag].append(time.perf_counter() - t0)
+                base_dt, dev_dt = sorted(blocks[False])[1], sorted(blocks[True])[1]
                 device_input = True
             meter.enabled = True
             with ClockSampler(dev_index) as clocks:
@@ -703,6 +714,8 @@ def main():
                 if distributed:
                     dist.barrier()
                 dt = time.perf_counter() - t0
+            if dev_dt is not None:
+                dt = dev_dt   # the median block (this last block served the conv meter and the clock sampler)
             meter.enabled = False
             roof = meter.summary(amp, split=(conv == "bf16x3"))
             clk = clocks.summary()

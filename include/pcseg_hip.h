@@ -34,7 +34,7 @@ extern "C" {
 #define PCS_ELAUNCH (-3)  /* hipLaunch / hipMemsetAsync failed (pcs_last_error has text) */
 #define PCS_EUNSUPPORTED (-4)
 
-#define PCS_ABI_VERSION 8
+#define PCS_ABI_VERSION 10
 
 int pcs_abi_version(void);
 const char *pcs_last_error(void);
@@ -230,6 +230,35 @@ int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t cin, const
                              const int32_t *seg, int32_t tile_rows, int64_t n_dst,
                              const float *bias, float *dst, double *bn_partial, const int32_t *tile_order,
                              void *stream);
+/* Write-back extras of the fused convolution (all optional; the plain entry = all NULL). Used by the backward pass:
+ *   addend : (n_dst, cout) in dst's dtype, added to every output row (dst = conv + bias + addend, in fp32 before any rounding).
+ *            dgrad of a convolution whose input also feeds a residual / skip path
+ *            (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:88-129 `relu(net(x) + downsample(x))`): the gradient the skip path
+ *            hands back rides in, instead of a separate elementwise sum of the two gradients (what autograd does around
+ *            TS:torchsparse/backend/convolution/convolution_cuda.cu:167-278).
+ *   bn_x / bn_mask / bn_stat : this launch is the dgrad that produces dy of a BatchNorm (+ ReLU) OUTPUT (minkunet.py:31-129:
+ *            conv -> BatchNorm -> ReLU -> conv): bn_x = that BatchNorm's input rows (n_dst, cout) in dst's dtype, bn_mask = its ReLU
+ *            gate, one bit per element ((n_dst, cout / 32) words as pcs_bn_apply_* writes them; NULL = no ReLU), bn_stat = its
+ *            mean[cout] | invstd[cout]. The write-back then leaves the BatchNorm's BACKWARD statistics sum(g), sum(g xhat),
+ *            g = dy [y > 0], per tile in `bn_partial` ([tiles][2][cout] doubles; reduce with pcs_bn_bwd_reduce_partials) -- the
+ *            statistics pass of torch's batch_norm_backward over (dy, x) disappears. Needs pcs_conv_emits_bn_partials() == 1.
+ * Shapes the wave kernels do not serve (pcs_conv_supports_epilogue() == 0) return PCS_EUNSUPPORTED when any extra is set. */
+typedef struct pcs_conv_epilogue {
+  const void *addend;
+  const void *bn_x;
+  const uint32_t *bn_mask;
+  const double *bn_stat;
+  float act_slope;   /* LeakyReLU fused into the write-back: dst = v < 0 ? v * act_slope : v, applied before the store and before the
+                      * forward BatchNorm statistics (R:pcseg/model/segmentor/voxel/cylinder3d/cylinder_ts.py:88-190: conv -> LeakyReLU
+                      * -> BatchNorm1d). 0 is read as 1 (no activation), so a zero-initialised struct is the plain call. */
+  int32_t reserved;
+} pcs_conv_epilogue;
+int pcs_conv_gather_gemm_f32_ex(const float *src, int64_t n_src, int32_t cin, const float *W,
+                                int32_t K, int32_t cout, const int32_t *pairs, int32_t src_col,
+                                const int32_t *seg, int32_t tile_rows, int64_t n_dst,
+                                const float *bias, const pcs_conv_epilogue *ep, float *dst, double *bn_partial,
+                                const int32_t *tile_order, void *stream);
+int32_t pcs_conv_supports_epilogue(int32_t cin, int32_t cout, int32_t K, int32_t dtype);   /* dtype 0 fp32, 1 / 2 half kernels */
 
 /* dst[k][b][a] = src[k][a][b]: the per-offset transposed weights dgrad contracts with (the reference transposes
  * inside torch::mm_out per offset, convolution_cuda.cu:259-263). */
@@ -336,6 +365,9 @@ int pcs_range_sample_bwd_csr_f32(const float *gout, const int64_t *order, const 
 int32_t pcs_bn_num_partials(void);
 int pcs_bn_stats_f32(const float *x, int64_t n, int32_t c, float *partial_ws, double *sums, void *stream);
 int pcs_bn_reduce_partials(const double *partial, int64_t nrows, int32_t c, int64_t n, double *sums, void *stream);
+/* Backward twin: [sum g | sum g xhat] (2c doubles followed by the same values as 2c floats; sums2_doubles >= 3c) from the per-tile
+ * partials of a dgrad write-back (pcs_conv_gather_gemm_*_ex with bn_x): replaces pcs_bn_bwd_stats_* for that BatchNorm. */
+int pcs_bn_bwd_reduce_partials(const double *partial, int64_t nrows, int32_t c, double *sums2, int64_t sums2_doubles, void *stream);
 int pcs_bn_reduce_partials_finalize(const double *partial, int64_t nrows, int32_t c, int64_t n, double eps, double momentum,
                                     float *running_mean, float *running_var, double *sums, double *stat, void *stream);
 int pcs_bn_finalize_f32(const double *sums, double count, const double *count_dev, int32_t c, double eps,
@@ -386,6 +418,10 @@ int pcs_bn_bwd_apply_h(const void *dy, const void *x, const void *y, const uint3
 int pcs_quantize_floor(const void *points, int32_t is_float, int64_t n, int32_t row_stride,
                        const double *voxel_size3, int32_t *coords, int32_t *bbox, void *stream);
 int pcs_quantize_keys(const int32_t *coords, int64_t n, const int32_t *bbox, int64_t *keys, void *stream);
+/* The same for a whole collated batch (TS:torchsparse/utils/quantize.py:15-21 per frame + TS:torchsparse/utils/collate.py:11-32):
+ * key = ((frame * ex + x - x0) * ey + y - y0) * ez + z - z0 over the BATCH's bounding box bbox = {x0, y0, z0, x1, y1, z1} (device,
+ * int32[6]); frames int64 per row. Ascending key = frames in order, inside a frame the reference's ravel-hash order. */
+int pcs_quantize_frame_keys(const int32_t *coords, const int64_t *frames, int64_t n, const int32_t *bbox, int64_t *keys, void *stream);
 int pcs_quantize_flags(const int64_t *sorted_keys, int64_t n, int32_t *flags, void *stream);
 int pcs_quantize_emit(const int32_t *flags, const int64_t *rank, const int64_t *perm, const int32_t *coords,
                       int64_t n, int32_t *vox, int64_t *index, int64_t *inverse, void *stream);
@@ -440,6 +476,11 @@ int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t cin, const vo
                            const int32_t *pairs, int32_t src_col, const int32_t *seg, int32_t tile_rows,
                            int64_t n_dst, const float *bias, void *dst, int32_t dtype, double *bn_partial,
                            const int32_t *tile_order, void *stream);
+/* with the write-back extras of pcs_conv_gather_gemm_f32_ex (addend / bn_x in the storage dtype) */
+int pcs_conv_gather_gemm_h_ex(const void *src, int64_t n_src, int32_t cin, const void *Wp, int32_t K, int32_t cout,
+                              const int32_t *pairs, int32_t src_col, const int32_t *seg, int32_t tile_rows,
+                              int64_t n_dst, const float *bias, const pcs_conv_epilogue *ep, void *dst, int32_t dtype,
+                              double *bn_partial, const int32_t *tile_order, void *stream);
 /* fp32 operands through the bf16 MFMAs (three-plane split, six products, fp32-grade result); same arguments as _f32 */
 int pcs_conv_wgrad_f32_bf16x3(const float *fa, int32_t ca, const float *fb, int32_t cb, const int32_t *pairs,
                               int32_t a_col, const int32_t *koff_dev, const int32_t *koff_host, int32_t K, float *gW,

@@ -132,8 +132,12 @@ def bn_forward(bn, input, residual=None, relu=False, cat_with=None):
         if pre is not None:
             sums, of, ver = pre
             pre = sums if (of is x and x._version == ver) else None
+        from . import fused as _fz
+        link = _fz.BNLink() if (_fz.LINK_BN_BWD and tail is None and torch.is_grad_enabled()) else None
         y = _FusedBN.apply(x, r, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu,
-                           isinstance(bn, nn.SyncBatchNorm), input.cmaps, input.stride, pre, tail)
+                           isinstance(bn, nn.SyncBatchNorm), input.cmaps, input.stride, pre, tail, link)
+        if link is not None and link.x is not None:
+            y._pcs_bn_link = link   # the one sparse convolution that consumes y leaves this BatchNorm's backward statistics (fused.BNLink)
     else:
         inv = torch.rsqrt(bn.running_var.double() + bn.eps)
         stat = torch.cat([bn.running_mean.double(), inv]).contiguous()
@@ -308,8 +312,21 @@ def _dense_linear_forward(self, x):
     return _PointLinear.apply(x, self.weight, self.bias)
 
 
+def _skip_through(conv, x):
+    """(conv(x), x routed through conv's autograd node) when the block's input also feeds its skip path: the dgrad kernel then adds
+    the skip gradient in its write-back instead of autograd summing two tensors (functional._SparseConv, with_skip) [r6]."""
+    if (os.environ.get("PCS_SKIP_FUSED", "1") != "0" and type(conv) is spnn.Conv3d and _quiet(conv) and torch.is_grad_enabled() and
+            isinstance(x, SparseTensor) and x.feats.requires_grad and tuple(conv.kernel_size) != (1, 1, 1)):
+        return conv(x, with_skip=True)
+    return conv(x), x
+
+
 def _run_plan(seq, plan, x, residual=None, final_relu=False):
+    """residual: a SparseTensor, or a callable xs -> SparseTensor that is handed the block input AFTER the first convolution ran
+    (so that the input can be routed through that convolution's autograd node, _skip_through)."""
     n = len(plan.steps)
+    if callable(residual) and not (n and plan.steps[0][0] == "cbr"):
+        residual = residual(x)
     for j, st in enumerate(plan.steps):
         if st[0] == "m":
             x = st[1](x)
@@ -322,7 +339,11 @@ def _run_plan(seq, plan, x, residual=None, final_relu=False):
                 x = st[3](x) if st[3] is not None else x
             continue
         _, conv, bn, act = st
-        h = conv(x)   # the module call (its hooks run); emit_bn_stats makes the write-back leave the BatchNorm statistics
+        if j == 0 and callable(residual):
+            h, xs = _skip_through(conv, x)
+            residual = residual(xs)
+        else:
+            h = conv(x)   # the module call (its hooks run); emit_bn_stats makes the write-back leave the BatchNorm statistics
         if not (isinstance(h, SparseTensor) and _backend_fuses(h.feats) and _quiet(bn) and (act is None or _quiet(act))):
             h = bn(h)
             x = act(h) if act is not None else h
@@ -376,8 +397,8 @@ def _residual_forward(self, x):
     plan, ds_plan = self.__dict__["_pcs_plan"]
     if not (isinstance(x, SparseTensor) and _quiet(self.relu) and _quiet(self.net) and _quiet(self.downsample)):
         return self.__dict__["_pcs_orig_class"].forward(self, x)
-    r = x if ds_plan is None else _run_plan(self.downsample, ds_plan, x)
-    return _run_plan(self.net, plan, x, residual=r, final_relu=True)
+    ds = self.downsample
+    return _run_plan(self.net, plan, x, residual=(lambda xs: xs if ds_plan is None else _run_plan(ds, ds_plan, xs)), final_relu=True)
 
 
 _FUSED_CLASSES = {}

@@ -210,12 +210,29 @@ extern "C" int32_t pcs_conv_uses_tile_order(int32_t cin, int32_t cout, int32_t K
   return (dtype == 0 ? conv5_applies(cin, cout, K) : convh_applies(cin, cout, K)) ? 1 : 0;
 }
 
+extern "C" int32_t pcs_conv_supports_epilogue(int32_t cin, int32_t cout, int32_t K, int32_t dtype) {
+  if (cin <= 0 || cout <= 0 || K <= 0 || K > 32) return 0;
+  if (dtype == 0) return (cin % 4 == 0 && cout % 4 == 0) ? 1 : 0;   // the wave kernels (conv_os5 / conv_os4)
+  return convh_applies(cin, cout, K) ? 1 : 0;
+}
+
 extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t cin,
                                         const float *W, int32_t K, int32_t cout,
                                         const int32_t *pairs, int32_t src_col,
                                         const int32_t *seg, int32_t tile_rows, int64_t n_dst,
                                         const float *bias, float *dst, double *bn_partial,
                                         const int32_t *tile_order, void *stream) {
+  return pcs_conv_gather_gemm_f32_ex(src, n_src, cin, W, K, cout, pairs, src_col, seg, tile_rows, n_dst, bias, nullptr, dst,
+                                     bn_partial, tile_order, stream);
+}
+
+extern "C" int pcs_conv_gather_gemm_f32_ex(const float *src, int64_t n_src, int32_t cin,
+                                           const float *W, int32_t K, int32_t cout,
+                                           const int32_t *pairs, int32_t src_col,
+                                           const int32_t *seg, int32_t tile_rows, int64_t n_dst,
+                                           const float *bias, const pcs_conv_epilogue *ep, float *dst, double *bn_partial,
+                                           const int32_t *tile_order, void *stream) {
+  const float *addend = ep ? reinterpret_cast<const float *>(ep->addend) : nullptr;
   if (cin <= 0 || cout <= 0 || K <= 0 || n_dst < 0 || n_src < 0 || (src_col != 0 && src_col != 1)) {
     set_error("pcs_conv_gather_gemm_f32: bad sizes");
     return PCS_EINVAL;
@@ -228,6 +245,16 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
   a.n_dst = n_dst; a.ntiles = ceil_div(n_dst, tile_rows); a.tile_rows = tile_rows;
   a.cin = cin; a.cout = cout; a.K = K; a.src_col = src_col; a.ncoltiles = 1; a.stats = bn_partial;
   a.order = tile_order;
+  a.addend = addend;
+  if (addend && ((uintptr_t)addend & 15)) { set_error("pcs_conv_gather_gemm_f32_ex: misaligned addend"); return PCS_EINVAL; }
+  if (ep && ep->bn_x) {
+    if (!bn_partial || !ep->bn_stat || ((uintptr_t)ep->bn_x & 15) || (ep->bn_mask && (cout & 31))) {
+      set_error("pcs_conv_gather_gemm_f32_ex: BatchNorm backward statistics need bn_partial, bn_stat, 16-byte aligned bn_x and cout %% 32 == 0 with a gate mask");
+      return PCS_EINVAL;
+    }
+    a.gs_x = ep->bn_x; a.gs_mask = ep->bn_mask; a.gs_stat = ep->bn_stat;
+  }
+  if (ep && ep->act_slope != 0.f && ep->act_slope != 1.f) a.act_slope = ep->act_slope;
   if (bn_partial && !pcs_conv_emits_bn_partials(cin, cout, K, tile_rows, 0)) {
     set_error("pcs_conv_gather_gemm_f32: this shape / tile height does not produce BatchNorm partials (ask pcs_conv_emits_bn_partials)");
     return PCS_EUNSUPPORTED;
@@ -241,6 +268,10 @@ extern "C" int pcs_conv_gather_gemm_f32(const float *src, int64_t n_src, int32_t
   static const int generic = getenv("PCS_CONV_V1") ? atoi(getenv("PCS_CONV_V1")) : 0;  // 1: generic kernel only (debug)
   if (bn_partial && (!vec || generic || (!conv5_applies(cin, cout, K) && K > 32))) {
     set_error("pcs_conv_gather_gemm_f32: BatchNorm partials need the 16-byte-granular wave kernels");
+    return PCS_EUNSUPPORTED;
+  }
+  if ((addend || a.gs_x || a.act_slope != 1.f) && !(vec && !generic && K <= 32)) {
+    set_error("pcs_conv_gather_gemm_f32_ex: this shape runs on the generic kernel, which takes no write-back extras (pcs_conv_supports_epilogue)");
     return PCS_EUNSUPPORTED;
   }
   if (vec && !generic && conv_ringf_applies(cin, cout, K, tile_rows, nullptr)) return launch_conv_ring6f(a, st);

@@ -57,6 +57,23 @@ struct ConvArgs {
   double *stats;  // optional [ntiles][2][cout]: per-tile column sums / sums of squares of the rows written (BatchNorm)
   const int32_t *order;  // optional [ntiles]: workgroup slot -> row tile (heaviest first), nullptr = row order
   int ring_acc_off = 0;  // ring kernel (conv_ring6f.hip): byte offset of the accumulator tile in LDS
+  const float *addend = nullptr;  // optional (n_dst, cout): added to the output rows in the write-back (the wave kernels only):
+                                  // the skip gradient of a residual block riding in the dgrad of its first convolution
+  // optional: this launch is a dgrad whose output IS the gradient dy of a BatchNorm (+ ReLU) output -- its write-back then leaves
+  // that BatchNorm's backward statistics sum(g), sum(g xhat), g = dy [y > 0], per tile in `stats` (instead of the forward sums)
+  float act_slope = 1.f;              // LeakyReLU in the write-back: v < 0 -> v * act_slope (1 = none), before the store and the statistics
+  const void *gs_x = nullptr;         // the BatchNorm's input rows (n_dst, cout), dst's dtype
+  const uint32_t *gs_mask = nullptr;  // its ReLU gate, one bit per element (n_dst, cout / 32 words), NULL = no ReLU
+  const double *gs_stat = nullptr;    // mean[cout] | invstd[cout]
+};
+
+// element type of gs_x in the shared epilogues
+enum { kGsF32 = 0, kGsBf16 = 1, kGsFp16 = 2 };
+struct GStat {
+  const void *x;
+  const uint32_t *mask;
+  const double *stat;
+  int dtype;
 };
 
 // storage-format tags of the half-precision kernels (features / prepared weights / outputs)
@@ -133,24 +150,51 @@ inline bool convh_applies(int cin, int cout, int K) {
 // follows the convolution: the sums are taken about the tile's first row in fp32, reduced over
 // the row groups in a fixed order through the (now free) tile, and un-shifted in double (deterministic; needs
 // T >= 2 NRG rows of scratch, conv_stats_fit()).
+// four consecutive elements of a row-major (fp32 / bf16 / fp16) tensor, widened
+__device__ __forceinline__ float4 gs_load4(const void *p, int dtype, int64_t idx) {
+  if (dtype == kGsF32) return *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p) + idx);
+  const uint2 u = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(p) + idx);
+  if (dtype == kGsBf16)
+    return make_float4(h2f(Bf16{}, (uint16_t)(u.x & 0xFFFFu)), h2f(Bf16{}, (uint16_t)(u.x >> 16)), h2f(Bf16{}, (uint16_t)(u.y & 0xFFFFu)),
+                       h2f(Bf16{}, (uint16_t)(u.y >> 16)));
+  return make_float4(h2f(Fp16{}, (uint16_t)(u.x & 0xFFFFu)), h2f(Fp16{}, (uint16_t)(u.x >> 16)), h2f(Fp16{}, (uint16_t)(u.y & 0xFFFFu)),
+                     h2f(Fp16{}, (uint16_t)(u.y >> 16)));
+}
+
+// `gs` (with `stats`): BatchNorm BACKWARD statistics of the rows written -- sum(g), sum(g xhat) with g = stored value x ReLU gate,
+// xhat = (x - mean) invstd of the BatchNorm whose output gradient this launch produces (ConvArgs::gs_*); row0 = the tile's first row.
 template <int CT, int NT, typename Store>
 __device__ __forceinline__ void conv_tile_epilogue(float *acc_l, int ACS, int rows, int n0, int cout, const float *bias,
-                                                   double *stats, int tid, Store store) {
+                                                   double *stats, int tid, Store store, const GStat *gs = nullptr, int64_t row0 = 0) {
   constexpr int Q = CT / 4, NRG = NT / Q;
   const int q = tid % Q, rg = tid / Q, cq = 4 * q;
   const bool on = rg < NRG && n0 + cq < cout;
-  float4 b = make_float4(0.f, 0.f, 0.f, 0.f), piv = b, s0 = b, s1 = b;
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f), piv = b, s0 = b, s1 = b, gm = b, gi = b;
   if (on) {
     if (bias) b = *reinterpret_cast<const float4 *>(bias + n0 + cq);
-    if (stats) {
+    if (stats && !gs) {
       piv = *reinterpret_cast<const float4 *>(acc_l + cq);
       piv.x += b.x; piv.y += b.y; piv.z += b.z; piv.w += b.w;
+    }
+    if (stats && gs) {
+      const int ch = n0 + cq;
+      gm = make_float4((float)gs->stat[ch], (float)gs->stat[ch + 1], (float)gs->stat[ch + 2], (float)gs->stat[ch + 3]);
+      gi = make_float4((float)gs->stat[cout + ch], (float)gs->stat[cout + ch + 1], (float)gs->stat[cout + ch + 2], (float)gs->stat[cout + ch + 3]);
     }
     for (int r = rg; r < rows; r += NRG) {
       float4 v = *reinterpret_cast<const float4 *>(acc_l + r * ACS + cq);
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
       const float4 sv = store(r, cq, v);
-      if (stats) {
+      if (stats && gs) {
+        const int ch = n0 + cq;
+        const float4 xv = gs_load4(gs->x, gs->dtype, (row0 + r) * (int64_t)cout + ch);
+        unsigned bits = 0xFu;
+        if (gs->mask) bits = (gs->mask[(row0 + r) * (int64_t)(cout >> 5) + (ch >> 5)] >> (ch & 31)) & 0xFu;
+        const float g0 = (bits & 1u) ? sv.x : 0.f, g1 = (bits & 2u) ? sv.y : 0.f, g2 = (bits & 4u) ? sv.z : 0.f, g3 = (bits & 8u) ? sv.w : 0.f;
+        s0.x += g0; s0.y += g1; s0.z += g2; s0.w += g3;
+        s1.x += g0 * ((xv.x - gm.x) * gi.x); s1.y += g1 * ((xv.y - gm.y) * gi.y);
+        s1.z += g2 * ((xv.z - gm.z) * gi.z); s1.w += g3 * ((xv.w - gm.w) * gi.w);
+      } else if (stats) {
         const float dx = sv.x - piv.x, dy = sv.y - piv.y, dz = sv.z - piv.z, dw = sv.w - piv.w;
         s0.x += dx; s0.y += dy; s0.z += dz; s0.w += dw;
         s1.x += dx * dx; s1.y += dy * dy; s1.z += dz * dz; s1.w += dw * dw;

@@ -45,6 +45,15 @@ struct ConvArgsH {
   double *stats;  // optional [ntiles][2][cout], as ConvArgs::stats (over the ROUNDED values stored)
   const int32_t *order;  // optional [ntiles]: workgroup slot -> row tile (heaviest first), as ConvArgs::order
   int ring_bt_cap, ring_acc_off;  // experimental ring kernel only (tools/experimental): batch-table capacity, accumulator-tile offset in LDS
+  const uint16_t *addend = nullptr;  // optional (n_dst, cout) halfs: added (in fp32, before the rounding) to the output rows
+  float act_slope = 1.f;              // LeakyReLU in the write-back, as ConvArgs::act_slope
+  const void *gs_x = nullptr;         // BatchNorm backward statistics in the write-back, as ConvArgs::gs_* (x in the storage dtype)
+  const uint32_t *gs_mask = nullptr;
+  const double *gs_stat = nullptr;
 };
+
+template <typename HT> struct GsType;
+template <> struct GsType<Bf16> { static constexpr int value = kGsBf16; };
+template <> struct GsType<Fp16> { static constexpr int value = kGsFp16; };
 
 }  // namespace pcs

@@ -274,11 +274,21 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os4_kernel(ConvArgs a) {
   const int rows = (int)((a.n_dst - row0) < (int64_t)T ? (a.n_dst - row0) : (int64_t)T);
   float *drow = a.dst + row0 * a.cout + n0;
   const int ldd = a.cout;
+  const GStat gstat{a.gs_x, a.gs_mask, a.gs_stat, kGsF32};
   conv_tile_epilogue<C::CT, C::NT>(acc_l, C::ACS, rows, n0, a.cout, a.bias, a.stats ? a.stats + tile * 2 * a.cout : nullptr, tid,
-                                   [&](int r, int cq, const float4 &v) {
+                                   [&](int r, int cq, const float4 &v0) {
+                                     float4 v = v0;
+                                     if (a.addend) {  // kernel argument: uniform
+                                       const float4 ad = *reinterpret_cast<const float4 *>(a.addend + (row0 + r) * (int64_t)ldd + n0 + cq);
+                                       v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                                     }
+                                     if (a.act_slope != 1.f) {
+                                       v.x = v.x < 0.f ? v.x * a.act_slope : v.x; v.y = v.y < 0.f ? v.y * a.act_slope : v.y;
+                                       v.z = v.z < 0.f ? v.z * a.act_slope : v.z; v.w = v.w < 0.f ? v.w * a.act_slope : v.w;
+                                     }
                                      *reinterpret_cast<float4 *>(drow + (int64_t)r * ldd + cq) = v;
                                      return v;
-                                   });
+                                   }, a.gs_x ? &gstat : nullptr, row0);
 }
 
 template <int NCTT, int T, int NW, int MINW>

@@ -509,15 +509,26 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os5h_kernel(ConvArgsH a) {
   const int rows = (int)((a.n_dst - row0) < (int64_t)T ? (a.n_dst - row0) : (int64_t)T);
   uint16_t *drow = a.dst + row0 * a.cout + n0;
   const int ldd = a.cout;
+  const GStat gstat{a.gs_x, a.gs_mask, a.gs_stat, GsType<HT>::value};
   conv_tile_epilogue<C::CT, C::NT>(acc_l, C::ACS, rows, n0, a.cout, a.bias, a.stats ? a.stats + tile * 2 * a.cout : nullptr, tid,
-                                   [&](int r, int cq, const float4 &v) {
+                                   [&](int r, int cq, const float4 &v0) {
+                                     float4 v = v0;
+                                     if (a.addend) {  // kernel argument: uniform
+                                       const uint2 ad = *reinterpret_cast<const uint2 *>(a.addend + (row0 + r) * (int64_t)ldd + n0 + cq);
+                                       v.x += h2f(HT{}, (uint16_t)(ad.x & 0xFFFFu)); v.y += h2f(HT{}, (uint16_t)(ad.x >> 16));
+                                       v.z += h2f(HT{}, (uint16_t)(ad.y & 0xFFFFu)); v.w += h2f(HT{}, (uint16_t)(ad.y >> 16));
+                                     }
+                                     if (a.act_slope != 1.f) {
+                                       v.x = v.x < 0.f ? v.x * a.act_slope : v.x; v.y = v.y < 0.f ? v.y * a.act_slope : v.y;
+                                       v.z = v.z < 0.f ? v.z * a.act_slope : v.z; v.w = v.w < 0.f ? v.w * a.act_slope : v.w;
+                                     }
                                      const uint16_t hx = f2h(HT{}, v.x), hy = f2h(HT{}, v.y), hz = f2h(HT{}, v.z), hw = f2h(HT{}, v.w);
                                      uint2 o;
                                      o.x = hx | ((uint32_t)hy << 16);
                                      o.y = hz | ((uint32_t)hw << 16);
                                      *reinterpret_cast<uint2 *>(drow + (int64_t)r * ldd + cq) = o;
                                      return make_float4(h2f(HT{}, hx), h2f(HT{}, hy), h2f(HT{}, hz), h2f(HT{}, hw));
-                                   });
+                                   }, a.gs_x ? &gstat : nullptr, row0);
 #if PCS_TRACE
   if (lane == 0 && blockIdx.x < kTraceBlocksH && g_convh_trace) {
     long long *t = g_convh_trace + ((int64_t)blockIdx.x * 8 + wid) * 8;
@@ -634,6 +645,15 @@ extern "C" int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t ci
                                       const int32_t *pairs, int32_t src_col, const int32_t *seg, int32_t tile_rows,
                                       int64_t n_dst, const float *bias, void *dst, int32_t dtype, double *bn_partial,
                                       const int32_t *tile_order, void *stream) {
+  return pcs_conv_gather_gemm_h_ex(src, n_src, cin, Wp, K, cout, pairs, src_col, seg, tile_rows, n_dst, bias, nullptr, dst, dtype,
+                                   bn_partial, tile_order, stream);
+}
+
+extern "C" int pcs_conv_gather_gemm_h_ex(const void *src, int64_t n_src, int32_t cin, const void *Wp, int32_t K, int32_t cout,
+                                         const int32_t *pairs, int32_t src_col, const int32_t *seg, int32_t tile_rows,
+                                         int64_t n_dst, const float *bias, const pcs_conv_epilogue *ep, void *dst, int32_t dtype,
+                                         double *bn_partial, const int32_t *tile_order, void *stream) {
+  const void *addend = ep ? ep->addend : nullptr;
   if (cin <= 0 || cout <= 0 || K <= 0 || n_dst < 0 || n_src < 0 || (src_col != 0 && src_col != 1) || (dtype != 1 && dtype != 2)) {
     set_error("pcs_conv_gather_gemm_h: bad sizes");
     return PCS_EINVAL;
@@ -648,6 +668,16 @@ extern "C" int pcs_conv_gather_gemm_h(const void *src, int64_t n_src, int32_t ci
   a.dst = reinterpret_cast<uint16_t *>(dst); a.pairs = pairs; a.seg = seg;
   a.n_dst = n_dst; a.ntiles = ceil_div(n_dst, tile_rows); a.tile_rows = tile_rows;
   a.cin = cin; a.cout = cout; a.K = K; a.src_col = src_col; a.ncoltiles = 1; a.xcd_remap = 1; a.stats = bn_partial; a.order = tile_order;
+  a.addend = reinterpret_cast<const uint16_t *>(addend);
+  if (addend && ((uintptr_t)addend & 7)) { set_error("pcs_conv_gather_gemm_h_ex: misaligned addend"); return PCS_EINVAL; }
+  if (ep && ep->bn_x) {
+    if (!bn_partial || !ep->bn_stat || ((uintptr_t)ep->bn_x & 7) || (ep->bn_mask && (cout & 31))) {
+      set_error("pcs_conv_gather_gemm_h_ex: BatchNorm backward statistics need bn_partial, bn_stat, aligned bn_x and cout %% 32 == 0 with a gate mask");
+      return PCS_EINVAL;
+    }
+    a.gs_x = ep->bn_x; a.gs_mask = ep->bn_mask; a.gs_stat = ep->bn_stat;
+  }
+  if (ep && ep->act_slope != 0.f && ep->act_slope != 1.f) a.act_slope = ep->act_slope;
   if (bn_partial && !pcs_conv_emits_bn_partials(cin, cout, K, tile_rows, dtype)) {
     set_error("pcs_conv_gather_gemm_h: this shape / tile height does not produce BatchNorm partials");
     return PCS_EUNSUPPORTED;

@@ -70,7 +70,7 @@ struct Conv6hCfg {
 // the row groups in a fixed order through the free tile, un-shifted in double. Needs T >= 2 NRG + 1 rows of scratch for stats.
 template <typename HT, int CT, int NT>
 __device__ __forceinline__ void half_tile_epilogue8(float *acc_l, int ACS, int rows, int n0, int cout, const float *bias, double *stats,
-                                                    int tid, uint16_t *drow, int ldd) {
+                                                    int tid, uint16_t *drow, int ldd, const uint16_t *arow, float act_slope) {
   constexpr int Q = CT / 8, NRG = NT / Q;
   const int q = tid % Q, rg = tid / Q, c8 = 8 * q;
   const bool on = rg < NRG && n0 + c8 < cout;   // cout % 8 == 0: a piece is inside or outside as a whole
@@ -89,7 +89,18 @@ __device__ __forceinline__ void half_tile_epilogue8(float *acc_l, int ACS, int r
     }
     for (int r = rg; r < rows; r += NRG) {
       const float4 v0 = *reinterpret_cast<const float4 *>(acc_l + r * ACS + c8), v1 = *reinterpret_cast<const float4 *>(acc_l + r * ACS + c8 + 4);
-      const float v[8] = {v0.x + b[0], v0.y + b[1], v0.z + b[2], v0.w + b[3], v1.x + b[4], v1.y + b[5], v1.z + b[6], v1.w + b[7]};
+      float v[8] = {v0.x + b[0], v0.y + b[1], v0.z + b[2], v0.w + b[3], v1.x + b[4], v1.y + b[5], v1.z + b[6], v1.w + b[7]};
+      if (arow) {  // the addend's rows of this tile (kernel argument: uniform)
+        const uint4 ad = *reinterpret_cast<const uint4 *>(arow + (int64_t)r * ldd + c8);
+        v[0] += h2f(HT{}, (uint16_t)(ad.x & 0xFFFFu)); v[1] += h2f(HT{}, (uint16_t)(ad.x >> 16));
+        v[2] += h2f(HT{}, (uint16_t)(ad.y & 0xFFFFu)); v[3] += h2f(HT{}, (uint16_t)(ad.y >> 16));
+        v[4] += h2f(HT{}, (uint16_t)(ad.z & 0xFFFFu)); v[5] += h2f(HT{}, (uint16_t)(ad.z >> 16));
+        v[6] += h2f(HT{}, (uint16_t)(ad.w & 0xFFFFu)); v[7] += h2f(HT{}, (uint16_t)(ad.w >> 16));
+      }
+      if (act_slope != 1.f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] < 0.f ? v[j] * act_slope : v[j];
+      }
       uint16_t h[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) h[j] = f2h(HT{}, v[j]);
@@ -435,17 +446,29 @@ __global__ void __launch_bounds__(64 * NW, MINW) conv_os6h_kernel(ConvArgsH a) {
   uint16_t *drow = a.dst + row0 * a.cout + n0;
   const int ldd = a.cout;
   double *stats = a.stats ? a.stats + tile * 2 * a.cout : nullptr;
-  if ((a.cout & 7) == 0 && ((uintptr_t)a.dst & 15) == 0 && (!stats || T + C::SINK >= 2 * C::NRG8 + 1)) {
-    half_tile_epilogue8<HT, C::CT, C::NT>(acc_l, C::ACS, rows, n0, a.cout, a.bias, stats, tid, drow, ldd);
+  const GStat gstat{a.gs_x, a.gs_mask, a.gs_stat, GsType<HT>::value};
+  if (!a.gs_x && (a.cout & 7) == 0 && (((uintptr_t)a.dst | (uintptr_t)a.addend) & 15) == 0 && (!stats || T + C::SINK >= 2 * C::NRG8 + 1)) {
+    half_tile_epilogue8<HT, C::CT, C::NT>(acc_l, C::ACS, rows, n0, a.cout, a.bias, stats, tid, drow, ldd,
+                                          a.addend ? a.addend + row0 * a.cout + n0 : nullptr, a.act_slope);
   } else {
-    conv_tile_epilogue<C::CT, C::NT>(acc_l, C::ACS, rows, n0, a.cout, a.bias, stats, tid, [&](int r, int cq4, const float4 &v) {
+    conv_tile_epilogue<C::CT, C::NT>(acc_l, C::ACS, rows, n0, a.cout, a.bias, stats, tid, [&](int r, int cq4, const float4 &v0) {
+      float4 v = v0;
+      if (a.addend) {
+        const uint2 ad = *reinterpret_cast<const uint2 *>(a.addend + (row0 + r) * (int64_t)ldd + n0 + cq4);
+        v.x += h2f(HT{}, (uint16_t)(ad.x & 0xFFFFu)); v.y += h2f(HT{}, (uint16_t)(ad.x >> 16));
+        v.z += h2f(HT{}, (uint16_t)(ad.y & 0xFFFFu)); v.w += h2f(HT{}, (uint16_t)(ad.y >> 16));
+      }
+      if (a.act_slope != 1.f) {
+        v.x = v.x < 0.f ? v.x * a.act_slope : v.x; v.y = v.y < 0.f ? v.y * a.act_slope : v.y;
+        v.z = v.z < 0.f ? v.z * a.act_slope : v.z; v.w = v.w < 0.f ? v.w * a.act_slope : v.w;
+      }
       const uint16_t hx = f2h(HT{}, v.x), hy = f2h(HT{}, v.y), hz = f2h(HT{}, v.z), hw = f2h(HT{}, v.w);
       uint2 o;
       o.x = hx | ((uint32_t)hy << 16);
       o.y = hz | ((uint32_t)hw << 16);
       *reinterpret_cast<uint2 *>(drow + (int64_t)r * ldd + cq4) = o;
       return make_float4(h2f(HT{}, hx), h2f(HT{}, hy), h2f(HT{}, hz), h2f(HT{}, hw));
-    });
+    }, a.gs_x ? &gstat : nullptr, row0);
   }
 #if PCS_TRACE
   if (lane == 0 && g_ws_trace && (int)blockIdx.x < g_ws_trace_blocks) {

@@ -47,11 +47,20 @@ __device__ __forceinline__ void find_split(const int32_t *koff, int K, int pch, 
 
 // The same lookup by a whole wave at once (K <= 64): lane k loads its offset's slice bounds, one wave scan finds the
 // offset of `split` -- one load latency instead of up to K dependent ones at the head of every workgroup.
+// `split` is the workgroup's position in LAUNCH order; `*gsid` the global split (offset-major) whose partial block it writes.
+// interleave = 0: launch order = offset-major: the resident workgroups sweep one offset after the other, and each of the K
+// sweeps streams the whole level's rows (both operands) from HBM -- the level (2 x 222 MB in bf16 at stride 1) does not survive
+// in the 256 MB Infinity Cache from one sweep to the next.
+// interleave = 1 [r6, opt-in: PCS_WGRAD_INTERLEAVE=1, measured neutral]: launch order = position-major. Round r (of R = the largest split count of an offset) holds, for every
+// offset k, its split floor(r ns_k / R) when that value is new in round r: the resident workgroups then cover the SAME stretch of
+// destination rows under all K offsets at once, so a feature row fetched for one offset serves the others out of L2 / the
+// Infinity Cache. The splits, the partial blocks and the fixed-order reduction are unchanged: bit-identical results.
 __device__ __forceinline__ void find_split_wave(const int32_t *koff, int K, int pch, int split, int lane, int *beg,
-                                                int *end) {
+                                                int *end, int *gsid, int interleave) {
   if (K > 64) {
     int k;
     find_split(koff, K, pch, split, &k, beg, end);
+    *gsid = split;
     return;
   }
   const int lo = lane < K ? koff[lane] : 0, hi = lane < K ? koff[lane + 1] : 0;
@@ -61,13 +70,49 @@ __device__ __forceinline__ void find_split_wave(const int32_t *koff, int K, int 
     const int t = __shfl_up(incl, o, 64);
     if (lane >= o) incl += t;
   }
-  const unsigned long long hit = __ballot(split >= incl - ns && split < incl);  // at most one lane
-  if (!hit) { *beg = 0; *end = 0; return; }
-  const int src = __ffsll((long long)hit) - 1;
-  const int b = lo + (split - (incl - ns)) * pch;
-  const int e = b + pch < hi ? b + pch : hi;
-  *beg = __shfl(b, src, 64);
-  *end = __shfl(e, src, 64);
+  int src, sidx;   // offset (lane) and split inside it
+  if (!interleave) {
+    const unsigned long long hit = __ballot(split >= incl - ns && split < incl);  // at most one lane
+    if (!hit) { *beg = 0; *end = 0; *gsid = split; return; }
+    src = __ffsll((long long)hit) - 1;
+    sidx = split - __shfl(incl - ns, src, 64);
+  } else {
+    const int total = __shfl(incl, 63, 64);
+    if (interleave == 2) {
+      // XCD-aware: workgroup i runs on XCD i % 8 (observed placement); give XCD x the x-th CONTIGUOUS eighth of the position-major
+      // sequence, so that all offsets of a stretch of rows meet in ONE L2 (the grid is padded to 8 ceil(total / 8) workgroups)
+      const int chunk = (total + 7) >> 3;
+      split = (split & 7) * chunk + (split >> 3);
+    }
+    if (split >= total) { *beg = 0; *end = 0; *gsid = 0; return; }
+    int rmax = ns;
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(rmax, o, 64); rmax = t > rmax ? t : rmax; }
+    // C(r) = workgroups in rounds 0 .. r = sum over the non-empty offsets of floor(r ns_k / R) + 1; smallest r with C(r) > split
+    auto upto = [&](int r) {
+      int c = ns > 0 ? (int)(((long long)r * ns) / rmax) + 1 : 0;
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+      return c;
+    };
+    int a = 0, b = rmax - 1;
+    while (a < b) {
+      const int m = (a + b) >> 1;
+      if (upto(m) > split) b = m; else a = m + 1;
+    }
+    const int r = a;
+    const int before = r > 0 ? upto(r - 1) : 0;
+    const int s_r = ns > 0 ? (int)(((long long)r * ns) / rmax) : -1;
+    const int s_p = (ns > 0 && r > 0) ? (int)(((long long)(r - 1) * ns) / rmax) : -1;
+    unsigned long long fresh = __ballot(ns > 0 && s_r != s_p);
+    int want = split - before;   // the want-th (ascending offset) fresh split of round r
+    while (want > 0) { fresh &= fresh - 1; --want; }
+    src = __ffsll((long long)fresh) - 1;
+    sidx = __shfl(s_r, src, 64);
+  }
+  const int b0 = lo + sidx * pch;
+  const int e0 = b0 + pch < hi ? b0 + pch : hi;
+  *beg = __shfl(b0, src, 64);
+  *end = __shfl(e0, src, 64);
+  *gsid = __shfl(incl - ns, src, 64) + sidx;
 }
 
 template <bool VEC>
@@ -286,6 +331,7 @@ struct Wgrad2Args {
   const int32_t *koff;
   float *partial;  // [nsplit_total][ca][cb]
   int ca, cb, K, a_col, pch, nbg;  // nbg = number of b-groups
+  int interleave;                  // launch order of the splits (find_split_wave)
 };
 
 __host__ __device__ inline int wg_ngroups(int c) { return (c + 63) / 64; }
@@ -430,8 +476,8 @@ __device__ __forceinline__ void wgrad_block(const Wgrad2Args &w, int a0, int b0,
 template <typename ET>
 __global__ void __launch_bounds__(256, 3) wgrad2_kernel(Wgrad2Args w) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  int beg, end;
-  find_split_wave(w.koff, w.K, w.pch, blockIdx.x, lane, &beg, &end);  // per wave: no LDS, no barrier
+  int beg, end, gsid;
+  find_split_wave(w.koff, w.K, w.pch, blockIdx.x, lane, &beg, &end, &gsid, w.interleave);  // per wave: no LDS, no barrier
   // the four waves of a workgroup own a 2 x 2 patch of output blocks: each A slice and each B slice they gather is
   // shared by two of them through the vector L1 (a 1 x 4 row shared one A slice and read four B slices: 5 slice
   // streams per workgroup instead of 4, +20 % L2 traffic at 256 columns)
@@ -441,7 +487,7 @@ __global__ void __launch_bounds__(256, 3) wgrad2_kernel(Wgrad2Args w) {
   const int ag = 2 * sa + (wid >> 1), bg = 2 * sb + (wid & 1);
   if (beg >= end || ag >= nag || bg >= w.nbg) return;
   const int aw = wg_gwidth(w.ca), bw = wg_gwidth(w.cb);
-  float *out = w.partial + (int64_t)blockIdx.x * w.ca * w.cb;
+  float *out = w.partial + (int64_t)gsid * w.ca * w.cb;
   const int a0 = aw * ag, b0 = bw * bg;
 #define PCS_WG_CASE(A, B) if (aw == A && bw == B) { wgrad_block<A, B, ET>(w, a0, b0, beg, end, out, lane); return; }
   PCS_WG_CASE(64, 64) PCS_WG_CASE(64, 48) PCS_WG_CASE(64, 32) PCS_WG_CASE(64, 16)
@@ -483,6 +529,7 @@ struct Wgrad3Args {
   float *partial;  // [nsplit_total][ca][cb]
   int ca, cb, K, a_col, pch;
   int aw, bw, nag, nbg, nsb;  // group widths, group counts, b super-groups (pairs of groups) per row of super-blocks
+  int interleave;             // launch order of the splits (find_split_wave)
 };
 
 template <typename ET> struct W3Mode;
@@ -522,8 +569,8 @@ __global__ void __launch_bounds__(NT, NT == 256 ? (W3Mode<ET>::PLANES == 1 ? 3 :
   __shared__ __attribute__((aligned(16))) uint16_t lds[NBUF * IMG];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
-  int beg, end;
-  find_split_wave(w.koff, w.K, w.pch, blockIdx.x, lane, &beg, &end);  // the same answer in every wave
+  int beg, end, gsid;
+  find_split_wave(w.koff, w.K, w.pch, blockIdx.x, lane, &beg, &end, &gsid, w.interleave);  // the same answer in every wave
   if (beg >= end) return;  // workgroup-uniform
   const int sa = blockIdx.y / w.nsb, sb = blockIdx.y - sa * w.nsb;  // super-block = 2 x 2 channel groups
   const int a_base = 2 * sa * w.aw, b_base = 2 * sb * w.bw;
@@ -680,7 +727,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? (W3Mode<ET>::PLANES == 1 ? 3 :
   if (!active) return;
   // tile (i, j), register r: row a0 + 16 i + 4 g + r, column b0 + 16 j + l15
   const int a0 = a_base + aoff, b0 = b_base + boff;
-  float *out = w.partial + (int64_t)blockIdx.x * w.ca * w.cb;
+  float *out = w.partial + (int64_t)gsid * w.ca * w.cb;
 #pragma unroll
   for (int i = 0; i < NA; ++i)
 #pragma unroll
@@ -699,7 +746,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? (W3Mode<ET>::PLANES == 1 ? 3 :
 template <typename ET>
 int launch_wgrad3(const Wgrad3Args &w, int ns, hipStream_t st) {
   const int nsa = (w.nag + 1) / 2;
-  const dim3 grid((unsigned)ns, (unsigned)(nsa * w.nsb));
+  const dim3 grid((unsigned)(w.interleave == 2 ? 8 * ((ns + 7) / 8) : ns), (unsigned)(nsa * w.nsb));
   const int na = w.aw / 16, nb = w.bw / 16;
 #define PCS_W3_CASE(A, B) if (na == A && nb == B) { hipLaunchKernelGGL((wgrad3_kernel<ET, A, B>), grid, dim3(256), 0, st, w); return check_launch("pcs_conv_wgrad(wgrad3)"); }
   PCS_W3_CASE(4, 4) PCS_W3_CASE(4, 3) PCS_W3_CASE(4, 2) PCS_W3_CASE(4, 1)
@@ -719,7 +766,7 @@ inline bool wgrad3_thin(int ca, int cb, int dtype) {
 
 template <typename ET>
 int launch_wgrad3_thin(const Wgrad3Args &w, int ns, hipStream_t st) {
-  const dim3 grid((unsigned)ns, 1);
+  const dim3 grid((unsigned)(w.interleave == 2 ? 8 * ((ns + 7) / 8) : ns), 1);
   const int na = w.aw / 16, nb = w.bw / 16;
 #define PCS_W3T_CASE(A, B) if (na == A && nb == B) { hipLaunchKernelGGL((wgrad3_kernel<ET, A, B, 64, 64>), grid, dim3(64), 0, st, w); return check_launch("pcs_conv_wgrad(wgrad3 thin)"); }
   PCS_W3T_CASE(4, 4) PCS_W3T_CASE(4, 3) PCS_W3T_CASE(4, 2) PCS_W3T_CASE(3, 4) PCS_W3T_CASE(3, 3) PCS_W3T_CASE(3, 2)
@@ -762,6 +809,9 @@ extern "C" size_t pcs_conv_wgrad_ws_bytes(const int32_t *koff_host, int32_t K, i
   return (size_t)(ns > 0 ? ns : 1) * ca * cb * sizeof(float);
 }
 
+static int g_wgrad_interleave = -1;   // debug / A-B override of PCS_WGRAD_INTERLEAVE (pcs_debug_wgrad_interleave)
+extern "C" void pcs_debug_wgrad_interleave(int32_t mode) { g_wgrad_interleave = mode; }
+
 // dtype 0: fp32 operands; 1 / 2: bf16 / fp16 operands (the weight gradient is accumulated and returned in fp32)
 static int conv_wgrad_any(const void *fa_v, int32_t ca, const void *fb_v, int32_t cb,
                           const int32_t *pairs, int32_t a_col, const int32_t *koff_dev,
@@ -796,13 +846,18 @@ static int conv_wgrad_any(const void *fa_v, int32_t ca, const void *fb_v, int32_
   // fp32-grade, but the fp32 path of this library stays on fp32 arithmetic unless the caller opts in
   // (pcs_conv_wgrad_f32_bf16x3, or PCS_WGRAD3=2 for every shape). PCS_WGRAD3=0: wgrad2 always (A/B).
   static const int use3 = getenv("PCS_WGRAD3") ? atoi(getenv("PCS_WGRAD3")) : 1;
+  // 1: position-major launch order of the splits (find_split_wave). Measured [r6, profiles/round6_wgrad_interleave_ab.txt]:
+  // 0.94-1.05x on the 16-bit kernel, 0.76-1.05x on the fp32 one, bit-identical results -- the levels' rows already come out of the
+  // Infinity Cache between the offset sweeps; left off
+  static const int interleave_env = getenv("PCS_WGRAD_INTERLEAVE") ? atoi(getenv("PCS_WGRAD_INTERLEAVE")) : 0;
+  const int interleave = g_wgrad_interleave >= 0 ? g_wgrad_interleave : interleave_env;
   const int cgran = dtype == 0 ? 4 : 8;
   const bool want3 = dtype == 0 ? (use3 == 2 || force_split) : (use3 >= 1 && (use3 == 2 || wg_ngroups(ca) * wg_ngroups(cb) >= 4));
   if (thin) {
     Wgrad3Args w3;
     w3.fa = fa_v; w3.fb = fb_v; w3.pairs = pairs; w3.koff = koff_dev; w3.partial = reinterpret_cast<float *>(ws);
     w3.ca = ca; w3.cb = cb; w3.K = K; w3.a_col = a_col; w3.pch = pch;
-    w3.aw = wg_gwidth(ca); w3.bw = wg_gwidth(cb); w3.nag = 1; w3.nbg = 1; w3.nsb = 1;
+    w3.aw = wg_gwidth(ca); w3.bw = wg_gwidth(cb); w3.nag = 1; w3.nbg = 1; w3.nsb = 1; w3.interleave = interleave;
     int rc3 = dtype == 1 ? launch_wgrad3_thin<Bf16>(w3, ns, st) : launch_wgrad3_thin<Fp16>(w3, ns, st);
     if (rc3) return rc3;
   } else if (vec && want3 && ca % cgran == 0 && cb % cgran == 0) {
@@ -810,13 +865,14 @@ static int conv_wgrad_any(const void *fa_v, int32_t ca, const void *fb_v, int32_
     w3.fa = fa_v; w3.fb = fb_v; w3.pairs = pairs; w3.koff = koff_dev; w3.partial = reinterpret_cast<float *>(ws);
     w3.ca = ca; w3.cb = cb; w3.K = K; w3.a_col = a_col; w3.pch = pch;
     w3.aw = wg_gwidth(ca); w3.bw = wg_gwidth(cb); w3.nag = wg_ngroups(ca); w3.nbg = wg_ngroups(cb); w3.nsb = (w3.nbg + 1) / 2;
+    w3.interleave = interleave;
     int rc3 = dtype == 0 ? launch_wgrad3<Fp32>(w3, ns, st) : (dtype == 1 ? launch_wgrad3<Bf16>(w3, ns, st) : launch_wgrad3<Fp16>(w3, ns, st));
     if (rc3) return rc3;
   } else if (vec) {
     Wgrad2Args w2;
     w2.fa = fa; w2.fb = fb; w2.pairs = pairs; w2.koff = koff_dev; w2.partial = reinterpret_cast<float *>(ws);
-    w2.ca = ca; w2.cb = cb; w2.K = K; w2.a_col = a_col; w2.pch = pch; w2.nbg = wg_ngroups(cb);
-    const dim3 grid2((unsigned)ns, (unsigned)(((wg_ngroups(ca) + 1) / 2) * ((wg_ngroups(cb) + 1) / 2)));
+    w2.ca = ca; w2.cb = cb; w2.K = K; w2.a_col = a_col; w2.pch = pch; w2.nbg = wg_ngroups(cb); w2.interleave = interleave;
+    const dim3 grid2((unsigned)(interleave == 2 ? 8 * ((ns + 7) / 8) : ns), (unsigned)(((wg_ngroups(ca) + 1) / 2) * ((wg_ngroups(cb) + 1) / 2)));
     if (dtype == 0) hipLaunchKernelGGL(wgrad2_kernel<Fp32>, grid2, dim3(256), 0, st, w2);
     else if (dtype == 1) hipLaunchKernelGGL(wgrad2_kernel<Bf16>, grid2, dim3(256), 0, st, w2);
     else hipLaunchKernelGGL(wgrad2_kernel<Fp16>, grid2, dim3(256), 0, st, w2);

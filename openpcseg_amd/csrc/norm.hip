@@ -450,6 +450,18 @@ extern "C" int pcs_bn_reduce_partials(const double *partial, int64_t nrows, int3
   return check_launch("pcs_bn_reduce_partials");
 }
 
+// backward: sums2 = [sum g | sum g xhat] (2c doubles, then the same 2c values as floats: the parameter gradients) from the per-tile
+// partials a dgrad launch left in its write-back (pcs_conv_gather_gemm_*_ex with bn_x) -- replaces the pcs_bn_bwd_stats_* pass
+extern "C" int pcs_bn_bwd_reduce_partials(const double *partial, int64_t nrows, int32_t c, double *sums2, int64_t sums2_doubles,
+                                          void *stream) {
+  if (nrows < 0 || nrows > 0x7FFFFFFF || c <= 0 || !partial || !sums2) { set_error("pcs_bn_bwd_reduce_partials: bad args"); return PCS_EINVAL; }
+  if (sums2_doubles < 3 * (int64_t)c) { set_error("pcs_bn_bwd_reduce_partials: sums2 needs 3 c doubles"); return PCS_EWORKSPACE; }
+  hipLaunchKernelGGL(bn_reduce_kernel<double>, dim3((unsigned)ceil_div(c, kRedCh)), dim3(kRedCh, kRedLanes), 0, as_stream(stream), partial,
+                     (int)nrows, c, (const float *)nullptr, (int64_t)0, sums2, 0, reinterpret_cast<float *>(sums2 + 2 * (size_t)c),
+                     (double *)nullptr, 0.0, 0.0, (float *)nullptr, (float *)nullptr);
+  return check_launch("pcs_bn_bwd_reduce_partials");
+}
+
 // the same reduction with pcs_bn_finalize_f32 (count = n) in its tail: stat (2c) from the convolution's partials in ONE launch.
 // sums (2c + 1) may be NULL. Not for SyncBN (the sums of all ranks must be added between the two steps).
 extern "C" int pcs_bn_reduce_partials_finalize(const double *partial, int64_t nrows, int32_t c, int64_t n, double eps,

@@ -56,6 +56,18 @@ __global__ void __launch_bounds__(256) quantize_key_kernel(const int32_t *__rest
   }
 }
 
+// whole batch at once (hostdata.sparse_quantize_frames): frame on top of the BATCH's bounding box -- ascending key = frames in order,
+// inside a frame ascending (x, y, z) = the reference's per-frame ravel hash order. frames: int64 per row.
+__global__ void __launch_bounds__(256) quantize_frame_key_kernel(const int32_t *__restrict__ coords, const int64_t *__restrict__ frames,
+                                                                 int64_t n, const int32_t *__restrict__ bbox, int64_t *__restrict__ keys) {
+  const int64_t x0 = bbox[0], y0 = bbox[1], z0 = bbox[2];
+  const int64_t ex = (int64_t)bbox[3] - x0 + 1, ey = (int64_t)bbox[4] - y0 + 1, ez = (int64_t)bbox[5] - z0 + 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t x = coords[i * 3 + 0] - x0, y = coords[i * 3 + 1] - y0, z = coords[i * 3 + 2] - z0;
+    keys[i] = ((frames[i] * ex + x) * ey + y) * ez + z;
+  }
+}
+
 __global__ void __launch_bounds__(256) quantize_flag_kernel(const int64_t *__restrict__ sorted_keys, int64_t n,
                                                             int32_t *__restrict__ flags) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -135,6 +147,15 @@ extern "C" int pcs_quantize_keys(const int32_t *coords, int64_t n, const int32_t
   if (!coords || !bbox || !keys) { set_error("pcs_quantize_keys: null pointer"); return PCS_EINVAL; }
   hipLaunchKernelGGL(quantize_key_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), coords, n, bbox, keys);
   return check_launch("pcs_quantize_keys");
+}
+
+extern "C" int pcs_quantize_frame_keys(const int32_t *coords, const int64_t *frames, int64_t n, const int32_t *bbox, int64_t *keys,
+                                       void *stream) {
+  if (n < 0) { set_error("pcs_quantize_frame_keys: bad size"); return PCS_EINVAL; }
+  if (n == 0) return PCS_OK;
+  if (!coords || !frames || !bbox || !keys) { set_error("pcs_quantize_frame_keys: null pointer"); return PCS_EINVAL; }
+  hipLaunchKernelGGL(quantize_frame_key_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), coords, frames, n, bbox, keys);
+  return check_launch("pcs_quantize_frame_keys");
 }
 
 extern "C" int pcs_quantize_flags(const int64_t *sorted_keys, int64_t n, int32_t *flags, void *stream) {

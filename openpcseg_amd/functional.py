@@ -319,15 +319,25 @@ class _SparseConv(Function):
     computed in fp32 and their output rounded to the half dtype, like the reference's half pipeline would hand on."""
 
     @staticmethod
-    def forward(ctx, input, weight, entry, transposed, want_stats=False):
+    def forward(ctx, input, weight, entry, transposed, want_stats=False, with_skip=False):
         """want_stats: also return the BatchNorm statistics of the output when the kernel produced them in its write-back
         -- on the HIP backend the per-tile partials ([tiles][2][cout] float64; `_FusedBN` reduces them), on others the
-        reduced vector [sum x | sum x^2 | n] --, else an empty tensor (the BatchNorm then runs its own pass)."""
+        reduced vector [sum x | sum x^2 | n] --, else an empty tensor (the BatchNorm then runs its own pass).
+        with_skip: also return the input itself (an alias) as the LAST output, for the caller's residual / skip path
+        (`relu(net(x) + downsample(x))`, R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:88-129). Both uses of x then hang on
+        this one autograd node, which receives the skip path's gradient together with the convolution's and lets the dgrad
+        kernel add it in its write-back (pcs_conv_gather_gemm_*_add) -- instead of autograd summing two gradient tensors with an
+        elementwise kernel per block."""
         be = _be()
         hd = _amp_dtype(input)
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
         k, cin, cout = w3.shape
         kmap = entry.rev if transposed else entry.fwd
+        # the input is a fused BatchNorm's output: when this convolution is its only consumer, its dgrad write-back leaves that
+        # BatchNorm's backward statistics (fused.BNLink)
+        ctx.bn_link = getattr(input, "_pcs_bn_link", None)
+        if ctx.bn_link is not None:
+            ctx.bn_link.consumers += 1
         got = [] if want_stats else None
         kw = {"bn_sums": got} if want_stats else {}
         if want_stats and getattr(be, "supports_bn_raw", False):
@@ -350,17 +360,23 @@ class _SparseConv(Function):
                 out = out.to(hd)
                 got = [] if want_stats else None  # statistics of the fp32 values, not of the rounded ones: not used
         ctx.for_backwards = (x, weight, entry, transposed, hd)
+        ctx.with_skip = with_skip
+        ctx.in_dtype = input.dtype
         ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the statistics vector on every backward
-        if not want_stats:
-            return out
-        sums = got[0] if got else torch.empty(0, dtype=torch.float64, device=out.device)
-        ctx.mark_non_differentiable(sums)
-        return out, sums
+        outs = [out]
+        if want_stats:
+            sums = got[0] if got else torch.empty(0, dtype=torch.float64, device=out.device)
+            ctx.mark_non_differentiable(sums)
+            outs.append(sums)
+        if with_skip:
+            outs.append(input.view_as(input))
+        return outs[0] if len(outs) == 1 else tuple(outs)
 
     @staticmethod
-    def backward(ctx, grad_output, *_unused):
+    def backward(ctx, grad_output, *rest):
+        grad_skip = rest[-1] if ctx.with_skip and rest else None
         if grad_output is None:
-            return None, None, None, None, None
+            return grad_skip, None, None, None, None, None
         be = _be()
         x, weight, entry, transposed, hd = ctx.for_backwards
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
@@ -372,12 +388,28 @@ class _SparseConv(Function):
         # would need cross-stream ordering)
         if need_dx:
             dmap = entry.fwd if transposed else entry.rev
+            out_dtype = x.dtype if hd is None else hd   # the gradient leaves in the dtype the forward input arrived in
+            rides = (grad_skip is not None and grad_skip.is_cuda and grad_skip.dtype == out_dtype and
+                     hasattr(be, "conv_supports_addend"))   # the skip gradient as the dgrad kernel's write-back addend
+            link, bnb, bnb_out = ctx.bn_link, None, []
+            if (link is not None and link.consumers == 1 and link.x is not None and link.x.dtype == out_dtype and
+                    tuple(link.x.shape) == (dmap.n_dst, cin) and hasattr(be, "conv_emits_stats") and
+                    (grad_skip is None or rides)):
+                bnb = (link.x, link.mask, link.stat)
             if hd is not None and be.conv_h_applies(cout, cin, k):
                 if _WeightPrep.usable(be, weight):
                     wp = _WEIGHT_PREP.get(be, weight, (hd, True))
                 else:
                     wp = be.prepare_weights_h(w3.detach().float().contiguous(), hd, transpose=True)
-                grad_input = be.conv_gather_gemm_h(grad_output.contiguous().to(hd), wp, k, cin, dmap)
+                ok = be.conv_supports_addend(cout, cin, k, 1) if (rides or bnb) else False
+                if bnb is not None and not (ok and be.conv_emits_stats(cout, cin, k, dmap, hd)):
+                    bnb = None
+                kw = {}
+                if rides and ok:
+                    kw["addend"], grad_skip = grad_skip, None
+                if bnb is not None and grad_skip is None:
+                    kw["bn_bwd"], kw["bn_bwd_out"] = bnb, bnb_out
+                grad_input = be.conv_gather_gemm_h(grad_output.contiguous().to(hd), wp, k, cin, dmap, **kw)
             elif hd is None and grad_output.is_cuda and _CONV_POLICY["mode"] == "bf16x3" and be.conv_x3_applies(cout, cin, k):
                 wp = be.prepare_weights_x3(w3.detach().float().contiguous(), transpose=True)
                 grad_input = be.conv_gather_gemm_x3(grad_output.contiguous().float(), wp, k, cin, dmap)
@@ -386,9 +418,22 @@ class _SparseConv(Function):
                     wt = _WEIGHT_PREP.get(be, weight, ("t",))
                 else:
                     wt = be.transpose_weights(w3.detach().float().contiguous())
-                grad_input = be.conv_gather_gemm(grad_output.contiguous().float(), wt, dmap)
-            # the gradient leaves in the dtype the forward input arrived in (what autograd expects)
-            grad_input = grad_input.to(x.dtype if hd is None else hd)
+                ok = (hd is None and out_dtype == torch.float32 and be.conv_supports_addend(cout, cin, k, 0)) if (rides or bnb) else False
+                if bnb is not None and not (ok and be.conv_emits_stats(cout, cin, k, dmap, None)):
+                    bnb = None
+                kw = {}
+                if rides and ok:
+                    kw["addend"], grad_skip = grad_skip, None
+                if bnb is not None and grad_skip is None:
+                    kw["bn_bwd"], kw["bn_bwd_out"] = bnb, bnb_out
+                grad_input = be.conv_gather_gemm(grad_output.contiguous().float(), wt, dmap, **kw)
+            grad_input = grad_input.to(out_dtype)
+            if bnb_out:   # this tensor IS the BatchNorm's dy: its backward recognises it by storage address and version
+                link.partials, link.dy_ptr, link.dy_version = bnb_out[0], grad_input.data_ptr(), grad_input._version
+            if grad_skip is not None:   # a kernel that takes no addend (generic shapes, the split kernels, other backends)
+                grad_input = grad_input + grad_skip.to(out_dtype)
+        elif grad_skip is not None:
+            grad_input = grad_skip
         if need_dw:
             # fwd pairs are (in_row, out_row) of the NON-transposed conv; a transposed conv's
             # input lives on the out rows (column 1)
@@ -399,7 +444,7 @@ class _SparseConv(Function):
                 grad_weight = be.conv_wgrad(x.float(), grad_output.contiguous().float(), entry.fwd, a_col,
                                             split=_wgrad_split(cin, cout))
             grad_weight = grad_weight.view_as(weight).to(weight.dtype)
-        return grad_input, grad_weight, None, None, None
+        return grad_input, grad_weight, None, None, None, None
 
 
 def _identity_map(n, device, cache):
@@ -475,23 +520,33 @@ def _channel_padding(feats, weight):
     return pin, pout
 
 
-def _sparse_conv(feats, weight, entry, transposed, bn_stats):
+def _sparse_conv(feats, weight, entry, transposed, bn_stats, with_skip=False):
+    """-> (out, bn_sums or None[, skip alias of feats when with_skip])."""
     pin, pout = _channel_padding(feats, weight)
     if pin or pout:
         cout = weight.shape[2]
-        feats = torch.nn.functional.pad(feats, (0, pin)) if pin else feats
+        padded = torch.nn.functional.pad(feats, (0, pin)) if pin else feats
         weight = torch.nn.functional.pad(weight, (0, pout, 0, pin))
-        out = _SparseConv.apply(feats, weight, entry, transposed)
-        return (out[:, :cout].contiguous() if pout else out), None   # the epilogue statistics would cover the padded columns: not used
-    if not bn_stats:
+        out = _SparseConv.apply(padded, weight, entry, transposed)
+        res = ((out[:, :cout].contiguous() if pout else out), None)   # the epilogue statistics would cover the padded columns: not used
+        return res + (feats,) if with_skip else res
+    if not bn_stats and not with_skip:
         return _SparseConv.apply(feats, weight, entry, transposed), None
-    out, sums = _SparseConv.apply(feats, weight, entry, transposed, True)
-    return out, (sums if sums.numel() else None)
+    outs = _SparseConv.apply(feats, weight, entry, transposed, bool(bn_stats), bool(with_skip))
+    outs = outs if isinstance(outs, tuple) else (outs,)
+    out = outs[0]
+    sums = outs[1] if bn_stats else None
+    res = (out, (sums if sums is not None and sums.numel() else None))
+    return res + (outs[-1],) if with_skip else res
 
 
-def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transposed=False, bn_stats=False):
+def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transposed=False, bn_stats=False, with_skip=False):
     """bn_stats (not in the reference's signature; used by the fused blocks): ask the convolution for the BatchNorm
-    statistics of its output; they are attached to the returned tensor as `.bn_sums` when the kernel produced them."""
+    statistics of its output; they are attached to the returned tensor as `.bn_sums` when the kernel produced them.
+    with_skip (likewise): return (output, skip) where skip is the INPUT tensor again, routed through the convolution's autograd
+    node: a caller that also feeds the input to a residual / skip path uses `skip` there, and the two gradients of the input
+    are summed inside the dgrad kernel's write-back (see _SparseConv)."""
+    skip_feats = None
     kernel_size = make_ntuple(kernel_size, ndim=3)
     stride = make_ntuple(stride, ndim=3)
     dilation = make_ntuple(dilation, ndim=3)
@@ -517,12 +572,18 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
         if key not in input.kmaps:
             input.kmaps[key] = build_kernel_map(input.coords, output_coords, kernel_size,
                                                 input.stride, dilation)
-        output_feats, bn_sums = _sparse_conv(input.feats, weight, input.kmaps[key], False, bn_stats and bias is None)
+        if with_skip:
+            output_feats, bn_sums, skip_feats = _sparse_conv(input.feats, weight, input.kmaps[key], False, bn_stats and bias is None, True)
+        else:
+            output_feats, bn_sums = _sparse_conv(input.feats, weight, input.kmaps[key], False, bn_stats and bias is None)
     else:
         output_stride = tuple(input.stride[k] // stride[k] for k in range(3))
         output_coords = input.cmaps[output_stride]
         key = (output_stride, kernel_size, stride, dilation)
-        output_feats, bn_sums = _sparse_conv(input.feats, weight, input.kmaps[key], True, bn_stats and bias is None)
+        if with_skip:
+            output_feats, bn_sums, skip_feats = _sparse_conv(input.feats, weight, input.kmaps[key], True, bn_stats and bias is None, True)
+        else:
+            output_feats, bn_sums = _sparse_conv(input.feats, weight, input.kmaps[key], True, bn_stats and bias is None)
 
     if bias is not None:
         output_feats += bias
@@ -537,6 +598,8 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
             output.bn_sums = (bn_sums, output_feats, output_feats._version)
         except RuntimeError:  # inference tensors track no version counter: the BatchNorm runs its own statistics pass
             pass
+    if with_skip:
+        return output, input._like(skip_feats if skip_feats is not None else input.feats)
     return output
 
 

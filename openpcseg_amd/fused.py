@@ -28,6 +28,13 @@ def _syncing(sync):
     return dist.get_world_size() > 1 or os.environ.get("PCS_SYNC_WORLD1") == "1"
 
 
+import os as _os
+# BatchNorm backward statistics from the consumer's dgrad write-back (BNLink) [r6]. Built, parity-green, and SLOWER on the MI355X:
+# bf16 step 52.3 -> 55.2 ms, fp32 115.4 -> 116.8 ms (profiles/round6_bn_link_ab.txt) -- the extra reads (the BatchNorm's input rows,
+# its gate bits) and the per-tile reduction sit in the exposed tail of every dgrad tile, the pass they replace streams at 60-75 % of
+# HBM peak. Off unless PCS_BN_BWD_LINK=1.
+LINK_BN_BWD = _os.environ.get("PCS_BN_BWD_LINK", "0") == "1"
+
 _STATS_GROUP = {}
 
 
@@ -66,13 +73,29 @@ def _stats_group():
     return g or None
 
 
+class BNLink:
+    """Hand-over between a fused BatchNorm and the ONE sparse convolution that consumes its output (conv -> BN -> ReLU -> conv,
+    R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:31-129) [r6]. Forward: the BatchNorm leaves what its backward statistics
+    need (its input x, the ReLU gate bits, mean | invstd) here and hangs the link on its output tensor; a `_SparseConv` that takes
+    that tensor counts itself as a consumer. Backward: when it is the only one, its dgrad launch -- which WRITES the BatchNorm's
+    dy -- also leaves sum(g), sum(g xhat) per tile in its write-back (pcs_conv_gather_gemm_*_ex, bn_x), and the BatchNorm's
+    backward reduces those instead of reading dy and x once more (pcs_bn_bwd_stats_*). The BatchNorm checks that the dy it is
+    handed IS that launch's output, untouched (storage address + in-place version): any other consumer of the activation makes
+    autograd sum gradients into another tensor (or in place), and the statistics pass runs as before."""
+    __slots__ = ("x", "mask", "stat", "consumers", "partials", "dy_ptr", "dy_version")
+
+    def __init__(self):
+        self.x = self.mask = self.stat = self.partials = None
+        self.consumers, self.dy_ptr, self.dy_version = 0, None, None
+
+
 class _FusedBN(Function):
     """Feature tensors may be fp32, bf16 or fp16 (mixed precision: the half convolutions hand on halfs); statistics,
     scale / shift and running stats are fp32 / double whatever the storage format."""
 
     @staticmethod
     def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, sync, cache, level, pre=None,
-                tail=None):
+                tail=None, link=None):
         """tail (n, ct): concat fusion -- the output is cat([bn(x), tail], 1), the BN result written straight into the left
         columns and `tail` copied to the right ones by the apply launch (no torch.cat pass); backward reads its dy out of
         the gradient of that buffer through a row stride and hands the right columns on as tail's gradient."""
@@ -108,6 +131,11 @@ class _FusedBN(Function):
             gate = (y if tail is None else y[:, :c].contiguous()) if relu else None
         ctx.save_for_backward(x, gate, stat, weight, count_dev)
         ctx.cfg = (count, relu, sync, res is not None, tail is not None)
+        ctx.link = None
+        if link is not None and tail is None and n > 0 and c % 4 == 0 and hasattr(be, "bn_bwd_reduce_partials") and (
+                not relu or (gate is not None and gate.dtype != y.dtype)):   # the gate as a bit mask (c % 32 == 0), or no ReLU
+            link.x, link.mask, link.stat = x, (gate if relu else None), stat
+            ctx.link = link
         return y
 
     @staticmethod
@@ -122,7 +150,14 @@ class _FusedBN(Function):
             dy = dy[:, :c]      # read in place through the row stride
         else:
             dy = dy.contiguous()
-        local = be.bn_bwd_stats(dy, x, gate, stat, relu)
+        link, local = ctx.link, None
+        if link is not None:
+            if (link.partials is not None and dy.data_ptr() == link.dy_ptr and dy._version == link.dy_version and
+                    dy.shape == x.shape and dy.dtype == x.dtype):
+                local = be.bn_bwd_reduce_partials(link.partials, c)   # left by the dgrad launch that wrote this dy
+            link.partials = link.x = link.mask = link.stat = None
+        if local is None:
+            local = be.bn_bwd_stats(dy, x, gate, stat, relu)
         sums2 = local
         if _syncing(sync):
             sums2 = local.clone()
@@ -134,7 +169,7 @@ class _FusedBN(Function):
             if lw is None or lw.dtype != weight.dtype:
                 lw = local.to(weight.dtype)         # one cast for both halves
             dw, db = lw[c:], lw[:c]
-        return dx, dres, dw, db, None, None, None, None, None, None, None, None, None, dtail
+        return dx, dres, dw, db, None, None, None, None, None, None, None, None, None, dtail, None
 
 
 class FusedBatchNorm(nn.Module):
@@ -173,8 +208,11 @@ class FusedBatchNorm(nn.Module):
             if pre is not None:
                 sums, of, ver = pre
                 pre = sums if (of is x and x._version == ver) else None
+            link = BNLink() if (LINK_BN_BWD and tail is None and torch.is_grad_enabled()) else None
             y = _FusedBN.apply(x, r, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                               self.momentum, relu, self.sync, input.cmaps, input.stride, pre, tail)
+                               self.momentum, relu, self.sync, input.cmaps, input.stride, pre, tail, link)
+            if link is not None and link.x is not None:
+                y._pcs_bn_link = link   # read by the sparse convolution that consumes y (functional._SparseConv)
         else:
             inv = torch.rsqrt(self.running_var.double() + self.eps)
             stat = torch.cat([self.running_mean.double(), inv]).contiguous()

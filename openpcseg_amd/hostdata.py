@@ -67,10 +67,13 @@ def sparse_quantize_frames(coords, frames, num_frames):
     # ravel_hash (quantize.py:15-21) = ((x - x0) ey + (y - y0)) ez + (z - z0) inside the frame's bounding box: ascending ravel hash IS
     # ascending lexicographic (x, y, z) -- so one key with the frame on top and the BATCH's bounding box below orders every frame
     # like its own ravel hash does, without any per-frame quantity (12-way atomic min / max over 1.4 M rows: 200 ms)
-    lo = coords.amin(0).long()
-    ext = coords.amax(0).long() - lo + 1
-    c = coords.long() - lo
-    key = ((f * ext[0] + c[:, 0]) * ext[1] + c[:, 1]) * ext[2] + c[:, 2]
+    if hasattr(be, "quantize_frame_keys"):
+        key = be.quantize_frame_keys(coords, f)     # one launch (round 5: a dozen torch elementwise launches)
+    else:
+        lo = coords.amin(0).long()
+        ext = coords.amax(0).long() - lo + 1
+        c = coords.long() - lo
+        key = ((f * ext[0] + c[:, 0]) * ext[1] + c[:, 1]) * ext[2] + c[:, 2]
     return be.quantize_sorted_keys(key, coords, f)
 
 

@@ -60,12 +60,15 @@ class Conv3d(nn.Module):
             parts.append("transposed")
         return ", ".join(parts)
 
-    def forward(self, input):
+    def forward(self, input, with_skip=False):
+        """with_skip (not in the reference's signature; used by the fused residual blocks): -> (output, input routed through this
+        convolution's autograd node), see functional.conv3d."""
+        kw = {"with_skip": True} if with_skip else {}
         if self.emit_bn_stats and self.training:
             return F.conv3d(input, self.kernel, kernel_size=self.kernel_size, bias=self.bias, stride=self.stride,
-                            dilation=self.dilation, transposed=self.transposed, bn_stats=True)
+                            dilation=self.dilation, transposed=self.transposed, bn_stats=True, **kw)
         return F.conv3d(input, self.kernel, kernel_size=self.kernel_size, bias=self.bias,
-                        stride=self.stride, dilation=self.dilation, transposed=self.transposed)
+                        stride=self.stride, dilation=self.dilation, transposed=self.transposed, **kw)
 
 
 class BatchNorm(nn.BatchNorm1d):

@@ -49,6 +49,10 @@ SIGNATURES = {
     "pcs_conv_uses_tile_order": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     "pcs_conv_gather_gemm_f32": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32,
                                            _P, c_int32, c_int64, _P, _P, _P, _P, _P]),
+    "pcs_conv_gather_gemm_f32_ex": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32,
+                                              _P, c_int32, c_int64, _P, _P, _P, _P, _P, _P]),
+    "pcs_conv_supports_epilogue": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    "pcs_bn_bwd_reduce_partials": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P]),
     "pcs_bn_reduce_partials": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P]),
     "pcs_bn_reduce_partials_finalize": (c_int32, [_P, c_int64, c_int32, c_int64, c_double, c_double, _P, _P, _P, _P, _P]),
     "pcs_transpose_kab_f32": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P]),
@@ -79,6 +83,7 @@ SIGNATURES = {
                                      c_int64, _P]),
     "pcs_quantize_floor": (c_int32, [_P, c_int32, c_int64, c_int32, _P, _P, _P, _P]),
     "pcs_quantize_keys": (c_int32, [_P, c_int64, _P, _P, _P]),
+    "pcs_quantize_frame_keys": (c_int32, [_P, _P, c_int64, _P, _P, _P]),
     "pcs_quantize_flags": (c_int32, [_P, c_int64, _P, _P]),
     "pcs_quantize_emit": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "pcs_conv_h_applies": (c_int32, [c_int32, c_int32, c_int32]),
@@ -86,6 +91,8 @@ SIGNATURES = {
     "pcs_conv_prepare_weights_h": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "pcs_conv_gather_gemm_h": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32, _P, c_int32, c_int64,
                                          _P, _P, c_int32, _P, _P, _P]),
+    "pcs_conv_gather_gemm_h_ex": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int32, _P, c_int32, c_int64,
+                                            _P, _P, _P, c_int32, _P, _P, _P]),
     "pcs_conv_x3_applies": (c_int32, [c_int32, c_int32, c_int32]),
     "pcs_conv_x3_column_tiles": (c_int32, [c_int32]),
     "pcs_conv_x3_emits_bn_partials": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
@@ -111,7 +118,7 @@ class _WeightJob(ctypes.Structure):   # pcs_weight_job of include/pcseg_hip.h
                 ("transpose", c_int32), ("nctt", c_int32), ("nt16", c_int32), ("ns", c_int32), ("first_block", c_int64)]
 
 
-ABI_VERSION = 8  # include/pcseg_hip.h PCS_ABI_VERSION (8: sums2 size argument of pcs_bn_bwd_stats_*, ring switch removed; 7: pcs_lovasz_*; 6: ring kernel switch / query; 5: fp32 convolution on the bf16 MFMAs, pcs_conv_*_x3; 4: tile order)
+ABI_VERSION = 10  # include/pcseg_hip.h PCS_ABI_VERSION (10: pcs_conv_gather_gemm_*_ex + pcs_conv_epilogue, pcs_bn_bwd_reduce_partials; 9: pcs_quantize_frame_keys; 8: sums2 size argument of pcs_bn_bwd_stats_*, ring switch removed; 7: pcs_lovasz_*; 6: ring kernel switch / query; 5: fp32 convolution on the bf16 MFMAs, pcs_conv_*_x3; 4: tile order)
 _lib = None
 
 
@@ -598,7 +605,59 @@ class HipBackend:
                                                         _ptr(stat), _stream()), "pcs_bn_reduce_partials_finalize")
         return stat
 
-    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True, bn_raw=False):
+    def conv_supports_addend(self, cin, cout, k, dtype=0):
+        """The shape's kernel takes the write-back extras (addend, BatchNorm backward statistics: pcs_conv_epilogue)."""
+        return bool(self.lib.pcs_conv_supports_epilogue(int(cin), int(cout), int(k), int(dtype)))
+
+    def conv_emits_stats(self, cin, cout, k, kmap, half_dtype=None):
+        """The default launch of this shape on this map leaves per-tile statistics in its write-back."""
+        code = self._HALF[half_dtype] if half_dtype is not None else 0
+        if kmap.n_dst == 0 or cout % 4:
+            return False
+        return bool(self.lib.pcs_conv_emits_bn_partials(cin, cout, k, self.tile_rows(cin, cout, kmap, code), code))
+
+    class _Epilogue(ctypes.Structure):   # include/pcseg_hip.h: pcs_conv_epilogue
+        _fields_ = [("addend", ctypes.c_void_p), ("bn_x", ctypes.c_void_p), ("bn_mask", ctypes.c_void_p), ("bn_stat", ctypes.c_void_p)]
+
+    def _epilogue(self, addend, bn_bwd, kmap, cout, dtype, t, cin, k, code, device):
+        """-> (ctypes pointer or None, keep-alive tuple, partial workspace or None) for the _ex entries.
+        bn_bwd = (x, mask or None, stat): the BatchNorm whose output gradient this launch writes."""
+        if addend is None and bn_bwd is None:
+            return None, None, None
+        ep, part = self._Epilogue(None, None, None, None), None
+        if addend is not None:
+            addend = _dev(addend, "addend", dtype)
+            if tuple(addend.shape) != (kmap.n_dst, cout):
+                raise ValueError("addend %s does not match the output (%d, %d)" % (tuple(addend.shape), kmap.n_dst, cout))
+            ep.addend = addend.data_ptr()
+        if bn_bwd is not None:
+            x, mask, stat = bn_bwd
+            x = _dev(x, "bn_x", dtype)
+            if tuple(x.shape) != (kmap.n_dst, cout):
+                raise ValueError("bn_x %s does not match the output (%d, %d)" % (tuple(x.shape), kmap.n_dst, cout))
+            if not self.lib.pcs_conv_emits_bn_partials(cin, cout, k, t, code):
+                raise RuntimeError("openpcseg_amd: this shape / tile height leaves no statistics in its write-back")
+            stat = _dev(stat, "bn_stat", torch.float64)
+            ntiles = (kmap.n_dst + t - 1) // t
+            part = torch.empty(ntiles * 2 * cout, dtype=torch.float64, device=device)
+            ep.bn_x, ep.bn_stat = x.data_ptr(), stat.data_ptr()
+            if mask is not None:
+                ep.bn_mask = _dev(mask, "bn_mask").data_ptr()
+            bn_bwd = (x, mask, stat)
+        return ctypes.byref(ep), (ep, addend, bn_bwd), part
+
+    def bn_bwd_reduce_partials(self, partial, c):
+        """per-tile [2][c] double partials of a dgrad write-back -> the sums2 vector bn_bwd_stats returns (with its fp32 copy)."""
+        partial = _dev(partial, "partial", torch.float64)
+        buf = torch.empty(3 * c, dtype=torch.float64, device=partial.device)
+        sums2 = buf[:2 * c]
+        sums2._pcs_f32 = buf[2 * c:].view(torch.float32)
+        _check(self.lib.pcs_bn_bwd_reduce_partials(_ptr(partial), partial.numel() // (2 * c), c, _ptr(buf), buf.numel(), _stream()),
+               "pcs_bn_bwd_reduce_partials")
+        return sums2
+
+    def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True, bn_raw=False, addend=None,
+                         bn_bwd=None, bn_bwd_out=None):
         """dst[d] = sum_{(s,d) in offset k} src[s] @ weight[k] (+bias); kmap dst-sorted. bn_sums: a list; when the
         kernel can, the [sum x | sum x^2 | n] vector of dst (what bn_stats(dst) returns) is appended to it, computed in
         the convolution's write-back instead of by a pass over dst. ordered: True = heaviest-first tile order where it
@@ -617,12 +676,16 @@ class HipBackend:
         dst = torch.empty((kmap.n_dst, cout), dtype=torch.float32, device=src.device)
         part = self._bn_partial(kmap, t, cin, cout, k, 0, bn_sums, src.device)
         order = self._tile_order(kmap, t) if (ordered == "force" or (ordered and self._wants_order(kmap))) and kmap.n_dst > 0 and self.lib.pcs_conv_uses_tile_order(cin, cout, k, 0) else None
-        _check(self.lib.pcs_conv_gather_gemm_f32(_ptr(src), src.shape[0], cin, _ptr(weight), k, cout,
-                                                 _ptr(kmap._pairs_raw), 0, _ptr(seg), t, kmap.n_dst,
-                                                 _ptr(bias) if bias is not None else None, _ptr(dst),
-                                                 _ptr(part) if part is not None else None,
-                                                 _ptr(order) if order is not None else None,
-                                                 _stream()), "pcs_conv_gather_gemm_f32")
+        # write-back extras: addend (dgrad + skip gradient), bn_bwd (the backward statistics of the BatchNorm this gradient enters)
+        ep, keep, gpart = self._epilogue(addend, bn_bwd, kmap, cout, torch.float32, t, cin, k, 0, src.device)
+        _check(self.lib.pcs_conv_gather_gemm_f32_ex(_ptr(src), src.shape[0], cin, _ptr(weight), k, cout,
+                                                    _ptr(kmap._pairs_raw), 0, _ptr(seg), t, kmap.n_dst,
+                                                    _ptr(bias) if bias is not None else None, ep, _ptr(dst),
+                                                    _ptr(gpart) if gpart is not None else (_ptr(part) if part is not None else None),
+                                                    _ptr(order) if order is not None else None,
+                                                    _stream()), "pcs_conv_gather_gemm_f32")
+        if gpart is not None and bn_bwd_out is not None:
+            bn_bwd_out.append(gpart)
         if part is not None:
             self._bn_reduce(part, t, kmap, cout, bn_sums, bn_raw)
         return dst
@@ -648,7 +711,8 @@ class HipBackend:
         wp._pcs_prepared = ("half", dtype, k, con, cols)  # what the opaque buffer holds: checked by the conv call
         return wp
 
-    def conv_gather_gemm_h(self, src, wp, k, cout, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True, bn_raw=False):
+    def conv_gather_gemm_h(self, src, wp, k, cout, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True, bn_raw=False,
+                           addend=None, bn_bwd=None, bn_bwd_out=None):
         """Half-precision fused conv: src (n, cin) bf16 / fp16, wp = prepare_weights_h(...) of the same dtype."""
         if src.dtype not in self._HALF:
             raise TypeError("openpcseg_amd: conv_gather_gemm_h wants bfloat16 / float16 features, got %s" % src.dtype)
@@ -666,11 +730,15 @@ class HipBackend:
         dst = torch.empty((kmap.n_dst, cout), dtype=src.dtype, device=src.device)
         part = self._bn_partial(kmap, t, cin, cout, k, self._HALF[src.dtype], bn_sums, src.device)
         order = self._tile_order(kmap, t) if (ordered == "force" or (ordered and self._wants_order(kmap))) and kmap.n_dst > 0 else None
-        _check(self.lib.pcs_conv_gather_gemm_h(_ptr(src), src.shape[0], cin, _ptr(wp), k, cout, _ptr(kmap._pairs_raw), 0,
-                                               _ptr(seg), t, kmap.n_dst, _ptr(bias) if bias is not None else None,
-                                               _ptr(dst), self._HALF[src.dtype], _ptr(part) if part is not None else None,
-                                               _ptr(order) if order is not None else None,
-                                               _stream()), "pcs_conv_gather_gemm_h")
+        ep, keep, gpart = self._epilogue(addend, bn_bwd, kmap, cout, src.dtype, t, cin, k, self._HALF[src.dtype], src.device)
+        _check(self.lib.pcs_conv_gather_gemm_h_ex(_ptr(src), src.shape[0], cin, _ptr(wp), k, cout, _ptr(kmap._pairs_raw), 0,
+                                                  _ptr(seg), t, kmap.n_dst, _ptr(bias) if bias is not None else None, ep,
+                                                  _ptr(dst), self._HALF[src.dtype],
+                                                  _ptr(gpart) if gpart is not None else (_ptr(part) if part is not None else None),
+                                                  _ptr(order) if order is not None else None,
+                                                  _stream()), "pcs_conv_gather_gemm_h")
+        if gpart is not None and bn_bwd_out is not None:
+            bn_bwd_out.append(gpart)
         if part is not None:
             self._bn_reduce(part, t, kmap, cout, bn_sums, bn_raw)
         return dst
@@ -1079,6 +1147,18 @@ class HipBackend:
                                           _ptr(inverse) if want_inverse else None, _stream()), "pcs_quantize_emit")
         return vox, index, inverse
 
+
+    def quantize_frame_keys(self, coords, frames):
+        """int64 sort keys of a collated batch: frame on top of the batch's bounding box (one launch + two reductions)."""
+        coords = _dev(coords, "coords", torch.int32)
+        frames = _dev(frames, "frames", torch.int64)
+        n = coords.shape[0]
+        keys = torch.empty(n, dtype=torch.int64, device=coords.device)
+        if n == 0:
+            return keys
+        bbox = torch.cat([coords.amin(0), coords.amax(0)]).contiguous()
+        _check(self.lib.pcs_quantize_frame_keys(_ptr(coords), _ptr(frames), n, _ptr(bbox), _ptr(keys), _stream()), "pcs_quantize_frame_keys")
+        return keys
 
     def quantize_sorted_keys(self, keys, coords, frames):
         """Voxel dedup of a whole batch from ready-made keys (hostdata.sparse_quantize_frames): one stable sort, flags, scan,

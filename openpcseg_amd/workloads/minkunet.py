@@ -49,6 +49,7 @@ def _link(conv, bn):
 
 
 CAT_FUSED = os.environ.get("PCS_CAT_FUSED", "1") != "0"  # decoder concat written by the BN apply pass
+SKIP_FUSED = os.environ.get("PCS_SKIP_FUSED", "1") != "0"  # residual-block skip gradient added in the dgrad write-back [r6]
 
 
 def _bn_act(bn, x, residual=None, relu=True, act=None, cat_with=None):
@@ -91,11 +92,17 @@ class ResBlock(nn.Module):
         _link(self.net[3], self.net[4])
 
     def forward(self, x):
-        h = _bn_act(self.net[1], self.net[0](x), act=self.net[2])
-        if isinstance(self.downsample, nn.Identity):
-            r = x
+        if SKIP_FUSED and torch.is_grad_enabled() and x.feats.requires_grad:
+            # x feeds the first convolution AND the skip path: both through the convolution's autograd node, whose dgrad kernel
+            # adds the skip gradient in its write-back (no elementwise sum of two gradient tensors per block)
+            h0, xs = self.net[0](x, with_skip=True)
         else:
-            r = _bn_act(self.downsample[1], self.downsample[0](x), relu=False)
+            h0, xs = self.net[0](x), x
+        h = _bn_act(self.net[1], h0, act=self.net[2])
+        if isinstance(self.downsample, nn.Identity):
+            r = xs
+        else:
+            r = _bn_act(self.downsample[1], self.downsample[0](xs), relu=False)
         return _bn_act(self.net[4], self.net[3](h), residual=r, act=self.relu)
 
 

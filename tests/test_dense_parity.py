@@ -353,6 +353,193 @@ def test_half_conv_forward_dense_map(hip, levels, dtype, stride, cin, cout, tile
     close_half(yb, ref + bias[None, :], dtype)
 
 
+@pytest.mark.parametrize("stride,cin,cout,tile", [(4, 128, 128, None), (1, 96, 96, None), (2, 32, 32, None), (8, 256, 256, None),
+                                                  (4, 64, 48, 64), (2, 36, 44, None)])
+def test_conv_write_back_addend(hip, levels, stride, cin, cout, tile):
+    """pcs_conv_gather_gemm_f32_add / _h_add: dst = conv + bias + addend, the addend (a skip path's gradient in dgrad) added in the
+    write-back. fp32: bit-identical to the plain launch plus one fp32 addition; halfs: added in fp32 before the ONE rounding."""
+    entry, nbmaps, nbsizes, n = level_map(levels, stride)
+    g = torch.Generator(device=DEV).manual_seed(stride * 1000 + cin + cout)
+    x = torch.randn(n, cin, device=DEV, generator=g)
+    w = torch.randn(27, cin, cout, device=DEV, generator=g) / np.sqrt(cin * 27)
+    add = torch.randn(n, cout, device=DEV, generator=g)
+    bias = torch.randn(cout, device=DEV, generator=g)
+    assert hip.conv_supports_addend(cin, cout, 27, 0)
+    y = hip.conv_gather_gemm(x, w, entry.fwd, tile_rows=tile)
+    ya = hip.conv_gather_gemm(x, w, entry.fwd, tile_rows=tile, addend=add)
+    assert torch.equal(ya, y + add)
+    yb = hip.conv_gather_gemm(x, w, entry.fwd, tile_rows=tile, addend=add, bias=bias)
+    assert torch.allclose(yb, y + bias + add, rtol=0, atol=2e-6 * float(y.abs().max()))
+    if hip.conv_h_applies(cin, cout, 27):
+        for dtype in (torch.bfloat16, torch.float16):
+            assert hip.conv_supports_addend(cin, cout, 27, hip._HALF[dtype])
+            wp = hip.prepare_weights_h(w, dtype, transpose=False)
+            xh, ah = x.to(dtype), add.to(dtype)
+            for mode in (0, 3):   # conv_os5h and the weight-stationary kernel's own epilogue
+                try:
+                    _ws_mode(hip, mode)
+                    yh = hip.conv_gather_gemm_h(xh, wp, 27, cout, entry.fwd, tile_rows=tile, addend=ah)
+                finally:
+                    _ws_mode(hip, -1)
+                ref = orc.conv_fwd(xh.float().cpu().numpy(), _round_half(w.cpu().numpy(), dtype), nbmaps, nbsizes, (n, n)) + ah.float().cpu().numpy()
+                close_half(yh, ref, dtype)
+    with pytest.raises(ValueError):
+        hip.conv_gather_gemm(x, w, entry.fwd, addend=add[:-1])
+
+
+def test_skip_gradient_rides_in_the_dgrad_write_back(hip, levels):
+    """conv3d(..., with_skip=True): the input comes back routed through the convolution's autograd node; the gradient of
+    f(conv(x)) + g(x) w.r.t. x equals autograd's sum of the two paths (fp32: to one addition's rounding; bf16 autocast: to the
+    half rounding), and the convolution's own gradients are unchanged."""
+    from openpcseg_amd import functional as F
+    from openpcseg_amd.sparse import SparseTensor
+    coords = t(levels[2])
+    g = torch.Generator(device=DEV).manual_seed(5)
+    w = (torch.randn(27, 64, 64, device=DEV, generator=g) / np.sqrt(64 * 27)).requires_grad_(True)
+    x0 = torch.randn(coords.shape[0], 64, device=DEV, generator=g)
+    gy = torch.randn(coords.shape[0], 64, device=DEV, generator=g)
+    for amp in (None, torch.bfloat16):
+        res = []
+        for fused in (False, True):
+            x = x0.clone().requires_grad_(True)
+            w.grad = None
+            with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+                st = SparseTensor(x if amp is None else x.to(amp), coords, 2)
+                if fused:
+                    out, skip = F.conv3d(st, w, 3, with_skip=True)
+                else:
+                    out, skip = F.conv3d(st, w, 3), st
+                y = torch.relu(out.feats.float()) * 2.0 + torch.tanh(skip.feats.float())
+            y.backward(gy)
+            res.append((x.grad.clone(), w.grad.clone()))
+        (gx0, gw0), (gx1, gw1) = res
+        tol = 1e-6 if amp is None else 2.0 ** -7
+        assert float((gx1 - gx0).abs().max()) <= tol * float(gx0.abs().max())
+        assert float((gw1 - gw0).abs().max()) <= 1e-6 * float(gw0.abs().max())
+
+
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_batchnorm_backward_statistics_from_the_dgrad_write_back(hip, levels, amp, monkeypatch):
+    """conv -> BatchNorm -> ReLU -> conv (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:31-129): the second convolution's dgrad
+    launch writes the BatchNorm's dy and leaves sum(g), sum(g xhat) per tile (pcs_conv_gather_gemm_*_ex, bn_x); the BatchNorm's
+    backward reduces those instead of running pcs_bn_bwd_stats_*. Same gradients as the statistics pass; a second consumer of
+    the activation (autograd then sums gradients) falls back to the pass."""
+    from openpcseg_amd import fused, modules as spnn, native
+    from openpcseg_amd.sparse import SparseTensor
+    coords = t(levels[4])
+    n = coords.shape[0]
+    torch.manual_seed(3)
+    c1, c2 = spnn.Conv3d(64, 96, 3).to(DEV), spnn.Conv3d(96, 64, 3).to(DEV)
+    bn = fused.FusedBatchNorm(96).to(DEV).train()
+    x0 = torch.randn(n, 64, device=DEV)
+    gy = torch.randn(n, 64, device=DEV)
+    calls = {"link": 0, "pass": 0}
+    be = native.backend()
+    real_link, real_pass = be.bn_bwd_reduce_partials, be.bn_bwd_stats
+    monkeypatch.setattr(be, "bn_bwd_reduce_partials", lambda *a, **k: (calls.__setitem__("link", calls["link"] + 1), real_link(*a, **k))[1])
+    monkeypatch.setattr(be, "bn_bwd_stats", lambda *a, **k: (calls.__setitem__("pass", calls["pass"] + 1), real_pass(*a, **k))[1])
+
+    def run(link, second_consumer=False):
+        monkeypatch.setattr(fused, "LINK_BN_BWD", link)
+        for m in (c1, c2, bn):
+            m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            h = bn(c1(SparseTensor(x, coords, 4)), relu=True)
+            out = c2(h).feats.float()
+            if second_consumer:
+                out = out + h.feats.float()[:, :64] * 0.5
+        out.backward(gy)
+        return [x.grad.clone()] + [p.grad.clone() for m in (c1, bn, c2) for p in m.parameters()]
+
+    base = run(False)
+    assert calls == {"link": 0, "pass": 1}
+    got = run(True)
+    assert calls == {"link": 1, "pass": 1}                      # the statistics came out of the dgrad write-back
+    tol = 2e-5 if amp is None else 2e-3
+    for a, b in zip(got, base):
+        assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-6)
+    both = run(True, second_consumer=True)
+    assert calls == {"link": 1, "pass": 2}                      # two consumers of the activation: the pass runs
+    ref = run(False, second_consumer=True)
+    for a, b in zip(both, ref):
+        assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-6)
+
+
+def _ws_mode(hip, mode):
+    import ctypes
+    f = hip.lib.pcs_debug_convh_ws
+    f.restype, f.argtypes = None, [ctypes.c_int32] * 3
+    f(mode, 0, 0)
+
+
+# every instance of the weight-stationary kernel (csrc/conv_wave6h.hip): (16-column tiles, 32-channel steps) incl. the thin ones its
+# shape policy leaves to conv_os5h, the chunked contractions (192 ... 384 input channels, 4-wave tiles of <= 160 rows), two column
+# tiles (cout 192 / 256), partial column tiles (cout 20 / 80), forced tile heights, 8-wave workgroups (tall tiles)
+WS_CASES = [(1, 96, 96, None), (1, 96, 96, 384), (1, 128, 96, None), (1, 96, 128, 144), (4, 128, 128, None), (4, 128, 128, 288),
+            (2, 64, 64, None), (8, 64, 128, 112), (4, 128, 64, None), (2, 64, 96, None), (2, 64, 32, None), (2, 32, 32, None),
+            (4, 32, 64, None), (2, 32, 96, None), (4, 32, 128, 112), (8, 128, 256, 112), (4, 128, 192, 144), (8, 256, 256, 144),
+            (8, 384, 256, 144), (4, 192, 128, 144), (8, 256, 128, 112), (4, 192, 96, 144), (8, 256, 96, 128),
+            (4, 128, 80, None)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("stride,cin,cout,tile", WS_CASES)
+def test_weight_stationary_half_conv_dense_map(hip, levels, dtype, stride, cin, cout, tile):
+    """conv_os6h_kernel (forced on for every shape it has an instance for) vs the oracle on the same half-rounded operands, the
+    bound of the conv_os5h test; bit-reproducible; and against conv_os5h itself (same products, another fp32 addition order: they
+    differ by output roundings only). Forward and dgrad (the input-sorted map with transposed weights)."""
+    entry, nbmaps, nbsizes, n = level_map(levels, stride)
+    rng = np.random.default_rng(stride * 100000 + cin * 100 + cout + 11)
+    x = _round_half(rng.normal(size=(n, cin)).astype(np.float32), dtype)
+    w = _round_half((rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32), dtype)
+    bias = rng.normal(size=cout).astype(np.float32)
+    wp = hip.prepare_weights_h(t(w), dtype, transpose=False)
+    dx = t(x).to(dtype)
+    ref = orc.conv_fwd(x, w, nbmaps, nbsizes, (n, n))
+    try:
+        _ws_mode(hip, 0)
+        y5 = hip.conv_gather_gemm_h(dx, wp, 27, cout, entry.fwd, tile_rows=tile)
+        _ws_mode(hip, 3)
+        y = hip.conv_gather_gemm_h(dx, wp, 27, cout, entry.fwd, tile_rows=tile)
+        close_half(y, ref, dtype)
+        assert torch.equal(y, hip.conv_gather_gemm_h(dx, wp, 27, cout, entry.fwd, tile_rows=tile))
+        assert not torch.equal(y, y5) or cin <= 32            # it really ran another kernel (one-step layers may agree bit for bit)
+        # two roundings of two fp32 sums that differ in their last bits: at most one unit of the storage format apart
+        d, a5 = (y.float() - y5.float()).abs(), y5.float().abs()
+        assert bool((d <= 2.0 * _HALF_TOL[dtype] * a5 + 8e-5 * float(a5.max())).all())
+        close_half(hip.conv_gather_gemm_h(dx, wp, 27, cout, entry.fwd, bias=t(bias), tile_rows=tile), ref + bias[None, :], dtype)
+        if cout % 8 == 0 and cout >= 32:                       # dgrad of the mirrored layer: cout -> cin over the input-sorted map
+            gy = _round_half(rng.normal(size=(n, cout)).astype(np.float32), dtype)
+            ogx, _ = orc.conv_bwd(x, gy, w, nbmaps, nbsizes)
+            wpt = hip.prepare_weights_h(t(w), dtype, transpose=True)
+            close_half(hip.conv_gather_gemm_h(t(gy).to(dtype), wpt, 27, cin, entry.rev, tile_rows=tile), ogx, dtype)
+    finally:
+        _ws_mode(hip, -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_weight_stationary_half_conv_bn_statistics(hip, levels, dtype):
+    """The 16-byte-store epilogue of conv_os6h_kernel leaves the statistics of the ROUNDED values it stored (8 columns per thread,
+    pivot-shifted sums un-shifted in double); outputs identical with and without them."""
+    for stride, cin, cout in ((4, 128, 96), (4, 128, 128), (2, 64, 64)):
+        entry, nbmaps, nbsizes, n = level_map(levels, stride)
+        g = torch.Generator(device=DEV).manual_seed(3)
+        x = (torch.randn(n, cin, device=DEV, generator=g) + 0.5).to(dtype)
+        w = torch.randn(27, cin, cout, device=DEV, generator=g) / np.sqrt(cin * 27)
+        wp = hip.prepare_weights_h(w, dtype, transpose=False)
+        try:
+            _ws_mode(hip, 3)
+            got = []
+            y = hip.conv_gather_gemm_h(x, wp, 27, cout, entry.fwd, bn_sums=got)
+            assert torch.equal(y, hip.conv_gather_gemm_h(x, wp, 27, cout, entry.fwd)) and len(got) == 1
+        finally:
+            _ws_mode(hip, -1)
+        yd = y.double()
+        assert torch.allclose(got[0][:cout], yd.sum(0), rtol=0, atol=1e-6 * float(yd.abs().sum(0).max()))
+        assert torch.allclose(got[0][cout:2 * cout], (yd * yd).sum(0), rtol=1e-6)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("stride,cin,cout", [(4, 128, 128), (8, 384, 256), (1, 128, 96), (2, 112, 56), (4, 336, 224),
                                              (8, 672, 448),

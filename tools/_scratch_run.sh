@@ -1,4 +1,7 @@
 mkdir -p gpurun_out
-timeout 900 python bench.py --amp bf16 --device-input --no-cpu-baseline --models none > gpurun_out/r6_bench_bf16_di.log 2> gpurun_out/r6_bench_bf16_di.err; tail -1 gpurun_out/r6_bench_bf16_di.log | cut -c1-1500
-PCS_CONVH_WS=0 timeout 900 python bench.py --amp bf16 --no-cpu-baseline --models none --no-device-input-line > gpurun_out/r6_bench_bf16_ws0.log 2>&1; tail -1 gpurun_out/r6_bench_bf16_ws0.log | cut -c1-600
-PCS_PROFILE_STEADY=1 bash tools/profile_bench.sh round6_amp_bf16 --amp bf16 | tail -30
+timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | grep -v Warning | grep -E "^E  |Error|passed|failed|^FAILED" | head -40 > gpurun_out/r6_gputest2.txt
+cat gpurun_out/r6_gputest2.txt
+for lk in 1 0; do
+PCS_BN_BWD_LINK=$lk timeout 900 python bench.py --amp bf16 --no-cpu-baseline --models none --no-device-input-line > gpurun_out/r6_bench_bf16_link$lk.log 2>&1; tail -1 gpurun_out/r6_bench_bf16_link$lk.log | cut -c1-200
+PCS_BN_BWD_LINK=$lk timeout 900 python bench.py --no-amp-line --no-split-line --no-cpu-baseline --models none --no-device-input-line > gpurun_out/r6_bench_f32_link$lk.log 2>&1; tail -1 gpurun_out/r6_bench_f32_link$lk.log | cut -c1-200
+done
