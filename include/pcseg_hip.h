@@ -399,6 +399,12 @@ int pcs_bn_bwd_stats_h(const void *dy, const void *x, const void *y, const uint3
 int pcs_bn_bwd_apply_h(const void *dy, const void *x, const void *y, const uint32_t *mask, const double *stat,
                        const double *sums2, double count, const double *count_dev, const float *w, int64_t n,
                        int32_t c, int32_t relu, int32_t dtype, void *dx, void *dres, int64_t lddy, void *stream);
+/* pcs_bn_bwd_apply_{f32,h} (dtype 0 / 1 / 2) for a BatchNorm whose INPUT is a LeakyReLU output (conv -> LeakyReLU -> BatchNorm1d,
+ * R:pcseg/model/segmentor/voxel/cylinder3d/cylinder_ts.py:88-190): dx leaves multiplied by (x > 0 ? 1 : in_slope), i.e. as the
+ * gradient of the activation's input -- torch's leaky_relu_backward pass disappears. */
+int pcs_bn_bwd_apply_act(const void *dy, const void *x, const void *y, const uint32_t *mask, const double *stat,
+                         const double *sums2, double count, const double *count_dev, const float *w, int64_t n, int32_t c,
+                         int32_t relu, int32_t dtype, float in_slope, void *dx, void *dres, int64_t lddy, void *stream);
 
 /* ---- device-side sparse_quantize ---------------------------------------------------------------
  * Replaces the dataloader-side NumPy voxel dedup TS:torchsparse/utils/quantize.py:9-46

@@ -111,7 +111,7 @@ def _backend_fuses(feats):
     return hasattr(be, "bn_apply") and feats.dim() == 2 and feats.dtype in (torch.float32, torch.bfloat16, torch.float16)
 
 
-def bn_forward(bn, input, residual=None, relu=False, cat_with=None):
+def bn_forward(bn, input, residual=None, relu=False, cat_with=None, in_slope=None):
     """`relu(bn(input) + residual)` [concatenated with cat_with] as one fused pass, on the parameters / buffers of the
     caller's own BatchNorm module (nn.BatchNorm1d semantics in train and eval mode; nn.SyncBatchNorm: the statistics are
     all-reduced over the default process group)."""
@@ -135,7 +135,7 @@ def bn_forward(bn, input, residual=None, relu=False, cat_with=None):
         from . import fused as _fz
         link = _fz.BNLink() if (_fz.LINK_BN_BWD and tail is None and torch.is_grad_enabled()) else None
         y = _FusedBN.apply(x, r, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu,
-                           isinstance(bn, nn.SyncBatchNorm), input.cmaps, input.stride, pre, tail, link)
+                           isinstance(bn, nn.SyncBatchNorm), input.cmaps, input.stride, pre, tail, link, in_slope)
         if link is not None and link.x is not None:
             y._pcs_bn_link = link   # the one sparse convolution that consumes y leaves this BatchNorm's backward statistics (fused.BNLink)
     else:
@@ -705,6 +705,88 @@ def _warn_unrecognised(what, why):
                   "lower speed (INTEGRATION.md section 4)." % (what, why), RuntimeWarning, stacklevel=3)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Cylinder_TS blocks (R:pcseg/model/segmentor/voxel/cylinder3d/cylinder_ts.py:88-330): chains of
+#     t = conv(x); t.F = LeakyReLU(t.F); t.F = BatchNorm1d(t.F)
+# recognised by the SHA-1 of each block's forward [r6]. Per link of the chain the reference runs conv, leaky_relu (read + write),
+# batch_norm (statistics read, apply read + write) and, backward, batch_norm_backward (2 + 3 passes) and leaky_relu_backward
+# (2 reads + 1 write); fused: the convolution's write-back applies the LeakyReLU and leaves the BatchNorm statistics, ONE apply
+# pass, and the backward apply pass multiplies the activation's derivative in. The blocks' residual sums ride in the last apply
+# pass; the two convolutions that read the block input share one autograd node for its gradient (_skip_through).
+_CYL_FORWARD_SHA1 = {"ResContextBlock": "ca01095d526ca22e88e3934d5d3c584bcc797798",
+                     "ResBlock": "5e33c3d957290051e87718bb5cb51fbcdb9328c9",
+                     "UpBlock": "9ec2fd9d3f0af222467bede0edc24312e70c82f6"}
+
+
+def _cab(conv, act, bn, x, residual=None, want_skip=False):
+    """conv -> LeakyReLU -> BatchNorm (+ residual) on a SparseTensor; -> (result, x routed through conv when want_skip)."""
+    from . import functional as Fn
+    ok = (type(conv) is spnn.Conv3d and type(act) is nn.LeakyReLU and _bn_like(bn) and _quiet(conv) and _quiet(act) and _quiet(bn) and
+          isinstance(x, SparseTensor) and _backend_fuses(x.feats) and conv.bias is None and conv.kernel.dim() == 3 and
+          Fn.conv_act_fusable(x.feats, conv.kernel) and os.environ.get("PCS_CYL_FUSED", "1") != "0")
+    if not ok:
+        h = conv(x)
+        h.F = act(h.F)
+        h.F = bn(h.F)
+        if residual is not None:
+            h.F = h.F + residual.F
+        return (h, x) if want_skip else h
+    skip = want_skip and torch.is_grad_enabled() and x.feats.requires_grad and os.environ.get("PCS_SKIP_FUSED", "1") != "0"
+    out = Fn.conv3d(x, conv.kernel, kernel_size=conv.kernel_size, stride=conv.stride, dilation=conv.dilation,
+                    transposed=conv.transposed, bn_stats=bn.training, with_skip=skip, act_slope=act.negative_slope)
+    h, xs = out if skip else (out, x)
+    y = bn_forward(bn, h, residual=residual, relu=False, in_slope=act.negative_slope)
+    return (y, xs) if want_skip else y
+
+
+def _cyl_context_forward(self, x):        # ResContextBlock.forward, cylinder_ts.py:137-155
+    if not isinstance(x, SparseTensor):
+        return self.__dict__["_pcs_orig_class"].forward(self, x)
+    shortcut, xs = _cab(self.conv1, self.act1, self.bn0, x, want_skip=True)
+    shortcut = _cab(self.conv1_2, self.act1_2, self.bn0_2, shortcut)
+    res_a = _cab(self.conv2, self.act2, self.bn1, xs)
+    return _cab(self.conv3, self.act3, self.bn2, res_a, residual=shortcut)
+
+
+def _cyl_resblock_forward(self, x):       # ResBlock.forward, cylinder_ts.py:229-252
+    if not isinstance(x, SparseTensor):
+        return self.__dict__["_pcs_orig_class"].forward(self, x)
+    res_a = _cyl_context_forward(self, x)
+    if self.pooling:
+        return self.pool(res_a), res_a
+    return res_a
+
+
+def _cyl_upblock_forward(self, x, skip):  # UpBlock.forward, cylinder_ts.py:312-330
+    if not isinstance(x, SparseTensor):
+        return self.__dict__["_pcs_orig_class"].forward(self, x, skip)
+    up_a = _cab(self.trans_dilao, self.trans_act, self.trans_bn, x)
+    up_a = self.up_subm(up_a)
+    up_a.F = up_a.F + skip.F
+    up_e = _cab(self.conv1, self.act1, self.bn1, up_a)
+    up_e = _cab(self.conv2, self.act2, self.bn2, up_e)
+    return _cab(self.conv3, self.act3, self.bn3, up_e)
+
+
+_CYL_FORWARDS = {"ResContextBlock": (_cyl_context_forward, ("conv1", "act1", "bn0", "conv1_2", "act1_2", "bn0_2", "conv2", "act2", "bn1", "conv3", "act3", "bn2")),
+                 "ResBlock": (_cyl_resblock_forward, ("conv1", "act1", "bn0", "conv1_2", "act1_2", "bn0_2", "conv2", "act2", "bn1", "conv3", "act3", "bn2", "pooling")),
+                 "UpBlock": (_cyl_upblock_forward, ("trans_dilao", "trans_act", "trans_bn", "up_subm", "conv1", "act1", "bn1", "conv2", "act2", "bn2", "conv3", "act3", "bn3"))}
+
+
+def _fuse_cylinder_block(m, undo):
+    name = type(m).__name__
+    if name not in _CYL_FORWARDS or getattr(type(m), "_pcs_fused_class", False):
+        return 0
+    fwd, attrs = _CYL_FORWARDS[name]
+    if not all(hasattr(m, a) for a in attrs) or not all(type(getattr(m, a)) is spnn.Conv3d for a in attrs if a.startswith(("conv", "trans_dilao"))):
+        return 0   # another model's block of the same name (the range branch's ResBlock is dense convolutions)
+    if _source_sha1(type(m).forward) != _CYL_FORWARD_SHA1[name]:
+        _warn_unrecognised("%s.forward" % name, "its source text differs from the reference's (recognition is by SHA-1 of the text)")
+        return 0
+    _reclass(m, fwd, None, undo)
+    return 1
+
+
 def _fuse_model_forward(m, undo):
     name = type(m).__name__
     if name in ("SPVCNN", "MinkUNet") and not getattr(type(m), "_pcs_fused_class", False):
@@ -753,10 +835,10 @@ def _adopt(plan, bns):
 
 def fuse(model, criterion=True, glue=True, forward=True):
     """Swap the forwards of the blocks this pass recognises (see the module docstring). Idempotent. Returns a dict of counts:
-    {"sequential": .., "residual": .., "conv_bn": .., "criterion": .., "glue": .., "forward": .., "dense": ..}."""
+    {"sequential": .., "residual": .., "conv_bn": .., "criterion": .., "glue": .., "forward": .., "dense": .., "cylinder": ..}."""
     if model.__dict__.get("_pcs_fused") is not None:
         return dict(model.__dict__["_pcs_fused"]["counts"])
-    counts = {"sequential": 0, "residual": 0, "conv_bn": 0, "criterion": 0, "glue": 0, "forward": 0, "dense": 0}
+    counts = {"sequential": 0, "residual": 0, "conv_bn": 0, "criterion": 0, "glue": 0, "forward": 0, "dense": 0, "cylinder": 0}
     undo, bns, owned = [], [], set()
     mods = list(model.modules())
     for m in mods:
@@ -784,7 +866,8 @@ def fuse(model, criterion=True, glue=True, forward=True):
                 counts["conv_bn"] += _adopt(plan, bns)
         elif criterion and not isinstance(m, nn.Sequential):
             counts["criterion"] += _fuse_criterion(m, undo)
-    if bns:
+    cyl = [m for m in mods if type(m).__name__ in _CYL_FORWARDS and type(getattr(m, "conv1", None)) is spnn.Conv3d]
+    if bns or cyl:
         # stock BatchNorm1d / SyncBatchNorm / Linear modules outside every recognised plan (Cylinder_TS's per-convolution BatchNorm1d on
         # `.F`, the first / last layers of its point MLP, classifiers) and plain CrossEntropyLoss children
         planned = set()
@@ -809,6 +892,9 @@ def fuse(model, criterion=True, glue=True, forward=True):
                         m._modules[name] = _MaskedCE(child)
                         undo.append(("submodule", m, name, child))
                         counts["criterion"] += 1
+    if bns:
+        for m in cyl:
+            counts["cylinder"] += _fuse_cylinder_block(m, undo)
     if bns and glue:
         counts["glue"] = _fuse_glue(model)
     if bns and forward and glue:   # the fused forwards are written against this package's glue helpers (see _glue_is_ours)

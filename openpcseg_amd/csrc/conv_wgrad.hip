@@ -51,7 +51,7 @@ __device__ __forceinline__ void find_split(const int32_t *koff, int K, int pch, 
 // interleave = 0: launch order = offset-major: the resident workgroups sweep one offset after the other, and each of the K
 // sweeps streams the whole level's rows (both operands) from HBM -- the level (2 x 222 MB in bf16 at stride 1) does not survive
 // in the 256 MB Infinity Cache from one sweep to the next.
-// interleave = 1 [r6, opt-in: PCS_WGRAD_INTERLEAVE=1, measured neutral]: launch order = position-major. Round r (of R = the largest split count of an offset) holds, for every
+// interleave = 1 [r6, measured neutral]: launch order = position-major. Round r (of R = the largest split count of an offset) holds, for every
 // offset k, its split floor(r ns_k / R) when that value is new in round r: the resident workgroups then cover the SAME stretch of
 // destination rows under all K offsets at once, so a feature row fetched for one offset serves the others out of L2 / the
 // Infinity Cache. The splits, the partial blocks and the fixed-order reduction are unchanged: bit-identical results.
@@ -846,11 +846,12 @@ static int conv_wgrad_any(const void *fa_v, int32_t ca, const void *fb_v, int32_
   // fp32-grade, but the fp32 path of this library stays on fp32 arithmetic unless the caller opts in
   // (pcs_conv_wgrad_f32_bf16x3, or PCS_WGRAD3=2 for every shape). PCS_WGRAD3=0: wgrad2 always (A/B).
   static const int use3 = getenv("PCS_WGRAD3") ? atoi(getenv("PCS_WGRAD3")) : 1;
-  // 1: position-major launch order of the splits (find_split_wave). Measured [r6, profiles/round6_wgrad_interleave_ab.txt]:
-  // 0.94-1.05x on the 16-bit kernel, 0.76-1.05x on the fp32 one, bit-identical results -- the levels' rows already come out of the
-  // Infinity Cache between the offset sweeps; left off
-  static const int interleave_env = getenv("PCS_WGRAD_INTERLEAVE") ? atoi(getenv("PCS_WGRAD_INTERLEAVE")) : 0;
-  const int interleave = g_wgrad_interleave >= 0 ? g_wgrad_interleave : interleave_env;
+  // launch order of the splits (find_split_wave): 0 offset-major, 1 position-major, 2 position-major with every XCD on its own
+  // contiguous eighth of the sequence. Measured [r6, profiles/round6_wgrad_interleave_ab{,2}.txt], bit-identical results: 1 is
+  // neutral (0.94-1.05x); 2 is 1.04-1.31x on the 16-bit kernel (3.05 -> 2.56 ms over the shapes of a step: all offsets of a stretch
+  // of rows meet in ONE L2 instead of the Infinity Cache) and neutral / 0.90x on the MFMA-bound fp32 kernel -> 2 for half operands
+  static const int interleave_env = getenv("PCS_WGRAD_INTERLEAVE") ? atoi(getenv("PCS_WGRAD_INTERLEAVE")) : -1;
+  const int interleave = g_wgrad_interleave >= 0 ? g_wgrad_interleave : (interleave_env >= 0 ? interleave_env : (dtype != 0 ? 2 : 0));
   const int cgran = dtype == 0 ? 4 : 8;
   const bool want3 = dtype == 0 ? (use3 == 2 || force_split) : (use3 >= 1 && (use3 == 2 || wg_ngroups(ca) * wg_ngroups(cb) >= 4));
   if (thin) {

@@ -294,7 +294,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const void *__restric
                                                            const double *__restrict__ count_dev,
                                                            const float *__restrict__ w, int64_t n, int c, int cv,
                                                            int relu, void *__restrict__ dx, void *__restrict__ dres,
-                                                           int64_t lddy) {
+                                                           int64_t lddy, float in_slope) {
+  // in_slope != 1: the BatchNorm's INPUT x is a LeakyReLU output (conv -> LeakyReLU -> BatchNorm,
+  // R:pcseg/model/segmentor/voxel/cylinder3d/cylinder_ts.py:88-190): dx is multiplied by the activation's derivative
+  // (x > 0 ? 1 : in_slope; the sign of a LeakyReLU output is its input's), i.e. it leaves as the gradient of the PRE-activation
   using VT = typename NV<V>::T;
   if (count_dev) count = *count_dev;
   if (!(count > 0.0)) count = 1.0;
@@ -323,7 +326,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const void *__restric
         float g = comp(gv, q);
         if (relu && ((V == 4 && mask) ? !((bits >> q) & 1u) : comp(yv, q) <= 0.f)) g = 0.f;
         const float xh = (comp(xv, q) - mean[q]) * invstd[q];
-        setc(o, q, (g - k1[q] - xh * k2[q]) * ws[q]);
+        float d = (g - k1[q] - xh * k2[q]) * ws[q];
+        if (in_slope != 1.f && !(comp(xv, q) > 0.f)) d *= in_slope;
+        setc(o, q, d);
         setc(r, q, g);
       }
       stv(ET{}, dx, i * c + (int64_t)j * V, o);
@@ -410,7 +415,7 @@ static int bn_apply_any(int dtype, const void *x, const void *res, const double 
 static int bn_bwd_apply_any(int dtype, const void *dy, const void *x, const void *y, const uint32_t *mask,
                             const double *stat, const double *sums2, double count, const double *count_dev,
                             const float *w, int64_t n, int32_t c, int32_t relu, void *dx, void *dres, int64_t lddy,
-                            void *stream) {
+                            void *stream, float in_slope = 1.f) {
   if (n < 0 || c <= 0 || (!count_dev && !(count > 0))) { set_error("pcs_bn_bwd_apply: bad sizes"); return PCS_EINVAL; }
   if (lddy == 0) lddy = c;
   if (lddy < c) { set_error("pcs_bn_bwd_apply: row stride of dy smaller than c"); return PCS_EINVAL; }
@@ -421,10 +426,10 @@ static int bn_bwd_apply_any(int dtype, const void *dy, const void *x, const void
   if (mask && (!vec || (c & 31))) { set_error("pcs_bn_bwd_apply: the ReLU bit mask needs c % 32 == 0 and aligned rows"); return PCS_EUNSUPPORTED; }
   if (vec) {
     Geo g = geo<4>(n, c);
-    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<4, ET>), g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, g.cv, relu, dx, dres, lddy));
+    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<4, ET>), g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, g.cv, relu, dx, dres, lddy, in_slope));
   } else {
     Geo g = geo<1>(n, c);
-    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<1, ET>), g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, g.cv, relu, dx, dres, lddy));
+    PCS_BN_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<1, ET>), g.grid, g.block, 0, st, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, g.cv, relu, dx, dres, lddy, in_slope));
   }
   return check_launch("pcs_bn_bwd_apply");
 }
@@ -517,6 +522,15 @@ extern "C" int pcs_bn_bwd_apply_f32(const float *dy, const float *x, const float
                                     const float *w, int64_t n, int32_t c, int32_t relu, float *dx, float *dres,
                                     int64_t lddy, void *stream) {
   return bn_bwd_apply_any(0, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, relu, dx, dres, lddy, stream);
+}
+// the same with the BatchNorm's input being a LeakyReLU output: dx leaves multiplied by (x > 0 ? 1 : in_slope) -- the gradient of the
+// activation's INPUT, handed straight to the convolution that produced it (its write-back applied the LeakyReLU: pcs_conv_epilogue.act_slope)
+extern "C" int pcs_bn_bwd_apply_act(const void *dy, const void *x, const void *y, const uint32_t *mask,
+                                    const double *stat, const double *sums2, double count, const double *count_dev,
+                                    const float *w, int64_t n, int32_t c, int32_t relu, int32_t dtype, float in_slope, void *dx,
+                                    void *dres, int64_t lddy, void *stream) {
+  if (dtype < 0 || dtype > 2 || !(in_slope > 0.f)) { set_error("pcs_bn_bwd_apply_act: dtype must be 0 / 1 / 2 and in_slope > 0"); return PCS_EINVAL; }
+  return bn_bwd_apply_any(dtype, dy, x, y, mask, stat, sums2, count, count_dev, w, n, c, relu, dx, dres, lddy, stream, in_slope);
 }
 extern "C" int pcs_bn_bwd_apply_h(const void *dy, const void *x, const void *y, const uint32_t *mask,
                                   const double *stat, const double *sums2, double count, const double *count_dev,

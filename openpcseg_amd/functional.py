@@ -319,15 +319,20 @@ class _SparseConv(Function):
     computed in fp32 and their output rounded to the half dtype, like the reference's half pipeline would hand on."""
 
     @staticmethod
-    def forward(ctx, input, weight, entry, transposed, want_stats=False, with_skip=False):
+    def forward(ctx, input, weight, entry, transposed, want_stats=False, with_skip=False, act_slope=None):
         """want_stats: also return the BatchNorm statistics of the output when the kernel produced them in its write-back
         -- on the HIP backend the per-tile partials ([tiles][2][cout] float64; `_FusedBN` reduces them), on others the
         reduced vector [sum x | sum x^2 | n] --, else an empty tensor (the BatchNorm then runs its own pass).
         with_skip: also return the input itself (an alias) as the LAST output, for the caller's residual / skip path
         (`relu(net(x) + downsample(x))`, R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:88-129). Both uses of x then hang on
         this one autograd node, which receives the skip path's gradient together with the convolution's and lets the dgrad
-        kernel add it in its write-back (pcs_conv_gather_gemm_*_add) -- instead of autograd summing two gradient tensors with an
-        elementwise kernel per block."""
+        kernel add it in its write-back (pcs_conv_gather_gemm_*_ex) -- instead of autograd summing two gradient tensors with an
+        elementwise kernel per block.
+        act_slope: the kernel applies LeakyReLU(act_slope) in its write-back (conv -> LeakyReLU -> BatchNorm1d,
+        R:pcseg/model/segmentor/voxel/cylinder3d/cylinder_ts.py:88-190). CONTRACT: the gradient this node is handed is then the
+        gradient of the PRE-activation -- the consumer (a fused BatchNorm with in_slope, fused._FusedBN) has multiplied the
+        activation's derivative in. Only block_fusion's Cylinder forwards use it, with exactly that consumer; shapes whose kernel
+        takes no write-back extras are refused by the caller (`conv_act_fusable`)."""
         be = _be()
         hd = _amp_dtype(input)
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
@@ -342,6 +347,8 @@ class _SparseConv(Function):
         kw = {"bn_sums": got} if want_stats else {}
         if want_stats and getattr(be, "supports_bn_raw", False):
             kw["bn_raw"] = True   # the per-tile partials themselves: the BatchNorm reduces and finalizes them in ONE launch
+        if act_slope is not None:
+            kw["act_slope"] = float(act_slope)
         if hd is not None and input.is_cuda and be.conv_h_applies(cin, cout, k):
             x = input.contiguous().to(hd)
             if _WeightPrep.usable(be, weight):
@@ -376,7 +383,7 @@ class _SparseConv(Function):
     def backward(ctx, grad_output, *rest):
         grad_skip = rest[-1] if ctx.with_skip and rest else None
         if grad_output is None:
-            return grad_skip, None, None, None, None, None
+            return grad_skip, None, None, None, None, None, None
         be = _be()
         x, weight, entry, transposed, hd = ctx.for_backwards
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
@@ -444,7 +451,21 @@ class _SparseConv(Function):
                 grad_weight = be.conv_wgrad(x.float(), grad_output.contiguous().float(), entry.fwd, a_col,
                                             split=_wgrad_split(cin, cout))
             grad_weight = grad_weight.view_as(weight).to(weight.dtype)
-        return grad_input, grad_weight, None, None, None, None
+        return grad_input, grad_weight, None, None, None, None, None
+
+
+def conv_act_fusable(feats, weight):
+    """The convolution of these operands runs on a kernel that takes the write-back extras (LeakyReLU, addend)."""
+    be = _be()
+    if not (feats.is_cuda and hasattr(be, "conv_supports_addend") and weight.dim() == 3):
+        return False
+    k, cin, cout = weight.shape
+    if _channel_padding(feats, weight) != (0, 0) or (_amp_dtype(feats) is None and _CONV_POLICY["mode"] == "bf16x3"):
+        return False
+    hd = _amp_dtype(feats)
+    if hd is not None and be.conv_h_applies(cin, cout, k):
+        return True
+    return be.conv_supports_addend(cin, cout, k, 0)
 
 
 def _identity_map(n, device, cache):
@@ -520,9 +541,16 @@ def _channel_padding(feats, weight):
     return pin, pout
 
 
-def _sparse_conv(feats, weight, entry, transposed, bn_stats, with_skip=False):
+def _sparse_conv(feats, weight, entry, transposed, bn_stats, with_skip=False, act_slope=None):
     """-> (out, bn_sums or None[, skip alias of feats when with_skip])."""
     pin, pout = _channel_padding(feats, weight)
+    if act_slope is not None:
+        assert not (pin or pout), "act_slope: the caller checks conv_act_fusable()"
+        outs = _SparseConv.apply(feats, weight, entry, transposed, bool(bn_stats), bool(with_skip), float(act_slope))
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        sums = outs[1] if bn_stats else None
+        res = (outs[0], (sums if sums is not None and sums.numel() else None))
+        return res + (outs[-1],) if with_skip else res
     if pin or pout:
         cout = weight.shape[2]
         padded = torch.nn.functional.pad(feats, (0, pin)) if pin else feats
@@ -540,7 +568,8 @@ def _sparse_conv(feats, weight, entry, transposed, bn_stats, with_skip=False):
     return res + (outs[-1],) if with_skip else res
 
 
-def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transposed=False, bn_stats=False, with_skip=False):
+def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transposed=False, bn_stats=False, with_skip=False,
+           act_slope=None):
     """bn_stats (not in the reference's signature; used by the fused blocks): ask the convolution for the BatchNorm
     statistics of its output; they are attached to the returned tensor as `.bn_sums` when the kernel produced them.
     with_skip (likewise): return (output, skip) where skip is the INPUT tensor again, routed through the convolution's autograd
@@ -573,17 +602,17 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
             input.kmaps[key] = build_kernel_map(input.coords, output_coords, kernel_size,
                                                 input.stride, dilation)
         if with_skip:
-            output_feats, bn_sums, skip_feats = _sparse_conv(input.feats, weight, input.kmaps[key], False, bn_stats and bias is None, True)
+            output_feats, bn_sums, skip_feats = _sparse_conv(input.feats, weight, input.kmaps[key], False, bn_stats and bias is None, True, act_slope)
         else:
-            output_feats, bn_sums = _sparse_conv(input.feats, weight, input.kmaps[key], False, bn_stats and bias is None)
+            output_feats, bn_sums = _sparse_conv(input.feats, weight, input.kmaps[key], False, bn_stats and bias is None, False, act_slope)
     else:
         output_stride = tuple(input.stride[k] // stride[k] for k in range(3))
         output_coords = input.cmaps[output_stride]
         key = (output_stride, kernel_size, stride, dilation)
         if with_skip:
-            output_feats, bn_sums, skip_feats = _sparse_conv(input.feats, weight, input.kmaps[key], True, bn_stats and bias is None, True)
+            output_feats, bn_sums, skip_feats = _sparse_conv(input.feats, weight, input.kmaps[key], True, bn_stats and bias is None, True, act_slope)
         else:
-            output_feats, bn_sums = _sparse_conv(input.feats, weight, input.kmaps[key], True, bn_stats and bias is None)
+            output_feats, bn_sums = _sparse_conv(input.feats, weight, input.kmaps[key], True, bn_stats and bias is None, False, act_slope)
 
     if bias is not None:
         output_feats += bias

@@ -95,7 +95,10 @@ class _FusedBN(Function):
 
     @staticmethod
     def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, sync, cache, level, pre=None,
-                tail=None, link=None):
+                tail=None, link=None, in_slope=None):
+        """in_slope: x is the output of a LeakyReLU that the producing convolution applied in its write-back; the gradient this
+        node returns for x is then the gradient of the PRE-activation (the derivative rides in the backward apply pass), which is
+        what that convolution's backward expects (functional._SparseConv, act_slope)."""
         """tail (n, ct): concat fusion -- the output is cat([bn(x), tail], 1), the BN result written straight into the left
         columns and `tail` copied to the right ones by the apply launch (no torch.cat pass); backward reads its dy out of
         the gradient of that buffer through a row stride and hands the right columns on as tail's gradient."""
@@ -131,6 +134,7 @@ class _FusedBN(Function):
             gate = (y if tail is None else y[:, :c].contiguous()) if relu else None
         ctx.save_for_backward(x, gate, stat, weight, count_dev)
         ctx.cfg = (count, relu, sync, res is not None, tail is not None)
+        ctx.in_slope = in_slope
         ctx.link = None
         if link is not None and tail is None and n > 0 and c % 4 == 0 and hasattr(be, "bn_bwd_reduce_partials") and (
                 not relu or (gate is not None and gate.dtype != y.dtype)):   # the gate as a bit mask (c % 32 == 0), or no ReLU
@@ -162,14 +166,17 @@ class _FusedBN(Function):
         if _syncing(sync):
             sums2 = local.clone()
             dist.all_reduce(sums2, group=_stats_group())
-        dx, dres = be.bn_bwd_apply(dy, x, gate, stat, sums2, count, weight, relu, has_res, count_dev=count_dev)
+        if ctx.in_slope is not None:
+            dx, dres = be.bn_bwd_apply(dy, x, gate, stat, sums2, count, weight, relu, has_res, count_dev=count_dev, in_slope=ctx.in_slope)
+        else:
+            dx, dres = be.bn_bwd_apply(dy, x, gate, stat, sums2, count, weight, relu, has_res, count_dev=count_dev)
         dw = db = None
         if weight is not None:  # local sums: DDP averages parameter grads
             lw = getattr(local, "_pcs_f32", None)   # the HIP reduction leaves them in fp32 as well
             if lw is None or lw.dtype != weight.dtype:
                 lw = local.to(weight.dtype)         # one cast for both halves
             dw, db = lw[c:], lw[:c]
-        return dx, dres, dw, db, None, None, None, None, None, None, None, None, None, dtail, None
+        return dx, dres, dw, db, None, None, None, None, None, None, None, None, None, dtail, None, None
 
 
 class FusedBatchNorm(nn.Module):

@@ -53,6 +53,8 @@ SIGNATURES = {
                                               _P, c_int32, c_int64, _P, _P, _P, _P, _P, _P]),
     "pcs_conv_supports_epilogue": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     "pcs_bn_bwd_reduce_partials": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P]),
+    "pcs_bn_bwd_apply_act": (c_int32, [_P, _P, _P, _P, _P, _P, c_double, _P, _P, c_int64, c_int32, c_int32, c_int32, c_float, _P, _P,
+                                       c_int64, _P]),
     "pcs_bn_reduce_partials": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P]),
     "pcs_bn_reduce_partials_finalize": (c_int32, [_P, c_int64, c_int32, c_int64, c_double, c_double, _P, _P, _P, _P, _P]),
     "pcs_transpose_kab_f32": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P]),
@@ -617,14 +619,15 @@ class HipBackend:
         return bool(self.lib.pcs_conv_emits_bn_partials(cin, cout, k, self.tile_rows(cin, cout, kmap, code), code))
 
     class _Epilogue(ctypes.Structure):   # include/pcseg_hip.h: pcs_conv_epilogue
-        _fields_ = [("addend", ctypes.c_void_p), ("bn_x", ctypes.c_void_p), ("bn_mask", ctypes.c_void_p), ("bn_stat", ctypes.c_void_p)]
+        _fields_ = [("addend", ctypes.c_void_p), ("bn_x", ctypes.c_void_p), ("bn_mask", ctypes.c_void_p), ("bn_stat", ctypes.c_void_p),
+                    ("act_slope", ctypes.c_float), ("reserved", ctypes.c_int32)]
 
-    def _epilogue(self, addend, bn_bwd, kmap, cout, dtype, t, cin, k, code, device):
+    def _epilogue(self, addend, bn_bwd, kmap, cout, dtype, t, cin, k, code, device, act_slope=None):
         """-> (ctypes pointer or None, keep-alive tuple, partial workspace or None) for the _ex entries.
         bn_bwd = (x, mask or None, stat): the BatchNorm whose output gradient this launch writes."""
-        if addend is None and bn_bwd is None:
+        if addend is None and bn_bwd is None and act_slope is None:
             return None, None, None
-        ep, part = self._Epilogue(None, None, None, None), None
+        ep, part = self._Epilogue(None, None, None, None, float(act_slope) if act_slope is not None else 0.0, 0), None
         if addend is not None:
             addend = _dev(addend, "addend", dtype)
             if tuple(addend.shape) != (kmap.n_dst, cout):
@@ -657,7 +660,7 @@ class HipBackend:
         return sums2
 
     def conv_gather_gemm(self, src, weight, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True, bn_raw=False, addend=None,
-                         bn_bwd=None, bn_bwd_out=None):
+                         bn_bwd=None, bn_bwd_out=None, act_slope=None):
         """dst[d] = sum_{(s,d) in offset k} src[s] @ weight[k] (+bias); kmap dst-sorted. bn_sums: a list; when the
         kernel can, the [sum x | sum x^2 | n] vector of dst (what bn_stats(dst) returns) is appended to it, computed in
         the convolution's write-back instead of by a pass over dst. ordered: True = heaviest-first tile order where it
@@ -677,7 +680,7 @@ class HipBackend:
         part = self._bn_partial(kmap, t, cin, cout, k, 0, bn_sums, src.device)
         order = self._tile_order(kmap, t) if (ordered == "force" or (ordered and self._wants_order(kmap))) and kmap.n_dst > 0 and self.lib.pcs_conv_uses_tile_order(cin, cout, k, 0) else None
         # write-back extras: addend (dgrad + skip gradient), bn_bwd (the backward statistics of the BatchNorm this gradient enters)
-        ep, keep, gpart = self._epilogue(addend, bn_bwd, kmap, cout, torch.float32, t, cin, k, 0, src.device)
+        ep, keep, gpart = self._epilogue(addend, bn_bwd, kmap, cout, torch.float32, t, cin, k, 0, src.device, act_slope)
         _check(self.lib.pcs_conv_gather_gemm_f32_ex(_ptr(src), src.shape[0], cin, _ptr(weight), k, cout,
                                                     _ptr(kmap._pairs_raw), 0, _ptr(seg), t, kmap.n_dst,
                                                     _ptr(bias) if bias is not None else None, ep, _ptr(dst),
@@ -712,7 +715,7 @@ class HipBackend:
         return wp
 
     def conv_gather_gemm_h(self, src, wp, k, cout, kmap, bias=None, tile_rows=None, bn_sums=None, ordered=True, bn_raw=False,
-                           addend=None, bn_bwd=None, bn_bwd_out=None):
+                           addend=None, bn_bwd=None, bn_bwd_out=None, act_slope=None):
         """Half-precision fused conv: src (n, cin) bf16 / fp16, wp = prepare_weights_h(...) of the same dtype."""
         if src.dtype not in self._HALF:
             raise TypeError("openpcseg_amd: conv_gather_gemm_h wants bfloat16 / float16 features, got %s" % src.dtype)
@@ -730,7 +733,7 @@ class HipBackend:
         dst = torch.empty((kmap.n_dst, cout), dtype=src.dtype, device=src.device)
         part = self._bn_partial(kmap, t, cin, cout, k, self._HALF[src.dtype], bn_sums, src.device)
         order = self._tile_order(kmap, t) if (ordered == "force" or (ordered and self._wants_order(kmap))) and kmap.n_dst > 0 else None
-        ep, keep, gpart = self._epilogue(addend, bn_bwd, kmap, cout, src.dtype, t, cin, k, self._HALF[src.dtype], src.device)
+        ep, keep, gpart = self._epilogue(addend, bn_bwd, kmap, cout, src.dtype, t, cin, k, self._HALF[src.dtype], src.device, act_slope)
         _check(self.lib.pcs_conv_gather_gemm_h_ex(_ptr(src), src.shape[0], cin, _ptr(wp), k, cout, _ptr(kmap._pairs_raw), 0,
                                                   _ptr(seg), t, kmap.n_dst, _ptr(bias) if bias is not None else None, ep,
                                                   _ptr(dst), self._HALF[src.dtype],
@@ -1094,13 +1097,20 @@ class HipBackend:
                                                _ptr(ws), _ptr(sums2), buf.numel(), lddy, _stream()), "pcs_bn_bwd_stats_h")
         return sums2
 
-    def bn_bwd_apply(self, dy, x, gate, stat, sums2, count, w, relu, want_res, count_dev=None):
+    def bn_bwd_apply(self, dy, x, gate, stat, sums2, count, w, relu, want_res, count_dev=None, in_slope=None):
         x = self._feat(x, "input")
         n, c = x.shape
         dy, lddy = self._rows(dy, "grad_output", x, c)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if want_res else None
         yp, mp = self._gate(gate, relu)
+        if in_slope is not None and float(in_slope) != 1.0:   # x is a LeakyReLU output: dx leaves as the gradient of the pre-activation
+            code = 0 if x.dtype == torch.float32 else self._HALF[x.dtype]
+            _check(self.lib.pcs_bn_bwd_apply_act(_ptr(dy), _ptr(x), yp, mp, _ptr(stat), _ptr(sums2), float(count),
+                                                 _ptr(count_dev) if count_dev is not None else None,
+                                                 _ptr(w) if w is not None else None, n, c, int(relu), code, float(in_slope),
+                                                 _ptr(dx), _ptr(dres) if want_res else None, lddy, _stream()), "pcs_bn_bwd_apply_act")
+            return dx, dres
         head = [_ptr(dy), _ptr(x), yp, mp, _ptr(stat), _ptr(sums2), float(count),
                 _ptr(count_dev) if count_dev is not None else None, _ptr(w) if w is not None else None, n, c, int(relu)]
         tail = [_ptr(dx), _ptr(dres) if want_res else None, lddy, _stream()]

@@ -372,6 +372,72 @@ def test_fused_spvcnn_and_rpvnet_on_hip(gold, env_hip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_fused_cylinder_blocks_equal_plain_on_hip(env_hip, monkeypatch, amp):
+    """Cylinder_TS's ResContextBlock / ResBlock / UpBlock (R:pcseg/model/segmentor/voxel/cylinder3d/cylinder_ts.py:88-330) after
+    `fuse`: LeakyReLU and the BatchNorm statistics in the convolution's write-back, the activation's derivative in the BatchNorm
+    backward apply pass -- against the same blocks with that fusion switched off (PCS_CYL_FUSED=0: the reference's own op sequence on
+    this package's kernels). Outputs, input gradient, every parameter gradient and the BatchNorm buffers."""
+    import openpcseg_amd
+    from openpcseg_amd import block_fusion as fz
+    from openpcseg_amd.sparse import SparseTensor
+    from openpcseg_amd.workloads.synthetic import make_batch
+    mg, mod = _load("pcseg.model.segmentor.voxel.cylinder3d.cylinder_ts")
+    coords = make_batch([3], n_points=20000)["lidar"].C.to(env_hip.dev)
+    n = coords.shape[0]
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ctx = mod.ResContextBlock(32, 32, indice_key="pre")
+            self.down = mod.ResBlock(32, 64, 0.2, height_pooling=True, indice_key="down2")
+            self.up = mod.UpBlock(64, 64, indice_key="up0", up_key="down2", height_pooling=True)
+
+        def forward(self, x):
+            c = self.ctx(x)
+            d, skip = self.down(c)
+            return self.up(d, skip)
+
+    def run(fused):
+        monkeypatch.setenv("PCS_CYL_FUSED", "1" if fused else "0")
+        torch.manual_seed(11)
+        net = Net().to(env_hip.dev).train()
+        counts = openpcseg_amd.fuse(net)
+        assert counts["cylinder"] == 3
+        x = torch.randn(n, 32, device=env_hip.dev, generator=torch.Generator(device=env_hip.dev).manual_seed(2)).requires_grad_(True)
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            out = net(SparseTensor(x, coords))
+        gy = torch.randn(out.F.shape, device=env_hip.dev, generator=torch.Generator(device=env_hip.dev).manual_seed(4))
+        out.F.float().backward(gy)
+        res = {"out": out.F.float().detach(), "gx": x.grad}
+        res.update({"g:" + k: p.grad for k, p in net.named_parameters() if p.grad is not None})
+        res.update({"b:" + k: b.float() for k, b in net.named_buffers() if b.dtype.is_floating_point})
+        fz.unfuse(net)
+        return res
+
+    plain, fused = run(False), run(True)
+    assert plain.keys() == fused.keys()
+
+    def err(a, b):
+        return {k: float((a[k].float() - b[k].float()).abs().mean()) / max(float(b[k].float().abs().mean()), 1e-9) for k in b}
+    if amp is None:
+        worst = {k: float((fused[k] - plain[k]).abs().max()) / max(float(plain[k].abs().max()), 1e-6) for k in plain}
+        assert max(worst.values()) <= 2e-4, max(worst.items(), key=lambda kv: kv[1])
+    else:
+        # two 16-bit routes that round at different places drift apart through a dozen BatchNorm backward passes (cancellation in
+        # g - mean(g) - xhat mean(g xhat)): each is held against the SAME blocks in fp32 -- the fused route must be as close to
+        # fp32 as the plain 16-bit route is
+        amp = None
+        ref = run(False)
+        e_plain, e_fused = err(plain, ref), err(fused, ref)
+        if os.environ.get("PCS_TEST_VERBOSE"):
+            for k in ref:
+                print("%-40s plain %.2e fused %.2e" % (k, e_plain[k], e_fused[k]))
+        for k in ref:
+            assert e_fused[k] <= 1.5 * e_plain[k] + 2e-3, (k, e_fused[k], e_plain[k])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout", [(9, 64), (32, 256), (256, 20), (100, 36)])
 def test_dense_linear_and_batchnorm_match_torch_on_hip(hip, cin, cout):
     """The re-classed stock nn.Linear / nn.BatchNorm1d of a fused model ((N, C) rows of >= 4096 points: Cylinder_TS's point MLP and
