@@ -41,9 +41,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA pe
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 TRAFFIC_FILE = "round6_conv_traffic.json"
 # what the counters say binds conv_os5h_kernel (profiles/round3_convh_pmc.md); filled in from the PMC passes of round 3
-HALF_BINDING_NOTE = ("vector-memory address path (TA / vector L1), not HBM and not the MFMA pipe: TA 65-81 % busy, MFMA pipe 10-19 %, "
-                     "L2 hit 77-94 %, HBM 1.3-3 TB/s on the two reference shapes; 1.1-1.6 MFMAs per 16-byte operand load "
-                     "(rocprofv3 --pmc, profiles/round3_convh_pmc.md)")
+HALF_BINDING_NOTE = ("gather latency / vector L1, not HBM and not the MFMA pipe [r6 counters, profiles/round6_convh_ws.md]: MFMA pipe 15 % busy, "
+                     "TA 63 %, vector L1 ~60 % of 64 B/clk/CU, waves parked 47 %; conv_os6h keeps the weights stationary in registers and "
+                     "prefetches the gathered rows a sub-group ahead (round 5's conv_os5h: TA 65-81 %, MFMA 10-19 %)")
 POINTS_PER_FRAME = 120000
 
 

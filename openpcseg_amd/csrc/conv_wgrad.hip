@@ -530,6 +530,7 @@ struct Wgrad3Args {
   int ca, cb, K, a_col, pch;
   int aw, bw, nag, nbg, nsb;  // group widths, group counts, b super-groups (pairs of groups) per row of super-blocks
   int interleave;             // launch order of the splits (find_split_wave)
+  int nsy = 1;                // super-blocks per split (interleave == 2: the launch is one-dimensional)
 };
 
 template <typename ET> struct W3Mode;
@@ -570,9 +571,17 @@ __global__ void __launch_bounds__(NT, NT == 256 ? (W3Mode<ET>::PLANES == 1 ? 3 :
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
   int beg, end, gsid;
-  find_split_wave(w.koff, w.K, w.pch, blockIdx.x, lane, &beg, &end, &gsid, w.interleave);  // the same answer in every wave
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (w.interleave == 2 && w.nsy > 1) {
+    // one-dimensional launch: on every XCD (workgroup id % 8) the super-blocks of one split run back to back, so the rows a split
+    // gathers for its first 128 x 128 block serve the others out of that XCD's L2 (256-channel layers: four blocks per split)
+    const int slot = bx >> 3;
+    by = slot % w.nsy;
+    bx = ((slot / w.nsy) << 3) | (bx & 7);
+  }
+  find_split_wave(w.koff, w.K, w.pch, bx, lane, &beg, &end, &gsid, w.interleave);  // the same answer in every wave
   if (beg >= end) return;  // workgroup-uniform
-  const int sa = blockIdx.y / w.nsb, sb = blockIdx.y - sa * w.nsb;  // super-block = 2 x 2 channel groups
+  const int sa = by / w.nsb, sb = by - sa * w.nsb;  // super-block = 2 x 2 channel groups
   const int a_base = 2 * sa * w.aw, b_base = 2 * sb * w.bw;
   const int a_stage = (w.ca - a_base) < 2 * w.aw ? (w.ca - a_base) : 2 * w.aw;  // channels staged per operand
   const int b_stage = (w.cb - b_base) < 2 * w.bw ? (w.cb - b_base) : 2 * w.bw;
@@ -746,7 +755,8 @@ __global__ void __launch_bounds__(NT, NT == 256 ? (W3Mode<ET>::PLANES == 1 ? 3 :
 template <typename ET>
 int launch_wgrad3(const Wgrad3Args &w, int ns, hipStream_t st) {
   const int nsa = (w.nag + 1) / 2;
-  const dim3 grid((unsigned)(w.interleave == 2 ? 8 * ((ns + 7) / 8) : ns), (unsigned)(nsa * w.nsb));
+  const int nsy = nsa * w.nsb;
+  const dim3 grid = w.interleave == 2 ? dim3((unsigned)(8 * ((ns + 7) / 8) * nsy), 1u) : dim3((unsigned)ns, (unsigned)nsy);
   const int na = w.aw / 16, nb = w.bw / 16;
 #define PCS_W3_CASE(A, B) if (na == A && nb == B) { hipLaunchKernelGGL((wgrad3_kernel<ET, A, B>), grid, dim3(256), 0, st, w); return check_launch("pcs_conv_wgrad(wgrad3)"); }
   PCS_W3_CASE(4, 4) PCS_W3_CASE(4, 3) PCS_W3_CASE(4, 2) PCS_W3_CASE(4, 1)
@@ -867,6 +877,7 @@ static int conv_wgrad_any(const void *fa_v, int32_t ca, const void *fb_v, int32_
     w3.ca = ca; w3.cb = cb; w3.K = K; w3.a_col = a_col; w3.pch = pch;
     w3.aw = wg_gwidth(ca); w3.bw = wg_gwidth(cb); w3.nag = wg_ngroups(ca); w3.nbg = wg_ngroups(cb); w3.nsb = (w3.nbg + 1) / 2;
     w3.interleave = interleave;
+    w3.nsy = ((w3.nag + 1) / 2) * w3.nsb;
     int rc3 = dtype == 0 ? launch_wgrad3<Fp32>(w3, ns, st) : (dtype == 1 ? launch_wgrad3<Bf16>(w3, ns, st) : launch_wgrad3<Fp16>(w3, ns, st));
     if (rc3) return rc3;
   } else if (vec) {

@@ -661,7 +661,7 @@ def test_conv_x3_nonfinite_inputs_follow_the_fp32_kernel(hip, levels):
     assert float((y3[ok] - y32[ok]).abs().max()) <= 2e-5 * float(y32[ok].abs().max())
 
 
-# The ring kernels are NOT in the product library [r5] (tools/experimental/csrc/): their two tests run only
+# The ring kernels are NOT in the product library [r5] (tools/experimental/csrc/, profiles/DESIGN_rounds1-5.md section 5d): their two tests run only
 # inside the subprocess tests/test_ring_variant.py starts with PCS_LIB_PATH = the variant build `tools/build_variant_lib.sh ring`.
 _ring_variant = pytest.mark.skipif(os.environ.get("PCS_RING_VARIANT") != "1",
                                    reason="ring kernels live in the variant library (tests/test_ring_variant.py runs these)")

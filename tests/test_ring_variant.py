@@ -1,5 +1,5 @@
 """The experimental column-parallel "ring" convolution kernels (round 4: parity-green, 0.47-0.70x the wave kernels,
-profiles/round4_ring.md) are NOT part of libpcseg_hip.so: sources under tools/experimental/csrc/, built only
+profiles/round4_ring.md, profiles/DESIGN_rounds1-5.md section 5d) are NOT part of libpcseg_hip.so: sources under tools/experimental/csrc/, built only
 into the variant library `tools/build_variant_lib.sh ring` (-DPCS_WITH_RING=1). This test keeps them from rotting: it builds the
 variant on the GPU box (hipcc is there) and runs their oracle-parity cases (tests/test_dense_parity.py::test_ring_conv_*) in a
 subprocess bound to that library."""

@@ -80,7 +80,7 @@ rows), the other 26 offsets hold 25-60 pairs (1-2 groups). At the heights the ha
 deeper) a slab staged once per (tile, offset) would be read 1.7 (stride 1), 1.9 (stride 2), 2.4 (strides 4-16) times: LDS staging
 would remove 1 - 1 / reuse = **42 % / 48 % / 58 %** of the weight-slab loads, i.e. 30-45 % of ALL operand loads of a kernel whose binding
 unit is the vector-memory address path (75-80 % of its loads are weight fragments, profiles/round3_convh_pmc.md). With the fragments
-then coming out of LDS at R = 2 (ds_read_b128 at its 128 B/clk peak) the estimate of the round-4 verdict -- ~1.3-1.5x
+then coming out of LDS at R = 2 (ds_read_b128 at its 128 B/clk peak, profiles/DESIGN_rounds1-5.md section 9) the estimate of the round-4 verdict -- ~1.3-1.5x
 on the half kernel -- is what this table supports; taller tiles raise the reuse further (2.3-3.4 at 288 rows) but cost LDS.
 A cheaper cut the same data point at: stage ONLY the centre offset's slab (known in advance, 6 groups per 192-row tile): -14 % of the
 slab loads at stride 1, -8 % at stride 8. None of this was built in round 5: the GPU-minute budget of the round went to the reference-source route and the
