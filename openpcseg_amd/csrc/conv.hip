@@ -4,7 +4,7 @@
 // and conv_block.hip (everything else); the weight gradient in conv_wgrad.hip.
 #include <math.h>
 
-#include "conv_ring.h"
+#include "conv_half.h"
 
 using namespace pcs;
 
@@ -85,40 +85,6 @@ extern "C" int32_t pcs_conv_pick_tile_rows_dt(int64_t n_dst, int64_t n_pairs, in
   if (fixed > 0) return fixed;
   const double ppr = (double)n_pairs / (double)n_dst;
   const int nctt = conv_nctt(cout);
-  if (dtype == 0 && conv_ringf_max_rows(cin, cout, K) > 0) {
-    // fp32 ring kernel (conv_ring6f.hip): one workgroup per CU; MFMA-bound, so the tile height only trades the 16-row padding of
-    // every (tile, offset) slice against the fill of the last round of workgroups
-    static const int ringf_fixed = getenv("PCS_CONV_RINGF_TILE") ? atoi(getenv("PCS_CONV_RINGF_TILE")) : 0;
-    int tmax = conv_ringf_max_rows(cin, cout, K);
-    if (tmax > 384) tmax = 384;
-    if (ringf_fixed >= 32 && ringf_fixed <= tmax && ringf_fixed % 16 == 0) return ringf_fixed;
-    const int64_t ncol = ceil_div(cout, 16 * conv_ringf_nctt(cout));
-    int best = tmax;
-    double best_cost = 0;
-    for (int T = tmax; T >= 96 && T >= tmax / 2; T -= 16) {
-      const double per_cu = (double)(ceil_div(n_dst, T) * ncol) / (double)device_cus();
-      const double c = 0.5 * (ceil(per_cu) + per_cu) * (T * ppr + 8.0 * K + 0.06 * T);
-      if (best_cost == 0 || c < best_cost * 0.98) { best = T; best_cost = c; }
-    }
-    return best;
-  }
-  if (dtype != 0 && conv_ring_max_rows(cin, cout, K) > 0) {
-    // ring kernel (conv_ring6h.hip): one workgroup per CU, every weight slab enters the CU once per tile -- the tallest tile the
-    // LDS holds beside the operand ring amortises it best; below a few rounds of workgroups a shorter tile that fills the
-    // last round. Cost of a tile: its pairs + per offset the padding of half a row block and the weight slab (~24 rows' worth).
-    static const int ring_fixed = getenv("PCS_CONV_RING_TILE") ? atoi(getenv("PCS_CONV_RING_TILE")) : 0;
-    const int tmax = conv_ring_max_rows(cin, cout, K);
-    if (ring_fixed >= 32 && ring_fixed <= tmax && ring_fixed % 16 == 0) return ring_fixed;
-    const int64_t ncol = ceil_div(cout, 16 * nctt);
-    int best = tmax;
-    double best_cost = 0;
-    for (int T = tmax; T >= 96 && T >= tmax / 2; T -= 16) {
-      const double per_cu = (double)(ceil_div(n_dst, T) * ncol) / (double)device_cus();
-      const double c = 0.5 * (ceil(per_cu) + per_cu) * (T * ppr + 24.0 * K);
-      if (best_cost == 0 || c < best_cost * 0.98) { best = T; best_cost = c; }
-    }
-    return best;
-  }
   if (dtype != 0) {
     // 16-bit MFMA kernels: bound by the operand stream and, on the sparse levels, by the serial commit chain of a
     // workgroup -- two (or more) 4-wave workgroups per CU beat one tall 8-wave workgroup except on the >= 256-channel
@@ -185,11 +151,7 @@ extern "C" int32_t pcs_conv_emits_bn_partials(int32_t cin, int32_t cout, int32_t
   if (cin <= 0 || cout <= 0 || K <= 0 || K > 32 || (cin % 4) || (cout % 4) || tile_rows < 16) return 0;
   int nctt = conv_nctt(cout), nt = 256;
   if (dtype == 0) {
-    RingShape rs;
-    if (conv_ringf_applies(cin, cout, K, tile_rows, &rs)) {
-      nctt = rs.nctt;
-      nt = 64 * rs.nwaves();
-    } else if (conv5_applies(cin, cout, K)) {
+    if (conv5_applies(cin, cout, K)) {
       nctt = conv5_nctt(cout, tile_rows);
       nt = 2 * conv5_lds_est(tile_rows, nctt) > 160 * 1024 ? 512 : 256;
     } else if (tile_rows != 64 && tile_rows != 128) {
@@ -197,9 +159,7 @@ extern "C" int32_t pcs_conv_emits_bn_partials(int32_t cin, int32_t cout, int32_t
     }
   } else {
     if (!convh_applies(cin, cout, K)) return 0;
-    RingShape rs;
-    nt = conv_ring_applies(cin, cout, K, tile_rows, &rs) ? 64 * rs.nwaves()
-                                                         : (2 * conv5_lds_est(tile_rows, nctt) > 160 * 1024 ? 512 : 256);
+    nt = 2 * conv5_lds_est(tile_rows, nctt) > 160 * 1024 ? 512 : 256;
   }
   return conv_stats_fit(tile_rows, 16 * nctt, nt) ? 1 : 0;
 }
@@ -274,23 +234,8 @@ extern "C" int pcs_conv_gather_gemm_f32_ex(const float *src, int64_t n_src, int3
     set_error("pcs_conv_gather_gemm_f32_ex: this shape runs on the generic kernel, which takes no write-back extras (pcs_conv_supports_epilogue)");
     return PCS_EUNSUPPORTED;
   }
-  if (vec && !generic && conv_ringf_applies(cin, cout, K, tile_rows, nullptr)) return launch_conv_ring6f(a, st);
   if (vec && !generic && conv5_applies(cin, cout, K)) return launch_conv_wave5(a, st);
   if (tile_rows != 64 && tile_rows != 128) { set_error("pcs_conv_gather_gemm_f32: this shape takes tile_rows 64 or 128"); return PCS_EUNSUPPORTED; }
   if (vec && !generic && K <= 32) return launch_conv_wave4(a, st);
   return launch_conv_block(a, vec, st);
 }
-
-#if PCS_WITH_RING   // variant build only (tools/build_variant_lib.sh ring): not part of include/pcseg_hip.h
-extern "C" int32_t pcs_conv_ring_enable(int32_t kind, int32_t mode) {
-  int &m = kind == 0 ? pcs::conv_ringf_mode() : pcs::conv_ring_mode();
-  const int prev = m;
-  m = mode > 0 ? 1 : (mode < 0 ? -1 : 0);
-  return prev;
-}
-
-extern "C" int32_t pcs_conv_ring_applies(int32_t cin, int32_t cout, int32_t K, int32_t tile_rows, int32_t dtype) {
-  if (dtype == 0) return pcs::conv_ringf_applies(cin, cout, K, tile_rows, nullptr) ? 1 : 0;
-  return pcs::conv_ring_applies(cin, cout, K, tile_rows, nullptr) ? 1 : 0;
-}
-#endif

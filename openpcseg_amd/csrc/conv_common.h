@@ -56,7 +56,6 @@ struct ConvArgs {
   int cin, cout, K, src_col, ncoltiles, xcd_remap, tile_rows;
   double *stats;  // optional [ntiles][2][cout]: per-tile column sums / sums of squares of the rows written (BatchNorm)
   const int32_t *order;  // optional [ntiles]: workgroup slot -> row tile (heaviest first), nullptr = row order
-  int ring_acc_off = 0;  // ring kernel (conv_ring6f.hip): byte offset of the accumulator tile in LDS
   const float *addend = nullptr;  // optional (n_dst, cout): added to the output rows in the write-back (the wave kernels only):
                                   // the skip gradient of a residual block riding in the dgrad of its first convolution
   // optional: this launch is a dgrad whose output IS the gradient dy of a BatchNorm (+ ReLU) output -- its write-back then leaves

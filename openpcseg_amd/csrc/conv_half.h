@@ -1,6 +1,5 @@
 // Shared by the 16-bit-MFMA fused-convolution code: conv_wave5h.hip (wave-autonomous row-block groups, ticket commit),
-// weights_multi.hip, and the experimental ring kernel outside the product (tools/experimental/csrc/conv_ring6h.hip). They read
-// the same prepared weights (MFMA fragment order, pcs_conv_prepare_weights_h) and share the tile epilogue of conv_common.h.
+// conv_wave6h.hip (weight-stationary ranges) and weights_multi.hip. They read the same prepared weights (MFMA fragment order, pcs_conv_prepare_weights_h) and share the tile epilogue of conv_common.h.
 #pragma once
 #include "conv_common.h"
 
@@ -44,7 +43,6 @@ struct ConvArgsH {
   int cin, cout, K, src_col, ncoltiles, xcd_remap, tile_rows, nt16, ns;
   double *stats;  // optional [ntiles][2][cout], as ConvArgs::stats (over the ROUNDED values stored)
   const int32_t *order;  // optional [ntiles]: workgroup slot -> row tile (heaviest first), as ConvArgs::order
-  int ring_bt_cap, ring_acc_off;  // experimental ring kernel only (tools/experimental): batch-table capacity, accumulator-tile offset in LDS
   const uint16_t *addend = nullptr;  // optional (n_dst, cout) halfs: added (in fp32, before the rounding) to the output rows
   float act_slope = 1.f;              // LeakyReLU in the write-back, as ConvArgs::act_slope
   const void *gs_x = nullptr;         // BatchNorm backward statistics in the write-back, as ConvArgs::gs_* (x in the storage dtype)

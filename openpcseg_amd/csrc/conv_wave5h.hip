@@ -18,7 +18,7 @@
 // the host layer and take the fp32 kernels. cin % 32 != 0 (56, 112, 168, 336 of RPVNet cr 1.75 ...) runs the TAIL
 // instance: the last step holds 8 / 16 / 24 channels, its out-of-range lane groups read a clamped in-row address
 // and are zeroed, and the prepared weights are zero-padded to the full step.
-#include "conv_ring.h"
+#include "conv_half.h"
 
 using namespace pcs;
 
@@ -685,10 +685,6 @@ extern "C" int pcs_conv_gather_gemm_h_ex(const void *src, int64_t n_src, int32_t
   const int nctt = conv_nctt(cout);
   a.nt16 = (int)ceil_div(cout, 16 * nctt) * nctt;
   a.ns = (int)ceil_div(cin, 32);
-  a.ring_bt_cap = 0; a.ring_acc_off = 0;
-  // 96 / 128-column tiles of >= 64-channel layers whose tile fits beside the operand ring: the column-parallel ring kernel
-  // (conv_ring6h.hip: every weight slab enters the CU once per tile, gathered rows once per column tile)
-  if (conv_ring_applies(cin, cout, K, tile_rows, nullptr)) return launch_conv_ring6h(a, dtype, as_stream(stream));
   // the weight-stationary kernel (conv_wave6h.hip); its chunked-contraction instances only on 4-wave workgroups (<= 160-row tiles)
   if (conv6h_mode() && conv6h_applies(cin, cout, K) && (!conv6h_is_chunked(cin, cout) || tile_rows <= 160))
     return launch_conv_wave6h(a, dtype, as_stream(stream));

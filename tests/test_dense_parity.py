@@ -661,48 +661,6 @@ def test_conv_x3_nonfinite_inputs_follow_the_fp32_kernel(hip, levels):
     assert float((y3[ok] - y32[ok]).abs().max()) <= 2e-5 * float(y32[ok].abs().max())
 
 
-# The ring kernels are NOT in the product library [r5] (tools/experimental/csrc/, profiles/DESIGN_rounds1-5.md section 5d): their two tests run only
-# inside the subprocess tests/test_ring_variant.py starts with PCS_LIB_PATH = the variant build `tools/build_variant_lib.sh ring`.
-_ring_variant = pytest.mark.skipif(os.environ.get("PCS_RING_VARIANT") != "1",
-                                   reason="ring kernels live in the variant library (tests/test_ring_variant.py runs these)")
-
-
-@_ring_variant
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("stride,cin,cout,tile", [(1, 96, 96, None), (1, 96, 96, 48), (2, 128, 96, 272), (4, 64, 128, None),
-                                                  (4, 192, 128, 208), (8, 256, 256, 80), (8, 384, 256, None), (8, 512, 96, None)])
-def test_ring_conv_forward_dense_map(hip, levels, dtype, stride, cin, cout, tile):
-    """conv_ring6h_kernel (column-parallel waves, gathered rows through the LDS ring) on the shapes it serves: one to four
-    32-channel steps per weight chunk, one to four chunks, 96 / 128-column tiles, partial last tiles, the tallest and very
-    short tiles, with and without the tile order; against the oracle on the same half-rounded operands, bit-reproducible,
-    and bit-identical to itself under the heaviest-first order."""
-    prev = hip.lib.pcs_conv_ring_enable(1, 1)   # the kernel under test, whatever the library's per-shape policy says
-    try:
-        _ring_case(hip, levels, dtype, stride, cin, cout, tile)
-    finally:
-        hip.lib.pcs_conv_ring_enable(1, prev)
-
-
-def _ring_case(hip, levels, dtype, stride, cin, cout, tile):
-    entry, nbmaps, nbsizes, n = level_map(levels, stride)
-    assert hip.lib.pcs_conv_ring_applies(cin, cout, 27, tile or hip.tile_rows(cin, cout, entry.fwd, hip._HALF[dtype]), hip._HALF[dtype]) == 1
-    rng = np.random.default_rng(stride * 100000 + cin * 100 + cout + 17)
-    x = _round_half(rng.normal(size=(n, cin)).astype(np.float32), dtype)
-    w = _round_half((rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32), dtype)
-    bias = rng.normal(size=cout).astype(np.float32)
-    wp = hip.prepare_weights_h(t(w), dtype, transpose=False)
-    dx = t(x).to(dtype)
-    y = hip.conv_gather_gemm_h(dx, wp, 27, cout, entry.fwd, tile_rows=tile, ordered=False)
-    close_half(y, orc.conv_fwd(x, w, nbmaps, nbsizes, (n, n)), dtype)
-    assert torch.equal(y, hip.conv_gather_gemm_h(dx, wp, 27, cout, entry.fwd, tile_rows=tile, ordered="force"))
-    got = []
-    yb = hip.conv_gather_gemm_h(dx, wp, 27, cout, entry.fwd, bias=t(bias), tile_rows=tile, bn_sums=got)
-    close_half(yb, orc.conv_fwd(x, w, nbmaps, nbsizes, (n, n)) + bias[None, :], dtype)
-    if got:   # BatchNorm partials of the write-back: the statistics pass over the stored values
-        ref = hip.bn_stats(yb)
-        assert torch.allclose(got[0], ref, rtol=1e-9, atol=1e-6 * float(ref.abs().max()))
-
-
 def test_commit_variants_bit_identical(hip, levels):
     """PCS_COMMIT_NOWAIT=0 / PCS_COMMIT_PHASED=0 (the fenced ticket hand-over and the compiler-interleaved commit kept behind
     macros in conv_wave5.hip, conv_wave5h.hip and conv_wave5x.hip) produce the same bits as the default build: a variant
@@ -744,43 +702,6 @@ print("HASH", h.hexdigest())
         out.append([l for l in p.stdout.splitlines() if l.startswith("HASH")][-1])
     os.remove(lib)
     assert out[0] == out[1]
-
-
-@_ring_variant
-@pytest.mark.parametrize("stride,cin,cout,tile", [(1, 96, 96, None), (1, 32, 64, None), (1, 96, 96, 48), (2, 128, 96, 272), (4, 64, 128, None),
-                                                  (4, 192, 128, 208), (4, 64, 64, 384), (8, 256, 256, 80), (8, 384, 256, None),
-                                                  (8, 160, 192, None)])
-def test_ring_conv_f32_forward_dense_map(hip, levels, stride, cin, cout, tile):
-    """conv_ring6f_kernel (fp32 MFMA, column-parallel waves, gathered rows through the LDS ring) against the scalar oracle: one
-    and two 32-channel steps per weight chunk, one to six chunks, 64 / 96 / 128-column tiles in one to three column tiles, the
-    tallest and very short tiles; bit-reproducible, independent of the tile order, BatchNorm partials of the write-back."""
-    prev = hip.lib.pcs_conv_ring_enable(0, 1)
-    try:
-        entry, nbmaps, nbsizes, n = level_map(levels, stride)
-        assert hip.lib.pcs_conv_ring_applies(cin, cout, 27, tile or hip.tile_rows(cin, cout, entry.fwd), 0) == 1
-        rng = np.random.default_rng(stride * 100000 + cin * 100 + cout + 23)
-        x = rng.normal(size=(n, cin)).astype(np.float32)
-        w = (rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32)
-        bias = rng.normal(size=cout).astype(np.float32)
-        dx, dw = t(x), t(w)
-        y = hip.conv_gather_gemm(dx, dw, entry.fwd, tile_rows=tile, ordered=False)
-        ref = orc.conv_fwd(x, w, nbmaps, nbsizes, (n, n))
-        close(y, ref, 2e-5)
-        assert torch.equal(y, hip.conv_gather_gemm(dx, dw, entry.fwd, tile_rows=tile, ordered="force"))
-        got = []
-        yb = hip.conv_gather_gemm(dx, dw, entry.fwd, bias=t(bias), tile_rows=tile, bn_sums=got)
-        close(yb, ref + bias[None, :], 2e-5)
-        if got:
-            st = hip.bn_stats(yb)
-            assert torch.allclose(got[0], st, rtol=1e-9, atol=1e-6 * float(st.abs().max()))
-        # dgrad = the same kernel on the input-sorted map with per-offset transposed weights
-        gy = rng.normal(size=(n, cout)).astype(np.float32)
-        ogx, _ = orc.conv_bwd(x, gy, w, nbmaps, nbsizes)
-        if hip.lib.pcs_conv_ring_applies(cout, cin, 27, hip.tile_rows(cout, cin, entry.rev), 0):
-            gx = hip.conv_gather_gemm(t(gy), hip.transpose_weights(dw), entry.rev)
-            close(gx, ogx, 2e-5)
-    finally:
-        hip.lib.pcs_conv_ring_enable(0, prev)
 
 
 @pytest.mark.parametrize("amp", [None, torch.bfloat16])

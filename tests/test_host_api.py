@@ -60,6 +60,24 @@ def test_product_never_imports_oracle():
     assert len(re.findall(r"^\s*(?:from|import)\s+oracle\b", bench, re.M)) == len(re.findall(r"^\s*(?:from|import)\s+oracle\b", body, re.M)) > 0
 
 
+def test_product_sources_hold_no_retired_kernels():
+    """The column-parallel "ring" kernels of round 4 (0.47-0.70x the wave kernels, profiles/round4_ring.md) are retired: no
+    hook, stub header or export of them is left in the product sources, the C ABI or the built library; their text is kept as a
+    record under tools/experimental/csrc/*.txt (not compiled by anything)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "openpcseg_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert not f.startswith("conv_ring"), f
+        assert "conv_ring" not in open(os.path.join(csrc, f)).read() and "PCS_WITH_RING" not in open(os.path.join(csrc, f)).read(), f
+    hdr = open(os.path.join(ROOT, "include", "pcseg_hip.h")).read()
+    assert "pcs_conv_ring_enable(" not in hdr and "pcs_conv_ring_applies(" not in hdr
+    assert all(f.endswith(".txt") for f in os.listdir(os.path.join(ROOT, "tools", "experimental", "csrc")))
+    lib = os.path.join(ROOT, "openpcseg_amd", "lib", "libpcseg_hip.so")
+    if os.path.exists(lib):
+        syms = subprocess.run(["nm", "-D", lib], capture_output=True, text=True).stdout
+        assert "pcs_conv_ring" not in syms and "conv_ring6" not in syms
+
+
 def test_reference_import_names():
     openpcseg_amd.install_as_torchsparse()
     import torchsparse

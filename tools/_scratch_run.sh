@@ -1,4 +1,6 @@
-mkdir -p gpurun_out
-timeout 900 python tools/wgrad_interleave_ab.py 2>&1 | grep -v amdgpu.ids > gpurun_out/wgrad_interleave_ab3.txt; cat gpurun_out/wgrad_interleave_ab3.txt
-timeout 1500 python -m pytest tests/test_dense_parity.py tests/test_hip_parity.py -m gpu -x -q -k "wgrad or backward" 2>&1 | grep -E "^E  |passed|failed|^FAILED" | head
-timeout 1500 python bench.py > gpurun_out/round6_default_bench.log 2> gpurun_out/round6_default_bench.err; tail -1 gpurun_out/round6_default_bench.log | cut -c1-2300
+#!/bin/bash
+cd /root/repo; mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r6_gputest2.txt 2>&1
+tail -5 gpurun_out/r6_gputest2.txt
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --models none > gpurun_out/r6_bench_order.log 2>&1
+tail -2 gpurun_out/r6_bench_order.log | cut -c1-1200

@@ -3,9 +3,6 @@
 #   e.g. tools/build_variant_lib.sh rmw -DPCS_COMMIT_ATOMIC=0 ; tools/build_variant_lib.sh wait -DPCS_COMMIT_NOWAIT=0
 # -> openpcseg_amd/lib/dbg/<name>.so: every conv*.hip recompiled with the flags (conv_common.h switches reach the launch
 # shape code too), the other objects of the product build linked as they are; select it with PCS_LIB_PATH.
-# name "ring" [r5]: the experimental column-parallel ring kernels (tools/experimental/csrc/conv_ring6{h,f}.hip, round 4: parity-green,
-# 0.47-0.70x the wave kernels, profiles/round4_ring.md), which are NOT in the product library: -DPCS_WITH_RING=1 compiles them in and
-# exports pcs_conv_ring_enable / pcs_conv_ring_applies; only the three files that see the switch are recompiled.
 # Variant builds are never loaded by default and are removed before a round ends (they must not travel as product).
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -14,22 +11,11 @@ python -m openpcseg_amd.build > /dev/null
 mkdir -p $ROOT/openpcseg_amd/lib/dbg /tmp/pcsvar_$name
 rm -f /tmp/pcsvar_$name/*.o
 CC="/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics -fPIC -Wno-unused-value -Wno-array-bounds"
-if [ "$name" = "ring" ]; then
-  X=$ROOT/tools/experimental/csrc
-  for f in $ROOT/openpcseg_amd/csrc/conv.hip $ROOT/openpcseg_amd/csrc/conv_wave5h.hip $X/conv_ring6h.hip $X/conv_ring6f.hip; do
-    extra=""; case $(basename $f) in conv_wave5*.hip|conv_ring6*.hip) extra="-fno-slp-vectorize";; esac
-    $CC $extra -DPCS_WITH_RING=1 -I$ROOT/openpcseg_amd/csrc -I$X "$@" -c $f -o /tmp/pcsvar_$name/$(basename $f).o &
-  done
-  wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/pcsvar_$name/*.o \
-    $(ls $ROOT/openpcseg_amd/lib/*.hip.o | grep -v "/conv.hip.o\|/conv_wave5h.hip.o") -o $ROOT/openpcseg_amd/lib/dbg/$name.so
-else
-  for f in $ROOT/openpcseg_amd/csrc/conv*.hip; do
-    extra=""; case $(basename $f) in conv_wave5*.hip) extra="-fno-slp-vectorize";; esac  # as openpcseg_amd/build.py EXTRA_FLAGS
-    $CC $extra "$@" -c $f -o /tmp/pcsvar_$name/$(basename $f).o &
-  done
-  wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/pcsvar_$name/*.o \
-    $(ls $ROOT/openpcseg_amd/lib/*.hip.o | grep -v "/conv") -o $ROOT/openpcseg_amd/lib/dbg/$name.so
-fi
+for f in $ROOT/openpcseg_amd/csrc/conv*.hip; do
+  extra=""; case $(basename $f) in conv_wave5*.hip) extra="-fno-slp-vectorize";; esac  # as openpcseg_amd/build.py EXTRA_FLAGS
+  $CC $extra "$@" -c $f -o /tmp/pcsvar_$name/$(basename $f).o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/pcsvar_$name/*.o \
+  $(ls $ROOT/openpcseg_amd/lib/*.hip.o | grep -v "/conv") -o $ROOT/openpcseg_amd/lib/dbg/$name.so
 echo $ROOT/openpcseg_amd/lib/dbg/$name.so

@@ -19,7 +19,8 @@ def main():
     reps = int(os.environ.get("PCS_SWEEP_REPS", "100"))
     dev = torch.device("cuda:0")
     coords = make_batch(list(range(frames)))["lidar"].C.to(dev)
-    coords = coords[torch.argsort(F.sphash(coords))].contiguous()
+    if os.environ.get("PCS_SWEEP_SORT0", "hash") == "hash":   # "ravel": level 0 as the input pipeline delivers it
+        coords = coords[torch.argsort(F.sphash(coords))].contiguous()
     levels, ts = [coords], 1
     for _ in range(4):
         levels.append(F.spdownsample(levels[-1], 2, 2, ts))
