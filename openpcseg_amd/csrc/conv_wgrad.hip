@@ -786,14 +786,16 @@ int launch_wgrad3_thin(const Wgrad3Args &w, int ns, hipStream_t st) {
   return PCS_EINVAL;
 }
 
-int wgrad_plan(const int32_t *koff_host, int K, int ca, int cb, int *pch_out, bool thin = false) {
+int wgrad_plan(const int32_t *koff_host, int K, int ca, int cb, int *pch_out, bool thin = false, bool half = false) {
   // workgroup = 4 output blocks of one split; >= 64 pairs per split
   const int nbq = (wg_ngroups(ca) * wg_ngroups(cb) + 3) / 4;
   int64_t P = koff_host[K] - koff_host[0];
   // measured per shape (tools/conv_microbench.py): ~3072 workgroups when an offset's weight block needs >= 4 of them
   // (256-channel layers), ~1536 otherwise (64..128 channels: +2..16 %; fewer, longer splits = less partial traffic)
   static const int tgt_env = getenv("PCS_WGRAD_TARGET") ? atoi(getenv("PCS_WGRAD_TARGET")) : 0;  // debug: workgroups per launch
-  int64_t target = (tgt_env > 0 ? tgt_env : (nbq >= 4 ? 3072 : 1536)) / nbq;
+  // [r6] 16-bit operands on the 256-channel layers: ~2048 (profiles/round6_wgrad_target_sweep.txt: 256 x 256 0.289 -> 0.248 ms at
+  // stride 8, 0.144 -> 0.121 ms at stride 16 -- the kernel is 3x shorter than the fp32 one, the partial sums weigh more)
+  int64_t target = (tgt_env > 0 ? tgt_env : (nbq >= 4 ? (half ? 2048 : 3072) : 1536)) / nbq;
   if (thin) target *= 4;   // one-wave workgroups: as many waves in flight as the four-wave form
   if (target < K) target = K;
   int pch = (int)ceil_div(P > 0 ? P : 1, target);
@@ -816,6 +818,8 @@ extern "C" size_t pcs_conv_wgrad_ws_bytes(const int32_t *koff_host, int32_t K, i
     const int ns_thin = wgrad_plan(koff_host, K, ca, cb, &pch, true);
     ns = ns_thin > ns ? ns_thin : ns;
   }
+  const int ns_half = wgrad_plan(koff_host, K, ca, cb, &pch, false, true);
+  ns = ns_half > ns ? ns_half : ns;
   return (size_t)(ns > 0 ? ns : 1) * ca * cb * sizeof(float);
 }
 
@@ -836,7 +840,7 @@ static int conv_wgrad_any(const void *fa_v, int32_t ca, const void *fb_v, int32_
   int pch;
   static const int use3_thin = getenv("PCS_WGRAD3") ? atoi(getenv("PCS_WGRAD3")) : 1;
   const bool thin = use3_thin >= 1 && wgrad3_thin(ca, cb, dtype) && (((uintptr_t)fa_v | (uintptr_t)fb_v) & 15) == 0;
-  const int ns = wgrad_plan(koff_host, K, ca, cb, &pch, thin);
+  const int ns = wgrad_plan(koff_host, K, ca, cb, &pch, thin, dtype != 0);
   const int64_t cc = (int64_t)ca * cb;
   if (ns == 0) {
     if (hipMemsetAsync(gW, 0, (size_t)K * cc * 4, st) != hipSuccess) { set_error("pcs_conv_wgrad_f32: memset failed"); return PCS_ELAUNCH; }
