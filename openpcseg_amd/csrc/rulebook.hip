@@ -236,14 +236,19 @@ __global__ void __launch_bounds__(256) rb_segments_kernel(const int32_t *__restr
   }
 }
 
-// Heaviest-first order of the row tiles of one segment table: work(t) = 16-row blocks of tile t over all offsets (what
+// Launch order of the row tiles of one segment table: heaviest first, work(t) = 16-row blocks of tile t over all offsets (what
 // the fused convolution issues MFMAs for). One workgroup: per-tile work (coalesced over the tiles of one offset, summed
-// with LDS atomics), histogram of the work values, descending prefix, scatter. The order among equally heavy tiles is
-// arbitrary -- it only decides which workgroup slot runs which tile, never a sum.
+// with LDS atomics), then a counting sort by work (histogram, descending prefix, scatter). The order among equally heavy
+// tiles is arbitrary -- it only decides which workgroup slot runs which tile, never a sum.
+// xcd != 0 [r6]: the conv kernels run launch position p on XCD p % 8 (conv_wave5.hip: slot mapping). Every XCD gets one
+// CONTIGUOUS eighth of the tiles (lengths differ by at most one, so position j * 8 + c is the j-th tile of eighth c) and walks it
+// heaviest first: the tiles in flight on an XCD still come from one stretch of rows and share its L2 -- measured
+// (profiles/round6_conv_xcd_order_ab2.txt, round6_conv_order_traffic2.txt): the speed of the chip-wide heaviest-first order
+// (+4-8 % over row order on the dense levels) with 11-33 % less HBM read traffic.
 constexpr int kOrderBins = 2048;    // work <= K * (tile_rows / 16 + 1) <= 32 * 33
 constexpr int kOrderTiles = 12288;  // tiles whose work fits the LDS (48 KB); more: the work is recomputed per pass
 __global__ void __launch_bounds__(1024) rb_tile_order_kernel(const int32_t *__restrict__ seg, int K, int64_t ntiles,
-                                                             int32_t *__restrict__ order) {
+                                                             int32_t *__restrict__ order, int xcd) {
   __shared__ int hist[kOrderBins];
   __shared__ int base[kOrderBins];
   __shared__ int work_l[kOrderTiles];
@@ -260,7 +265,6 @@ __global__ void __launch_bounds__(1024) rb_tile_order_kernel(const int32_t *__re
     }
     return clampw(w);
   };
-  for (int i = tid; i < kOrderBins; i += 1024) hist[i] = 0;
   if (in_lds) {
     for (int i = tid; i < (int)ntiles; i += 1024) work_l[i] = 0;
     __syncthreads();
@@ -273,30 +277,37 @@ __global__ void __launch_bounds__(1024) rb_tile_order_kernel(const int32_t *__re
       if (nb) atomicAdd(&work_l[t], nb);
     }
   }
-  __syncthreads();
-  for (int64_t t = tid; t < ntiles; t += 1024) atomicAdd(&hist[in_lds ? clampw(work_l[t]) : work_of(t)], 1);
-  __syncthreads();
-  // base[w] = number of tiles heavier than w: two bins per thread, scanned from the heavy end
-  {
-    const int b0 = kOrderBins - 1 - 2 * tid, b1 = b0 - 1;  // this thread's bins, heavy first
-    const int h0 = hist[b0], h1 = hist[b1];
-    int incl = h0 + h1;
-    const int lane = tid & 63, wid = tid >> 6;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += v;
-    }
-    if (lane == 63) wsum[wid] = incl;
+  const int nparts = xcd ? 8 : 1;
+  const int64_t q = ntiles / nparts, r = ntiles % nparts;
+  for (int c = 0; c < nparts; ++c) {  // one counting sort per part: tiles [lo, lo + ln) -> positions j * nparts + c
+    const int64_t lo = c * q + (c < r ? c : r), ln = q + (c < r ? 1 : 0);
     __syncthreads();
-    int off = 0;
-    for (int w = 0; w < wid; ++w) off += wsum[w];
-    const int excl = off + incl - (h0 + h1);
-    base[b0] = excl;
-    base[b1] = excl + h0;
+    for (int i = tid; i < kOrderBins; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int64_t t = lo + tid; t < lo + ln; t += 1024) atomicAdd(&hist[in_lds ? clampw(work_l[t]) : work_of(t)], 1);
+    __syncthreads();
+    // base[w] = number of tiles heavier than w: two bins per thread, scanned from the heavy end
+    {
+      const int b0 = kOrderBins - 1 - 2 * tid, b1 = b0 - 1;  // this thread's bins, heavy first
+      const int h0 = hist[b0], h1 = hist[b1];
+      int incl = h0 + h1;
+      const int lane = tid & 63, wid = tid >> 6;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63) wsum[wid] = incl;
+      __syncthreads();
+      int off = 0;
+      for (int w = 0; w < wid; ++w) off += wsum[w];
+      const int excl = off + incl - (h0 + h1);
+      base[b0] = excl;
+      base[b1] = excl + h0;
+    }
+    __syncthreads();
+    for (int64_t t = lo + tid; t < lo + ln; t += 1024)
+      order[(int64_t)atomicAdd(&base[in_lds ? clampw(work_l[t]) : work_of(t)], 1) * nparts + c] = (int32_t)t;
   }
-  __syncthreads();
-  for (int64_t t = tid; t < ntiles; t += 1024)
-    order[atomicAdd(&base[in_lds ? clampw(work_l[t]) : work_of(t)], 1)] = (int32_t)t;
 }
 
 struct RbWs {
@@ -432,6 +443,8 @@ extern "C" int pcs_rulebook_tile_order(const int32_t *seg, int32_t K, int64_t nt
   if (K <= 0 || K > 32 || ntiles < 0 || ntiles > 0x7FFFFFFF) { set_error("pcs_rulebook_tile_order: bad sizes"); return PCS_EINVAL; }
   if (ntiles == 0) return PCS_OK;
   if (!seg || !order) { set_error("pcs_rulebook_tile_order: null pointer"); return PCS_EINVAL; }
-  hipLaunchKernelGGL(rb_tile_order_kernel, dim3(1), dim3(1024), 0, as_stream(stream), seg, (int)K, ntiles, order);
+  // PCS_TILE_ORDER_XCD=0: the chip-wide heaviest-first order of rounds 2-5 (A/B)
+  static const int xcd = getenv("PCS_TILE_ORDER_XCD") ? atoi(getenv("PCS_TILE_ORDER_XCD")) : 1;
+  hipLaunchKernelGGL(rb_tile_order_kernel, dim3(1), dim3(1024), 0, as_stream(stream), seg, (int)K, ntiles, order, xcd);
   return check_launch("pcs_rulebook_tile_order");
 }

@@ -551,12 +551,11 @@ class HipBackend:
 
     @staticmethod
     def _wants_order(kmap):
-        """The heaviest-first order pays wherever the work of the tiles differs: +4..8 % per launch on the dense levels,
-        +2..5 % on the full-resolution levels in the order the input pipeline delivers them (ascending ravel hash: tiles
-        of dense and of sparse regions; profiles/round6_conv_xcd_order_ab.txt), nothing on rows in hash order (all tiles
-        alike). Its own kernel is ~15-40 us per map and tile height; below 4 pairs per row (k = 2 maps, 1-D / 2-D
-        kernels) the launches keep the row order."""
-        return kmap.n_dst > 0 and kmap.num_pairs_estimate() >= 4.0 * kmap.n_dst
+        """The heaviest-first order (per XCD: csrc/rulebook.hip) pays where workgroups are long and few: the dense levels
+        (>= 6 pairs per row: +4..8 % per launch). On the full-resolution levels it is +2..5 % but costs 1.3-1.6x the HBM
+        reads of the XCD-contiguous row order (profiles/round6_conv_xcd_order_ab2.txt, round6_conv_order_traffic2.txt):
+        those launches keep the row order."""
+        return kmap.n_dst > 0 and kmap.num_pairs_estimate() >= 6.0 * kmap.n_dst
 
     def _tile_order(self, kmap, tile_rows):
         """Heaviest-first order of the row tiles of (kmap, tile_rows), cached beside the segment table it is made from

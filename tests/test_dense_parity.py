@@ -111,7 +111,8 @@ def test_conv_forward_dense_map(hip, levels, stride, cin, cout, tile):
 
 @pytest.mark.parametrize("stride,tile", [(1, 384), (2, 128), (4, 224), (8, 288), (8, 112)])
 def test_tile_order_heaviest_first(hip, levels, stride, tile):
-    """pcs_rulebook_tile_order: a permutation of the row tiles, work (16-row blocks over all offsets) non-increasing."""
+    """pcs_rulebook_tile_order: a permutation of the row tiles; the slots of XCD c (launch position % 8 == c) hold exactly the c-th
+    contiguous eighth of the tiles (lengths differ by at most one), work (16-row blocks over all offsets) non-increasing inside it."""
     entry = level_map(levels, stride)[0]
     km = entry.fwd
     seg = hip._segments(km, tile).view(27, -1).cpu().numpy().astype(np.int64)
@@ -119,8 +120,13 @@ def test_tile_order_heaviest_first(hip, levels, stride, tile):
     ntiles = (km.n_dst + tile - 1) // tile
     assert order.shape == (ntiles,) and np.array_equal(np.sort(order), np.arange(ntiles))
     work = ((seg[:, 1:] - seg[:, :-1] + 15) // 16).sum(0)
-    w = work[order]
-    assert (w[:-1] >= w[1:]).all() and w[0] == work.max()
+    q, r = divmod(ntiles, 8)
+    for c in range(8):
+        lo, ln = c * q + min(c, r), q + (1 if c < r else 0)
+        mine = order[c::8]
+        assert np.array_equal(np.sort(mine), np.arange(lo, lo + ln))
+        w = work[mine]
+        assert (w[:-1] >= w[1:]).all() and (ln == 0 or w[0] == work[lo:lo + ln].max())
 
 
 @pytest.mark.parametrize("stride,cin,cout,tile", [(4, 128, 128, None), (8, 256, 256, None), (1, 96, 96, 384), (2, 64, 64, 128)])

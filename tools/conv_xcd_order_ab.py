@@ -61,8 +61,30 @@ def main():
         # heaviest first inside each contiguous eighth: stable partition of the heavy order by chunk id
         part = torch.cat([heavy[(heavy // chunk) == k] for k in range(8)])
         orders = {"rows": None, "heavy": heavy, "xcd": xcd_contiguous(rows), "xcdheavy": xcd_contiguous(part)}
+        # xb<BS>: contiguous eighths (balanced lengths), inside each the blocks of BS consecutive tiles heaviest block first, row
+        # order inside a block (the tiles in flight on an XCD stay neighbours, the light ones still come last)
+        seg = be._segments(kmap, t).view(kmap.K, ntiles + 1).long()
+        work = ((seg[:, 1:] - seg[:, :-1] + 15) // 16).sum(0)
+        q, r = divmod(ntiles, 8)
+        for bs in (16, 32, 64):
+            seqs = []
+            for c in range(8):
+                lo, ln = c * q + min(c, r), q + (1 if c < r else 0)
+                tl = torch.arange(lo, lo + ln, device=dev)
+                nb = (ln + bs - 1) // bs
+                bw = torch.zeros(max(nb, 1), dtype=torch.long, device=dev).index_add_(0, (tl - lo) // bs, work[lo:lo + ln])
+                rank = torch.argsort(torch.argsort(-bw[:nb], stable=True), stable=True)      # block -> place
+                key = rank[(tl - lo) // bs] * bs + (tl - lo) % bs
+                seqs.append(tl[torch.argsort(key, stable=True)])
+            out = torch.full((8 * (q + 1),), -1, dtype=torch.long, device=dev)
+            for c in range(8):
+                out[c:c + 8 * seqs[c].numel():8] = seqs[c]
+            orders["xb%d" % bs] = out[out >= 0].to(torch.int32)
         ref, base = None, None
+        only = os.environ.get("PCS_AB_ONLY")   # one order only (counter runs: every conv launch of the process is that order)
         for name, order in orders.items():
+            if only and name != only:
+                continue
             if order is None:
                 kw = dict(ordered=False)
             else:
