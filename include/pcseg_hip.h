@@ -34,7 +34,7 @@ extern "C" {
 #define PCS_ELAUNCH (-3)  /* hipLaunch / hipMemsetAsync failed (pcs_last_error has text) */
 #define PCS_EUNSUPPORTED (-4)
 
-#define PCS_ABI_VERSION 10
+#define PCS_ABI_VERSION 11
 
 int pcs_abi_version(void);
 const char *pcs_last_error(void);
@@ -139,7 +139,7 @@ int pcs_ti_weights_f32(const float *coords, int32_t coord_ld, const int64_t *idx
  * coordinate truncated toward zero to a multiple of sample_stride[d]. mode 1 = general
  * branch (downsample.py:29-45): n*K keys for coords+offsets[k]; rows that fail
  * `% sample_stride == 0` or `>= coords_min` get the key INT64_MAX (sorts last).
- * Step 2: the caller sorts/uniques the keys. Step 3: pcs_downsample_unpack.
+ * Step 2: pcs_sort_unique_i64 (v11; or any ascending sort + unique of the caller's). Step 3: pcs_downsample_unpack.
  * *err (device int32, caller-zeroed) is set to 1 if a coordinate does not fit the packing
  * (|x|,|y|,|z| >= 2^17 or batch outside [0, 511]).
  * sample_stride3 is a HOST pointer (three small positive ints); offsets / coords_min3 are
@@ -149,6 +149,14 @@ int pcs_downsample_pack(const int32_t *coords, int64_t n, const int32_t *sample_
                         int32_t mode, const int32_t *offsets, int32_t K,
                         const int32_t *coords_min3, int64_t *keys, int32_t *err, void *stream);
 int pcs_downsample_unpack(const int64_t *keys, int64_t m, int32_t *coords, void *stream);
+/* Step 2 of spdownsample [v11]: out[0 .. m) = the distinct keys in ascending (signed) order -- what the reference's
+ * `torch.unique(coords, dim=0)` (downsample.py:47-51) yields on the packed rows. info (device int64[3]) receives everything the
+ * host has to read back in one record: info[0] = m, info[1] = the largest key (INT64_MIN when m = 0; INT64_MAX = the general
+ * branch's "rejected candidate" sentinel is present and is the last key), info[2] = *err_flag (0 when err_flag is NULL).
+ * out holds n keys; ws / ws_bytes from pcs_sort_unique_ws_bytes(n) (never allocates; PCS_EWORKSPACE when too small). */
+size_t pcs_sort_unique_ws_bytes(int64_t n);
+int pcs_sort_unique_i64(const int64_t *keys, int64_t n, int64_t *out, int64_t *info, const int32_t *err_flag, void *ws,
+                        size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Rulebook (kernel map)  TS:torchsparse/nn/functional/conv.py:156-176

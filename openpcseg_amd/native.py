@@ -36,6 +36,8 @@ SIGNATURES = {
     "pcs_ti_weights_f32": (c_int32, [_P, c_int32, _P, c_int64, c_float, _P, _P]),
     "pcs_downsample_pack": (c_int32, [_P, c_int64, _P, c_int32, _P, c_int32, _P, _P, _P, _P]),
     "pcs_downsample_unpack": (c_int32, [_P, c_int64, _P, _P]),
+    "pcs_sort_unique_ws_bytes": (c_size_t, [c_int64]),
+    "pcs_sort_unique_i64": (c_int32, [_P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "pcs_rulebook_ws_bytes": (c_size_t, [c_int64, c_int32]),
     "pcs_rulebook_probe": (c_int32, [_P, c_int64, _P, c_int32, _P, c_int64, _P, _P, _P, c_size_t, c_int32, _P]),
     "pcs_rulebook_fill": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P]),
@@ -120,7 +122,7 @@ class _WeightJob(ctypes.Structure):   # pcs_weight_job of include/pcseg_hip.h
                 ("transpose", c_int32), ("nctt", c_int32), ("nt16", c_int32), ("ns", c_int32), ("first_block", c_int64)]
 
 
-ABI_VERSION = 10  # include/pcseg_hip.h PCS_ABI_VERSION (10: pcs_conv_gather_gemm_*_ex + pcs_conv_epilogue, pcs_bn_bwd_reduce_partials; 9: pcs_quantize_frame_keys; 8: sums2 size argument of pcs_bn_bwd_stats_*, ring switch removed; 7: pcs_lovasz_*; 6: ring kernel switch / query; 5: fp32 convolution on the bf16 MFMAs, pcs_conv_*_x3; 4: tile order)
+ABI_VERSION = 11  # include/pcseg_hip.h PCS_ABI_VERSION (11: pcs_sort_unique_i64; 10: pcs_conv_gather_gemm_*_ex + pcs_conv_epilogue, pcs_bn_bwd_reduce_partials; 9: pcs_quantize_frame_keys; 8: sums2 size argument of pcs_bn_bwd_stats_*, ring switch removed; 7: pcs_lovasz_*; 6: ring kernel switch / query; 5: fp32 convolution on the bf16 MFMAs, pcs_conv_*_x3; 4: tile order)
 _lib = None
 
 
@@ -465,6 +467,19 @@ class HipBackend:
         return w
 
     # -- spdownsample ---------------------------------------------------------------------------
+    def sort_unique(self, keys, err=None):
+        """Distinct int64 keys in ascending order (pcs_sort_unique_i64). Returns (buf, info): buf holds the info[0] distinct keys
+        at its front, info = device int64 [count, largest key, *err]; no host read here."""
+        keys = _dev(keys, "keys", torch.int64)
+        nk = keys.numel()
+        buf = torch.empty(nk, dtype=torch.int64, device=keys.device)
+        info = torch.empty(3, dtype=torch.int64, device=keys.device)
+        ws_bytes = self.lib.pcs_sort_unique_ws_bytes(nk)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=keys.device)
+        _check(self.lib.pcs_sort_unique_i64(_ptr(keys), nk, _ptr(buf), _ptr(info), _ptr(err) if err is not None else None, _ptr(ws),
+                                            ws_bytes, _stream()), "pcs_sort_unique_i64")
+        return buf, info
+
     def downsample(self, coords, sample_stride, offsets=None, coords_min=None):
         """Unique, (b,x,y,z)-sorted output coordinates. offsets=None -> fast branch."""
         coords = _dev(coords, "coords", torch.int32)
@@ -483,18 +498,17 @@ class HipBackend:
             rc = self.lib.pcs_downsample_pack(_ptr(coords), n, ss, 1, _ptr(offsets), k,
                                               _ptr(coords_min), _ptr(keys), _ptr(err), _stream())
         _check(rc, "pcs_downsample_pack")
-        uniq = torch.unique(keys)  # sorted ascending == reference's lexicographic (b,x,y,z); sizes its output on the host
-        # one host read for the two flags (the unique above already waited for the queue): range error, and whether the
-        # general branch left its "rejected candidate" sentinel at the end
-        if offsets is None or uniq.numel() == 0:
-            bad, has_sentinel = bool(err.item()), False
-        else:
-            bad, has_sentinel = torch.stack([err[0] != 0, uniq[-1] == 0x7FFFFFFFFFFFFFFF]).tolist()
+        # sorted distinct keys == the reference's lexicographic (b,x,y,z) unique rows (pcs_sort_unique_i64). ONE host read per
+        # call -- the count that sizes the output, the largest key (the general branch's "rejected candidate" sentinel sorts
+        # last) and the range error flag in one pinned record (torch.unique + the flag read were two round trips)
+        buf, info = self.sort_unique(keys, err)
+        m, last, bad = info.tolist()
         if bad:
             raise RuntimeError("openpcseg_amd: spdownsample coordinate out of the packed range "
                                "(|x|,|y|,|z| < 2^17, 0 <= batch < 512)")
-        if offsets is not None and has_sentinel:
-            uniq = uniq[:-1]
+        if offsets is not None and m > 0 and last == 0x7FFFFFFFFFFFFFFF:
+            m -= 1
+        uniq = buf[:m]
         m = uniq.numel()
         out = torch.empty((m, 4), dtype=torch.int32, device=coords.device)
         _check(self.lib.pcs_downsample_unpack(_ptr(uniq), m, _ptr(out), _stream()), "pcs_downsample_unpack")

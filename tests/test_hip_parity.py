@@ -139,6 +139,32 @@ def test_downsample_random(hip):
         assert (F.spdownsample(t(cc), *args).cpu().numpy() == orc.spdownsample(cc, *args)).all()
 
 
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 4097, 300000, 2500000])
+def test_sort_unique_keys(hip, n):
+    """pcs_sort_unique_i64 (step 2 of spdownsample, TS:torchsparse/nn/functional/downsample.py:47-51): the distinct keys in
+    ascending SIGNED order = numpy's unique, the one-record read-back (count, largest key, error flag), duplicates of every
+    multiplicity, negative keys, the INT64_MAX sentinel, empty and one-element inputs; the size query is what the call checks."""
+    rng = np.random.default_rng(n + 5)
+    keys = rng.integers(-(1 << 62), 1 << 62, size=n, dtype=np.int64)
+    if n > 2:
+        keys[rng.integers(0, n, size=n // 2)] = keys[rng.integers(0, n, size=n // 2)]   # duplicates
+        keys[rng.integers(0, n, size=max(n // 50, 1))] = np.iinfo(np.int64).max          # the sentinel, many times
+        keys[rng.integers(0, n, size=max(n // 70, 1))] = rng.integers(-5, 5, size=max(n // 70, 1))
+    ref = np.unique(keys)
+    err = torch.full((1,), 7, dtype=torch.int32, device=DEV)
+    buf, info = hip.sort_unique(t(keys), err)
+    m, last, flag = info.tolist()
+    assert m == ref.size and flag == 7
+    assert last == (int(ref[-1]) if ref.size else np.iinfo(np.int64).min)
+    assert (buf[:m].cpu().numpy() == ref).all()
+    buf2, info2 = hip.sort_unique(t(keys))
+    assert info2.tolist() == [m, last, 0] and torch.equal(buf2[:m], buf[:m])
+    if n > 0:
+        ws = torch.empty(64, dtype=torch.uint8, device=DEV)
+        rc = hip.lib.pcs_sort_unique_i64(t(keys).data_ptr(), n, buf.data_ptr(), info.data_ptr(), None, ws.data_ptr(), 64, None)
+        assert rc != 0 and hip.lib.pcs_sort_unique_ws_bytes(n) > 64 and b"workspace" in hip.lib.pcs_last_error()
+
+
 @pytest.mark.parametrize("name,ks,in_stride", [("k3s1", 3, 1), ("k2s2", 2, 1), ("k133", (1, 3, 3), 1),
                                                 ("k313", (3, 1, 3), 1), ("k3s2", 3, 1), ("k3s221", 3, 1)])
 def test_kmap_golden(hip, golden, name, ks, in_stride):

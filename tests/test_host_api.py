@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = native.load_library()  # dlopen works without a GPU
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pcs_abi_version() == native.ABI_VERSION == 10
+    assert lib.pcs_abi_version() == native.ABI_VERSION == 11
     assert lib.pcs_hashtable_capacity(1000) == 2048
     assert lib.pcs_hashtable_bytes(2048) == 2048 * 12
     assert lib.pcs_conv_tile_rows(32, 32) in (64, 128)
