@@ -189,12 +189,11 @@ int pcs_rulebook_fill(const int32_t *results, int64_t nq, int32_t K, const void 
 int pcs_rulebook_tile_segments(const int32_t *pairs, const int32_t *koff, int32_t K,
                                int64_t n_dst, int32_t tile_rows, int32_t dst_col,
                                int32_t *seg, void *stream);
-/* Launch order of the row tiles of a segment table, heaviest first (work of a tile = its 16-row MFMA blocks over all
+/* Heaviest-first order of the row tiles of a segment table (work of a tile = its 16-row MFMA blocks over all
  * offsets): order[i] = the tile the i-th workgroup slot of the fused convolution runs. Workgroups are dispatched in
- * index order, so the light tiles run last and the launch drains evenly (+4..8 % on the deep levels). Since round 6 the
- * slots of one XCD (i % 8) walk one contiguous eighth of the tiles, heaviest first inside it: same speed, 11-33 % less
- * HBM read traffic than the chip-wide order (PCS_TILE_ORDER_XCD=0). The order among equally heavy tiles is
- * unspecified; results never depend on the order. */
+ * index order, so the light tiles run last and the launch drains evenly (+4..8 % on the deep levels). The order among
+ * equally heavy tiles is unspecified; results never depend on the order. (PCS_TILE_ORDER_XCD=1, measured and not the
+ * default: the slots of one XCD (i % 8) walk one contiguous eighth of the tiles, heaviest first inside it.) */
 int pcs_rulebook_tile_order(const int32_t *seg, int32_t K, int64_t ntiles, int32_t *order, void *stream);
 
 /* ------------------------------------------------------------------------------------------

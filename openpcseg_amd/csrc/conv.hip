@@ -56,7 +56,7 @@ extern "C" int pcs_transpose_kab_f32(const float *src, int32_t K, int32_t A, int
 
 // Bumped whenever a fused-conv kernel, its launch shape picker or its epilogue changes: measurements keyed to kernels
 // (profiles/*_conv_traffic.json) carry the revision they were taken on and bench.py refuses a stale one.
-extern "C" const char *pcs_conv_kernel_revision(void) { return "r6.1"; }
+extern "C" const char *pcs_conv_kernel_revision(void) { return "r6.0"; }
 
 extern "C" int32_t pcs_conv_tile_rows(int32_t cin, int32_t cout) {
   (void)cin;

@@ -240,11 +240,13 @@ __global__ void __launch_bounds__(256) rb_segments_kernel(const int32_t *__restr
 // the fused convolution issues MFMAs for). One workgroup: per-tile work (coalesced over the tiles of one offset, summed
 // with LDS atomics), then a counting sort by work (histogram, descending prefix, scatter). The order among equally heavy
 // tiles is arbitrary -- it only decides which workgroup slot runs which tile, never a sum.
-// xcd != 0 [r6]: the conv kernels run launch position p on XCD p % 8 (conv_wave5.hip: slot mapping). Every XCD gets one
-// CONTIGUOUS eighth of the tiles (lengths differ by at most one, so position j * 8 + c is the j-th tile of eighth c) and walks it
-// heaviest first: the tiles in flight on an XCD still come from one stretch of rows and share its L2 -- measured
-// (profiles/round6_conv_xcd_order_ab2.txt, round6_conv_order_traffic2.txt): the speed of the chip-wide heaviest-first order
-// (+4-8 % over row order on the dense levels) with 11-33 % less HBM read traffic.
+// xcd != 0 [r6, opt-in: PCS_TILE_ORDER_XCD=1]: the conv kernels run launch position p on XCD p % 8 (conv_wave5.hip: slot mapping).
+// Every XCD gets one CONTIGUOUS eighth of the tiles (lengths differ by at most one, so position j * 8 + c is the j-th tile of
+// eighth c) and walks it heaviest first: the tiles in flight on an XCD still come from one stretch of rows and share its L2.
+// Measured (profiles/round6_conv_xcd_order_ab2.txt, round6_conv_order_traffic2.txt, round6_order_bench_ab.txt): per launch the
+// speed of the chip-wide order (+4-8 % over row order on the dense levels) with 11-33 % less HBM read traffic; over a whole
+// training step 0.6 % (fp32) / 0.9 % (bf16) SLOWER than the chip-wide order, twice out of twice, and the step's conv traffic only
+// 1-3 % lower (the full-resolution levels, in row order either way, carry most of it) -> not the default.
 constexpr int kOrderBins = 2048;    // work <= K * (tile_rows / 16 + 1) <= 32 * 33
 constexpr int kOrderTiles = 12288;  // tiles whose work fits the LDS (48 KB); more: the work is recomputed per pass
 __global__ void __launch_bounds__(1024) rb_tile_order_kernel(const int32_t *__restrict__ seg, int K, int64_t ntiles,
@@ -443,8 +445,9 @@ extern "C" int pcs_rulebook_tile_order(const int32_t *seg, int32_t K, int64_t nt
   if (K <= 0 || K > 32 || ntiles < 0 || ntiles > 0x7FFFFFFF) { set_error("pcs_rulebook_tile_order: bad sizes"); return PCS_EINVAL; }
   if (ntiles == 0) return PCS_OK;
   if (!seg || !order) { set_error("pcs_rulebook_tile_order: null pointer"); return PCS_EINVAL; }
-  // PCS_TILE_ORDER_XCD=0: the chip-wide heaviest-first order of rounds 2-5 (A/B)
-  static const int xcd = getenv("PCS_TILE_ORDER_XCD") ? atoi(getenv("PCS_TILE_ORDER_XCD")) : 1;
+  // PCS_TILE_ORDER_XCD=1: heaviest first inside each XCD's contiguous eighth instead of chip-wide (see the kernel's comment:
+  // equal per launch, 0.6-0.9 % slower over a training step, 11-33 % fewer HBM reads on the launches it applies to)
+  static const int xcd = getenv("PCS_TILE_ORDER_XCD") ? atoi(getenv("PCS_TILE_ORDER_XCD")) : 0;
   hipLaunchKernelGGL(rb_tile_order_kernel, dim3(1), dim3(1024), 0, as_stream(stream), seg, (int)K, ntiles, order, xcd);
   return check_launch("pcs_rulebook_tile_order");
 }
