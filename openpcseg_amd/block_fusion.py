@@ -566,6 +566,28 @@ def _fuse_glue(model):
     return n
 
 
+def _prebuild_encoder(model, x0):
+    """functional.prebuild_coords for the reference's encoder layout: stage1..stage4, each opened by a strided, non-transposed
+    Conv3d (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:233-262) whose own stride / kernel size are read here. Any other
+    layout: nothing is prebuilt. The coordinates are the ones those convolutions would compute themselves (same call, same dict)."""
+    steps = model.__dict__.get("_pcs_enc_steps")
+    if steps is None:
+        from .modules import Conv3d
+        steps = []
+        for name in ("stage1", "stage2", "stage3", "stage4"):
+            st = getattr(model, name, None)
+            conv = next((m for m in st.modules() if isinstance(m, Conv3d)), None) if isinstance(st, nn.Module) else None
+            if conv is None or conv.transposed or all(int(v) == 1 for v in conv.stride):
+                steps = []
+                break
+            steps.append((tuple(conv.stride), tuple(conv.kernel_size)))
+        model.__dict__["_pcs_enc_steps"] = steps
+    if steps and os.environ.get("PCS_PREBUILD_LEVELS", "1") != "0":
+        from . import functional as F
+        F.prebuild_coords(x0, steps)
+    return x0
+
+
 def _minkunet_forward(self, batch_dict, return_logit=False, return_tta=False):
     """Training-mode forward of the reference's MinkUNet (R:pcseg/model/segmentor/voxel/minkunet/minkunet.py:385-434) with the
     classifier commuted in front of the three trilinear interpolations; everything else line by line as the reference."""
@@ -579,7 +601,7 @@ def _minkunet_forward(self, batch_dict, return_logit=False, return_tta=False):
         return self.__dict__["_pcs_orig_class"].forward(self, batch_dict, return_logit, return_tta)
     x.F = x.F[:, :self.in_feature_dim]
     z = ts.PointTensor(x.F, x.C.float())
-    x0 = initial_voxelize(z, self.pres, self.vres)
+    x0 = _prebuild_encoder(self, initial_voxelize(z, self.pres, self.vres))
     x0 = self.stem(x0)
     z0 = voxel_to_point(x0, z, nearest=False)
     x1 = self.stage1(x0)
@@ -632,7 +654,7 @@ def _spvcnn_forward(self, batch_dict, return_logit=False, return_tta=False):
         return self.__dict__["_pcs_orig_class"].forward(self, batch_dict, return_logit, return_tta)
     x.F = x.F[:, :self.in_feature_dim]
     z = ts.PointTensor(x.F, x.C.float())
-    x0 = initial_voxelize(z, self.pres, self.vres)
+    x0 = _prebuild_encoder(self, initial_voxelize(z, self.pres, self.vres))
     x0 = self.stem(x0)
     z0 = voxel_to_point(x0, z, nearest=False)
     x1 = point_to_voxel(x0, z0)

@@ -26,7 +26,7 @@ from . import native
 from .sparse import SparseTensor, get_kernel_offsets, make_ntuple
 
 __all__ = ["sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize", "calc_ti_weights",
-           "spdownsample", "conv3d", "relu", "leaky_relu"]
+           "spdownsample", "prebuild_coords", "conv3d", "relu", "leaky_relu"]
 
 
 def _be():
@@ -566,6 +566,27 @@ def _sparse_conv(feats, weight, entry, transposed, bn_stats, with_skip=False, ac
     sums = outs[1] if bn_stats else None
     res = (out, (sums if sums is not None and sums.numel() else None))
     return res + (outs[-1],) if with_skip else res
+
+
+def prebuild_coords(x, steps):
+    """Output coordinates of the strided convolutions a network is KNOWN to apply to x's coordinate set, in order -- steps =
+    [(stride, kernel_size), ...] -- computed now and left in x.cmaps, where conv3d finds them (the same dict entry the first
+    strided convolution of each level would have made: TS:torchsparse/nn/functional/conv.py:156-164). Every spdownsample ends in
+    a host read of its output size; issued lazily those reads sit between the encoder stages, each one draining the launch queue
+    the host had built up. Up front they cost the same device work and leave the rest of forward + backward without a read."""
+    coords, ts = x.coords, make_ntuple(x.stride, ndim=3)
+    for stride, kernel_size in steps:
+        stride, kernel_size = make_ntuple(stride, ndim=3), make_ntuple(kernel_size, ndim=3)
+        out_stride = tuple(ts[k] * stride[k] for k in range(3))
+        if out_stride in x.cmaps:
+            coords = x.cmaps[out_stride]
+        elif all(s == 1 for s in stride):
+            pass
+        else:
+            coords = spdownsample(coords, stride, kernel_size, ts)
+            x.cmaps[out_stride] = coords
+        ts = out_stride
+    return x
 
 
 def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transposed=False, bn_stats=False, with_skip=False,

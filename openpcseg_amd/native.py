@@ -565,10 +565,10 @@ class HipBackend:
 
     @staticmethod
     def _wants_order(kmap):
-        """The heaviest-first order pays where workgroups are long and few: the dense levels (>= 6 pairs per row: +4..8 %
-        per launch). On the full-resolution levels it is +2..5 % per launch but costs 1.3-2.3x the HBM reads of the
-        XCD-contiguous row order (profiles/round6_conv_xcd_order_ab2.txt, round6_conv_order_traffic2.txt): those launches
-        keep the row order."""
+        """The heaviest-first order pays where workgroups are long and few and differ in work: the dense, coordinate-ordered
+        levels (>= 6 pairs per row: +4..8 % per launch). The stride-1 level is in hash order inside the network (all tiles
+        alike: +-1 %), the stride-2 level would gain 4 % for 2.3x the HBM reads of the XCD-contiguous row order
+        (profiles/round6_conv_xcd_order_ab2.txt, round6_conv_order_traffic2.txt): those launches keep the row order."""
         return kmap.n_dst > 0 and kmap.num_pairs_estimate() >= 6.0 * kmap.n_dst
 
     def _tile_order(self, kmap, tile_rows):

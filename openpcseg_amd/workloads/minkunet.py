@@ -12,6 +12,7 @@ import os
 import torch
 from torch import nn
 
+from .. import functional as F
 from .. import modules as spnn
 from ..fused import FusedBatchNorm, FusedLinear
 from ..sparse import PointTensor, cat, fapply
@@ -49,6 +50,7 @@ def _link(conv, bn):
 
 
 CAT_FUSED = os.environ.get("PCS_CAT_FUSED", "1") != "0"  # decoder concat written by the BN apply pass
+PREBUILD = os.environ.get("PCS_PREBUILD_LEVELS", "1") != "0"   # all levels' coordinates at the start of forward [r6]
 SKIP_FUSED = os.environ.get("PCS_SKIP_FUSED", "1") != "0"  # residual-block skip gradient added in the dgrad write-back [r6]
 
 
@@ -155,7 +157,10 @@ class MinkUNet(nn.Module):
             torch._foreach_add_([m.num_batches_tracked for m in self._bn_layers], 1)
         x.F = x.F[:, :self.in_dim]
         z = PointTensor(x.F, x.C.float())
-        x0 = self._stem(initial_voxelize(z, self.pres, self.vres))
+        xv = initial_voxelize(z, self.pres, self.vres)
+        if PREBUILD:   # the four stride-2 levels now: their size read-backs leave the encoder (functional.prebuild_coords)
+            F.prebuild_coords(xv, [(2, 2)] * 4)
+        x0 = self._stem(xv)
         z0 = voxel_to_point(x0, z)
         lin = self.classifier[0]
         # classifier(cat(devoxelize(x4), devoxelize(y2), devoxelize(y4))) with the linear map applied on the voxels first

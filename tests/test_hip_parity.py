@@ -139,6 +139,32 @@ def test_downsample_random(hip):
         assert (F.spdownsample(t(cc), *args).cpu().numpy() == orc.spdownsample(cc, *args)).all()
 
 
+def test_prebuild_coords_are_the_lazy_ones(hip):
+    """functional.prebuild_coords leaves in cmaps exactly what the strided convolutions would compute themselves (both
+    spdownsample branches: k2 s2 fast, k3 s2 general), so a network runs bit-identically with its levels built up front."""
+    from openpcseg_amd import functional as F
+    from openpcseg_amd.sparse import SparseTensor
+    rng = np.random.default_rng(11)
+    c = random_scene(rng, 30000, 70, 3)
+    feats = rng.normal(size=(c.shape[0], 8)).astype(np.float32)
+    ws = [t((rng.normal(size=(8, 8, 8)) * 0.1).astype(np.float32)), t((rng.normal(size=(27, 8, 8)) * 0.1).astype(np.float32)),
+          t((rng.normal(size=(8, 8, 8)) * 0.1).astype(np.float32))]
+    steps = [(2, 2), (2, 3), (2, 2)]
+
+    def run(prebuild):
+        x = SparseTensor(t(feats), t(c))
+        if prebuild:
+            F.prebuild_coords(x, steps)
+            assert sorted(x.cmaps) == [(2, 2, 2), (4, 4, 4), (8, 8, 8)]
+        for w, (s, k) in zip(ws, steps):
+            x = F.conv3d(x, w, k, stride=s)
+        return x
+
+    a, b = run(False), run(True)
+    assert sorted(a.cmaps) == sorted(b.cmaps) and all(torch.equal(a.cmaps[k], b.cmaps[k]) for k in a.cmaps)
+    assert torch.equal(a.C, b.C) and torch.equal(a.F, b.F)
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 4097, 300000, 2500000])
 def test_sort_unique_keys(hip, n):
     """pcs_sort_unique_i64 (step 2 of spdownsample, TS:torchsparse/nn/functional/downsample.py:47-51): the distinct keys in

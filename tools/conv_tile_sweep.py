@@ -67,7 +67,7 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / reps
             print("level=%d n=%d pairs=%d %d->%d tile=%s%s%s: %.0f us  %.1f TFLOP/s  (diff vs first %.1e)" %
-                  (level, n, p, cin, cout, tile or be.tile_rows(cin, cout, entry.fwd), "".join("+" + o for o in opts), (" " + spec.split()[4]) if half is not None else "", us,
+                  (level, n, p, cin, cout, tile or be.tile_rows(cin, cout, entry.fwd, 0 if half is None else be._HALF[half]), "".join("+" + o for o in opts), (" " + spec.split()[4]) if half is not None else "", us,
                    2.0 * p * cin * cout / us / 1e6, err), flush=True)
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Launch order of the fused convolution's row tiles vs the XCD a workgroup lands on (workgroup id % 8), on the bench's own maps
-(level 0 in the order the input pipeline delivers: ascending ravel hash per frame = lexicographic; deeper levels in spdownsample's
-order). Orders: rows (tile = workgroup id), heavy (heaviest first, the product's choice on dense levels), xcd (every XCD walks a
+(deeper levels in spdownsample's coordinate order, as in the network; level 0 in coordinate order by default -- inside the network
+the stride-1 voxels are in ascending-hash order, initial_voxelize: PCS_AB_SORT0=hash). Orders: rows (tile = workgroup id), heavy (heaviest first, the product's choice on dense levels), xcd (every XCD walks a
 contiguous eighth of the row order), xcdheavy (contiguous eighths, heaviest first inside each).
 Usage: python tools/conv_xcd_order_ab.py "<level> <cin> <cout> [bf16]" ...   PCS_AB_SORT0=hash puts level 0 in hash order."""
 import os
