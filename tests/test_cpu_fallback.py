@@ -131,3 +131,27 @@ def test_refuses_device_tensors(be):
     x = torch.zeros(2, 4, dtype=torch.int32).as_subclass(FakeCuda)
     with pytest.raises(RuntimeError, match="CPU tensor"):
         be.hash(x)
+
+
+def test_prebuild_coords_matches_the_lazy_levels(golden, be):
+    """functional.prebuild_coords (host logic, device-independent): the levels it leaves in cmaps are the ones the strided
+    convolutions compute themselves -- both spdownsample branches, anisotropic strides, levels already present are kept."""
+    coords = t(golden["scene_coords"])
+    steps = [(2, 2), ((2, 2, 1), 3), (2, 2)]
+    ws = [torch.zeros(8, 4, 4), torch.zeros(27, 4, 4), torch.zeros(8, 4, 4)]
+
+    def run(prebuild):
+        x = SparseTensor(torch.zeros(coords.shape[0], 4), coords, 1)
+        if prebuild:
+            F.prebuild_coords(x, steps)
+            assert sorted(x.cmaps) == [(2, 2, 2), (4, 4, 2), (8, 8, 4)]
+            marker = x.cmaps[(2, 2, 2)]
+            F.prebuild_coords(x, steps[:1])
+            assert x.cmaps[(2, 2, 2)] is marker
+        for w, (s, k) in zip(ws, steps):
+            x = F.conv3d(x, w, k, stride=s)
+        return x
+
+    a, b = run(False), run(True)
+    assert sorted(a.cmaps) == sorted(b.cmaps) and all(torch.equal(a.cmaps[k], b.cmaps[k]) for k in a.cmaps)
+    assert (a.cmaps[(2, 2, 2)].numpy() == golden["ds_k2s2"]).all()
