@@ -566,6 +566,16 @@ int64_t pcs_lovasz_workspace_bytes(int64_t n, int32_t num_class, int32_t has_ign
 int pcs_lovasz_softmax_f32(const float *probas, const int64_t *labels, int64_t n, int32_t num_class, int32_t has_ignore,
                            int64_t ignore, float *loss, float *grad, void *ws, int64_t ws_bytes, void *stream);
 
+/* ---- measurement switches (NOT part of the drop-in contract: no reference function stands behind them; results never depend on
+ * them; used by tools/convh_ws_ab.py and tools/wgrad_interleave_ab.py to A/B two kernel policies inside one process) -------------
+ * pcs_debug_convh_ws: mode -1 = environment (PCS_CONVH_WS, default on), 0 = the 16-bit convolution on conv_os5h only, 1 = the
+ *   weight-stationary kernel where the policy picks it, >= 2 = wherever an instance exists; `ru` unused; rs = 1: two-row-block
+ *   sub-groups on the two shapes that have both instances.
+ * pcs_debug_wgrad_interleave: launch order of the weight-gradient splits, -1 = default (2 for 16-bit operands, 0 for fp32),
+ *   0 offset-major, 1 position-major, 2 position-major with every XCD on a contiguous eighth. */
+void pcs_debug_convh_ws(int32_t mode, int32_t ru, int32_t rs);
+void pcs_debug_wgrad_interleave(int32_t mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,8 @@ SIGNATURES = {
     "pcs_weights_multi": (c_int32, [_P, c_int32, c_int64, _P]),
     "pcs_lovasz_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32, c_int64]),
     "pcs_lovasz_softmax_f32": (c_int32, [_P, _P, c_int64, c_int32, c_int32, c_int64, _P, _P, _P, c_int64, _P]),
+    "pcs_debug_convh_ws": (None, [c_int32, c_int32, c_int32]),       # measurement switches (A/B tools), not part of the contract
+    "pcs_debug_wgrad_interleave": (None, [c_int32]),
 }
 
 class _WeightJob(ctypes.Structure):   # pcs_weight_job of include/pcseg_hip.h

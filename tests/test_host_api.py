@@ -26,6 +26,12 @@ def test_library_exports_every_declared_symbol():
     lib = native.load_library()  # dlopen works without a GPU
     for name in declared:
         assert hasattr(lib, name), name
+    # and the other way round: nothing named pcs_* leaves the library without a declaration in the header
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH if hasattr(native, "LIB_PATH") else lib._name],
+                          capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (pcs_[a-z0-9_]+)$", syms, re.M))
+    assert exported and exported <= declared, exported - declared
     assert lib.pcs_abi_version() == native.ABI_VERSION == 11
     assert lib.pcs_hashtable_capacity(1000) == 2048
     assert lib.pcs_hashtable_bytes(2048) == 2048 * 12
