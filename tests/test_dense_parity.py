@@ -135,6 +135,20 @@ def test_tile_order_heaviest_first(hip, levels, stride, tile):
         assert (w[:-1] >= w[1:]).all() and (ln == 0 or w[0] == work[lo:lo + ln].max())
 
 
+def test_tile_order_per_xcd_variant():
+    """PCS_TILE_ORDER_XCD=1 (the opt-in order: heaviest first inside each XCD's contiguous eighth) is read once per process: the
+    order property and the order-independence of the convolution results are checked in a subprocess started with it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PCS_TILE_ORDER_XCD="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_dense_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_tile_order_heaviest_first or test_conv_is_independent_of_the_tile_order", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0 and " passed" in p.stdout, (p.stdout + p.stderr)[-1500:]
+
+
 @pytest.mark.parametrize("stride,cin,cout,tile", [(4, 128, 128, None), (8, 256, 256, None), (1, 96, 96, 384), (2, 64, 64, 128)])
 def test_conv_is_independent_of_the_tile_order(hip, levels, stride, cin, cout, tile):
     """The tile order only decides which workgroup slot runs which tile: outputs and the BatchNorm partial sums are
