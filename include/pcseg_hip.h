@@ -87,8 +87,16 @@ int pcs_count(const int32_t *idx, int64_t n, int32_t *out, int64_t s, void *stre
  */
 int pcs_voxelize_fwd_f32(const float *feats, const int32_t *idx, const int32_t *counts,
                          int64_t n, int64_t m, int32_t c, float *out, void *stream);
-/* contention-free forward: order (n_in_voxels) int64 = point rows sorted by voxel (points with idx < 0 first, skipped
- * by rowptr[0]), rowptr (m+1) int64; every out row written once, deterministic summation order */
+/* The CSR the contention-free forms below run over [v11]: index (n,) int32 = target row of every entry (a voxel per point for
+ * K7, a voxel per (point, corner) for K10; < 0 or >= m = no row) -> order (n,) int64 = entry positions sorted by target row,
+ * equal rows in ascending position (stable: the summation order of every output row is fixed), entries without a row behind
+ * the last row; rowptr (m+1,) int64 = start of each row's run. One radix sort over the bits a row index needs + one binary
+ * search per row. ws / ws_bytes from pcs_index_csr_ws_bytes(n, m) (0 on bad sizes); never allocates. */
+size_t pcs_index_csr_ws_bytes(int64_t n, int64_t m);
+int pcs_index_csr_i32(const int32_t *index, int64_t n, int64_t m, int64_t *order, int64_t *rowptr, void *ws,
+                      size_t ws_bytes, void *stream);
+/* contention-free forward: order int64 = point rows sorted by voxel (points with idx < 0 outside [rowptr[0], rowptr[m])),
+ * rowptr (m+1) int64; every out row written once, deterministic summation order */
 int pcs_voxelize_fwd_csr_f32(const float *feats, const int64_t *order, const int64_t *rowptr,
                              const int32_t *counts, int64_t m, int32_t c, float *out, void *stream);
 int pcs_voxelize_bwd_f32(const float *gout, const int32_t *idx, const int32_t *counts,

@@ -36,6 +36,8 @@ SIGNATURES = {
     "pcs_ti_weights_f32": (c_int32, [_P, c_int32, _P, c_int64, c_float, _P, _P]),
     "pcs_downsample_pack": (c_int32, [_P, c_int64, _P, c_int32, _P, c_int32, _P, _P, _P, _P]),
     "pcs_downsample_unpack": (c_int32, [_P, c_int64, _P, _P]),
+    "pcs_index_csr_ws_bytes": (c_size_t, [c_int64, c_int64]),
+    "pcs_index_csr_i32": (c_int32, [_P, c_int64, c_int64, _P, _P, _P, c_size_t, _P]),
     "pcs_sort_unique_ws_bytes": (c_size_t, [c_int64]),
     "pcs_sort_unique_i64": (c_int32, [_P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "pcs_rulebook_ws_bytes": (c_size_t, [c_int64, c_int32]),
@@ -124,7 +126,7 @@ class _WeightJob(ctypes.Structure):   # pcs_weight_job of include/pcseg_hip.h
                 ("transpose", c_int32), ("nctt", c_int32), ("nt16", c_int32), ("ns", c_int32), ("first_block", c_int64)]
 
 
-ABI_VERSION = 11  # include/pcseg_hip.h PCS_ABI_VERSION (11: pcs_sort_unique_i64; 10: pcs_conv_gather_gemm_*_ex + pcs_conv_epilogue, pcs_bn_bwd_reduce_partials; 9: pcs_quantize_frame_keys; 8: sums2 size argument of pcs_bn_bwd_stats_*, ring switch removed; 7: pcs_lovasz_*; 6: ring kernel switch / query; 5: fp32 convolution on the bf16 MFMAs, pcs_conv_*_x3; 4: tile order)
+ABI_VERSION = 11  # include/pcseg_hip.h PCS_ABI_VERSION (11: pcs_sort_unique_i64, pcs_index_csr_i32; 10: pcs_conv_gather_gemm_*_ex + pcs_conv_epilogue, pcs_bn_bwd_reduce_partials; 9: pcs_quantize_frame_keys; 8: sums2 size argument of pcs_bn_bwd_stats_*, ring switch removed; 7: pcs_lovasz_*; 6: ring kernel switch / query; 5: fp32 convolution on the bf16 MFMAs, pcs_conv_*_x3; 4: tile order)
 _lib = None
 
 
@@ -889,9 +891,21 @@ class HipBackend:
 
 
     # -- cylinder / range scatter ---------------------------------------------------------------
-    @staticmethod
-    def _csr(index, m):
-        vals, order = torch.sort(index.reshape(-1))
+    def _csr(self, index, m):
+        """(order, rowptr) of a scatter index: entries sorted by target row (stable), row starts. int32 device indices
+        (voxelize, devoxelize) through pcs_index_csr_i32 -- a radix sort over the bits of m only; other dtypes through torch."""
+        flat = index.reshape(-1)
+        if flat.is_cuda and flat.dtype == torch.int32 and os.environ.get("PCS_INDEX_CSR", "1") != "0":
+            flat = flat if flat.is_contiguous() else flat.contiguous()
+            n = flat.numel()
+            order = torch.empty(n, dtype=torch.int64, device=flat.device)
+            rowptr = torch.empty(m + 1, dtype=torch.int64, device=flat.device)
+            ws_bytes = self.lib.pcs_index_csr_ws_bytes(n, m)
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=flat.device)
+            _check(self.lib.pcs_index_csr_i32(_ptr(flat), n, m, _ptr(order), _ptr(rowptr), _ptr(ws), ws_bytes, _stream()),
+                   "pcs_index_csr_i32")
+            return order, rowptr
+        vals, order = torch.sort(flat)
         rowptr = torch.searchsorted(vals, torch.arange(m + 1, device=index.device, dtype=vals.dtype))
         return order.contiguous(), rowptr.contiguous()
 

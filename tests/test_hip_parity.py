@@ -139,6 +139,25 @@ def test_downsample_random(hip):
         assert (F.spdownsample(t(cc), *args).cpu().numpy() == orc.spdownsample(cc, *args)).all()
 
 
+@pytest.mark.parametrize("n,m", [(0, 5), (1, 1), (1000, 1), (4096, 65535), (4097, 65536), (300000, 36068), (3000000, 1158864)])
+def test_index_csr(hip, n, m):
+    """pcs_index_csr_i32: entries sorted by target row, equal rows in ascending position (what a stable sort gives), entries
+    without a row (negative or >= m) outside [rowptr[0], rowptr[m]); row counts at the power-of-two edges of the key width."""
+    rng = np.random.default_rng(n + m)
+    idx = rng.integers(-1, m, size=n, dtype=np.int64).astype(np.int32)
+    if n > 10:
+        idx[rng.integers(0, n, size=5)] = m + 3          # beyond the last row: no row
+        idx[rng.integers(0, n, size=5)] = m - 1          # the last row is used
+    order, rowptr = hip._csr(t(idx), m)
+    order, rowptr = order.cpu().numpy(), rowptr.cpu().numpy()
+    assert rowptr.shape == (m + 1,) and order.shape == (n,) and np.array_equal(np.sort(order), np.arange(n))
+    valid = (idx >= 0) & (idx < m)
+    counts = np.bincount(idx[valid], minlength=m)
+    assert rowptr[0] == 0 and np.array_equal(np.diff(rowptr), counts) and rowptr[m] == valid.sum()
+    ref = np.argsort(np.where(valid, idx, m), kind="stable")
+    assert np.array_equal(order[:rowptr[m]], ref[:rowptr[m]])
+
+
 def test_prebuild_coords_are_the_lazy_ones(hip):
     """functional.prebuild_coords leaves in cmaps exactly what the strided convolutions would compute themselves (both
     spdownsample branches: k2 s2 fast, k3 s2 general), so a network runs bit-identically with its levels built up front."""
