@@ -155,3 +155,39 @@ def test_prebuild_coords_matches_the_lazy_levels(golden, be):
     a, b = run(False), run(True)
     assert sorted(a.cmaps) == sorted(b.cmaps) and all(torch.equal(a.cmaps[k], b.cmaps[k]) for k in a.cmaps)
     assert (a.cmaps[(2, 2, 2)].numpy() == golden["ds_k2s2"]).all()
+
+
+def test_prebuild_encoder_reads_the_models_own_stage_convolutions(golden, be):
+    """block_fusion._prebuild_encoder (host logic): the plan comes from the FIRST Conv3d of stage1..stage4 -- its own stride and
+    kernel size --, any other layout (a stage that does not open with a strided, non-transposed convolution, a missing stage)
+    prebuilds nothing, and PCS_PREBUILD_LEVELS=0 switches it off."""
+    import os
+    from torch import nn
+    from openpcseg_amd import block_fusion as bf
+    from openpcseg_amd.modules import Conv3d
+
+    def model(specs):
+        m = nn.Module()
+        for i, (k, s, tr) in enumerate(specs):
+            setattr(m, "stage%d" % (i + 1), nn.Sequential(nn.Sequential(Conv3d(4, 4, kernel_size=k, stride=s, transposed=tr)), nn.Identity()))
+        return m
+
+    coords = t(golden["scene_coords"])
+    x = SparseTensor(torch.zeros(coords.shape[0], 4), coords, 1)
+    good = model([(2, 2, False), (3, 2, False), (2, 2, False), (2, (2, 2, 1), False)])
+    bf._prebuild_encoder(good, x)
+    assert good.__dict__["_pcs_enc_steps"] == [((2, 2, 2), (2, 2, 2)), ((2, 2, 2), (3, 3, 3)), ((2, 2, 2), (2, 2, 2)), ((2, 2, 1), (2, 2, 2))]
+    assert sorted(x.cmaps) == [(2, 2, 2), (4, 4, 4), (8, 8, 8), (16, 16, 8)]
+    assert (x.cmaps[(2, 2, 2)].numpy() == golden["ds_k2s2"]).all()
+    for bad in (model([(2, 2, False), (3, 1, False), (2, 2, False), (2, 2, False)]), model([(2, 2, False), (2, 2, True), (2, 2, False), (2, 2, False)]),
+                model([(2, 2, False)] * 3)):
+        y = SparseTensor(torch.zeros(coords.shape[0], 4), coords, 1)
+        bf._prebuild_encoder(bad, y)
+        assert bad.__dict__["_pcs_enc_steps"] == [] and not y.cmaps
+    os.environ["PCS_PREBUILD_LEVELS"] = "0"
+    try:
+        z = SparseTensor(torch.zeros(coords.shape[0], 4), coords, 1)
+        bf._prebuild_encoder(good, z)
+        assert not z.cmaps
+    finally:
+        del os.environ["PCS_PREBUILD_LEVELS"]
