@@ -4,8 +4,6 @@ kernels (section 8 f1). Same signatures and ordering contract as
   sparse_quantize / ravel_hash   TS:torchsparse/utils/quantize.py:9-46
   sparse_collate(_fn)            TS:torchsparse/utils/collate.py:11-59
 """
-from itertools import repeat
-
 import numpy as np
 import torch
 
@@ -15,37 +13,54 @@ __all__ = ["ravel_hash", "sparse_quantize", "sparse_quantize_frames", "sparse_co
 
 
 def ravel_hash(x):
-    """Row-major linear index of integer coords inside their bounding box (uint64)."""
-    assert x.ndim == 2, x.shape
-    x = (x - x.min(axis=0)).astype(np.uint64, copy=False)
-    extent = x.max(axis=0).astype(np.uint64) + 1
-    h = np.zeros(x.shape[0], dtype=np.uint64)
-    for d in range(x.shape[1] - 1):
-        h += x[:, d]
-        h *= extent[d + 1]
-    h += x[:, -1]
-    return h
+    """Row-major linear index of integer coordinate rows inside their own bounding box, uint64: the sort key whose ascending
+    order is the output order of `sparse_quantize` (TS:torchsparse/utils/quantize.py:12-21 defines that order)."""
+    x = np.asarray(x)
+    if x.ndim != 2:
+        raise AssertionError(x.shape)
+    if x.shape[0] == 0:
+        return np.zeros(0, dtype=np.uint64)
+    rel = x.astype(np.int64) - x.min(axis=0).astype(np.int64)
+    extent = rel.max(axis=0) + 1
+    if float(np.prod(extent.astype(np.float64))) < 2.0 ** 62:   # the usual case: one vectorised mixed-radix evaluation
+        return np.ravel_multi_index(tuple(rel.T), tuple(int(e) for e in extent)).astype(np.uint64)
+    key = rel[:, 0].astype(np.uint64)                            # huge boxes: the same index modulo 2^64
+    for d in range(1, x.shape[1]):
+        key = key * np.uint64(extent[d]) + rel[:, d].astype(np.uint64)
+    return key
+
+
+def _first_of_each_run(key):
+    """One stable sort of the keys -> (rows of the FIRST occurrence of every distinct key, in ascending key order;
+    for every row the rank of its key). The same three steps the device path runs (sort, run flags, scan:
+    csrc/quantize.hip), instead of np.unique's bookkeeping."""
+    n = key.shape[0]
+    order = np.argsort(key, kind="stable")
+    sk = key[order]
+    starts = np.ones(n, dtype=bool)
+    starts[1:] = sk[1:] != sk[:-1]
+    rank = np.cumsum(starts) - 1
+    inverse = np.empty(n, dtype=np.int64)
+    inverse[order] = rank
+    return order[starts], inverse
 
 
 def sparse_quantize(coords, voxel_size=1, *, return_index=False, return_inverse=False):
-    """floor(coords / voxel_size) -> unique voxels, one representative (first occurrence) per
-    voxel, output ordered by ascending ravel hash."""
+    """floor(coords / voxel_size) -> the distinct voxels, each represented by its first row, ordered by ascending ravel hash
+    (same signature, outputs and order as TS:torchsparse/utils/quantize.py:24-46)."""
     if isinstance(voxel_size, (float, int)):
-        voxel_size = tuple(repeat(voxel_size, 3))
-    assert isinstance(voxel_size, tuple) and len(voxel_size) == 3
+        voxel_size = (voxel_size,) * 3
+    if not (isinstance(voxel_size, tuple) and len(voxel_size) == 3):
+        raise AssertionError(voxel_size)
     if isinstance(coords, torch.Tensor):  # device tensor in -> device tensors out (no CPU path for tensors)
         from . import native
         vox, index, inverse = native.backend().quantize(coords, voxel_size, return_index, return_inverse)
-        outputs = [vox] + ([index] if return_index else []) + ([inverse] if return_inverse else [])
-        return outputs[0] if len(outputs) == 1 else outputs
-    coords = np.floor(coords / np.array(voxel_size)).astype(np.int32)
-    _, indices, inverse = np.unique(ravel_hash(coords), return_index=True, return_inverse=True)
-    outputs = [coords[indices]]
-    if return_index:
-        outputs.append(indices)
-    if return_inverse:
-        outputs.append(inverse)
-    return outputs[0] if len(outputs) == 1 else outputs
+    else:
+        cells = np.floor(coords / np.array(voxel_size)).astype(np.int32)
+        index, inverse = _first_of_each_run(ravel_hash(cells))
+        vox = cells[index]
+    extras = ([index] if return_index else []) + ([inverse] if return_inverse else [])
+    return [vox] + extras if extras else vox
 
 
 def sparse_quantize_frames(coords, frames, num_frames):
@@ -78,37 +93,51 @@ def sparse_quantize_frames(coords, frames, num_frames):
 
 
 def sparse_collate(inputs):
-    """Concatenate SparseTensors along N, appending the batch index as the 4th coord column."""
+    """Samples -> one SparseTensor: rows concatenated in sample order, the sample number as a 4th coordinate column
+    (TS:torchsparse/utils/collate.py:11-32). Both outputs are allocated once and filled slice by slice."""
     stride = inputs[0].stride
-    coords, feats = [], []
-    for b, x in enumerate(inputs):
+    rows = []
+    for x in inputs:
         if isinstance(x.coords, np.ndarray):
             x.coords = torch.tensor(x.coords)
         if isinstance(x.feats, np.ndarray):
             x.feats = torch.tensor(x.feats)
-        assert isinstance(x.coords, torch.Tensor), type(x.coords)
-        assert isinstance(x.feats, torch.Tensor), type(x.feats)
-        assert x.stride == stride, (x.stride, stride)
-        col = torch.full((x.coords.shape[0], 1), b, device=x.coords.device, dtype=torch.int)
-        coords.append(torch.cat((x.coords, col), dim=1))
-        feats.append(x.feats)
-    return SparseTensor(coords=torch.cat(coords, dim=0), feats=torch.cat(feats, dim=0), stride=stride)
+        if not (isinstance(x.coords, torch.Tensor) and isinstance(x.feats, torch.Tensor)):
+            raise AssertionError((type(x.coords), type(x.feats)))
+        if x.stride != stride:
+            raise AssertionError((x.stride, stride))
+        rows.append(int(x.coords.shape[0]))
+    first = inputs[0]
+    total = sum(rows)
+    width = first.coords.shape[1]
+    coords = torch.empty((total, width + 1), dtype=torch.result_type(first.coords, torch.tensor(0, dtype=torch.int)),
+                         device=first.coords.device)
+    feats = torch.empty((total,) + tuple(first.feats.shape[1:]), dtype=first.feats.dtype, device=first.feats.device)
+    lo = 0
+    for b, (x, n) in enumerate(zip(inputs, rows)):
+        coords[lo:lo + n, :width] = x.coords
+        coords[lo:lo + n, width] = b
+        feats[lo:lo + n] = x.feats
+        lo += n
+    return SparseTensor(coords=coords, feats=feats, stride=stride)
 
 
 def sparse_collate_fn(inputs):
+    """The dataloader's collate: a list of per-sample dicts -> one dict, by the type of each entry (SparseTensor: batched with a
+    batch column; arrays / tensors: stacked; dicts: recursively; anything else: the list). TS:torchsparse/utils/collate.py:35-59."""
     if not isinstance(inputs[0], dict):
         return inputs
-    out = {}
-    for name, first in inputs[0].items():
-        column = [sample[name] for sample in inputs]
-        if isinstance(first, dict):
-            out[name] = sparse_collate_fn(column)
-        elif isinstance(first, np.ndarray):
-            out[name] = torch.stack([torch.tensor(v) for v in column], dim=0)
-        elif isinstance(first, torch.Tensor):
-            out[name] = torch.stack(column, dim=0)
-        elif isinstance(first, SparseTensor):
-            out[name] = sparse_collate(column)
-        else:
-            out[name] = column
-    return out
+
+    def merge(values):
+        head = values[0]
+        if isinstance(head, SparseTensor):
+            return sparse_collate(values)
+        if isinstance(head, dict):
+            return sparse_collate_fn(values)
+        if isinstance(head, np.ndarray):
+            return torch.stack([torch.tensor(v) for v in values], dim=0)
+        if isinstance(head, torch.Tensor):
+            return torch.stack(values, dim=0)
+        return values
+
+    return {name: merge([sample[name] for sample in inputs]) for name in inputs[0]}

@@ -136,6 +136,31 @@ def test_sparse_quantize_matches_reference(golden):
     assert out["lidar"].C.tolist() == [[0, 0, 0, 0], [1, 1, 1, 0], [2, 2, 2, 1]] and out["n"] == [1, 2]
 
 
+def test_sparse_quantize_host_path_properties():
+    """The NumPy path is a stable sort + run flags (like the device path), not np.unique: same outputs as np.unique over the
+    ravel hash -- first occurrence, ascending hash order, inverse -- on random clouds with many duplicates, anisotropic voxel
+    sizes, negative coordinates, one row and no rows; ravel_hash itself against the mixed-radix definition."""
+    rng = np.random.default_rng(7)
+    for n, vs in [(0, 1), (1, 0.5), (7, (0.5, 0.25, 1.0)), (5000, 0.37), (5000, (2, 3, 1))]:
+        pts = rng.integers(-40, 40, size=(n, 3)).astype(np.float64) * 0.21
+        vox, idx, inv = hostdata.sparse_quantize(pts, vs, return_index=True, return_inverse=True)
+        cells = np.floor(pts / np.array(vs if isinstance(vs, tuple) else (vs,) * 3)).astype(np.int32)
+        if n == 0:
+            assert vox.shape == (0, 3) and idx.shape == (0,) and inv.shape == (0,)
+            continue
+        rel = (cells - cells.min(0)).astype(np.uint64)
+        ext = rel.max(0) + np.uint64(1)
+        h = (rel[:, 0] * ext[1] + rel[:, 1]) * ext[2] + rel[:, 2]
+        assert (hostdata.ravel_hash(cells) == h).all()
+        _, i2, v2 = np.unique(h, return_index=True, return_inverse=True)
+        assert (idx == i2).all() and (inv == v2).all() and (vox == cells[i2]).all()
+        assert (vox[inv] == cells).all()
+        only = hostdata.sparse_quantize(pts, vs)
+        assert isinstance(only, np.ndarray) and (only == vox).all()
+    mixed = hostdata.sparse_collate([SparseTensor(torch.zeros(2, 3), torch.zeros(2, 3)), SparseTensor(torch.ones(1, 3), torch.ones(1, 3))])
+    assert mixed.C.dtype == torch.float32 and mixed.C[:, 3].tolist() == [0.0, 0.0, 1.0] and mixed.F.shape == (3, 3)
+
+
 def test_sparse_quantize_tensor_input_goes_to_the_backend(oracle_backend):
     """torch tensor in -> tensors out through backend().quantize (HIP in the product; the oracle here)."""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "quantize_golden.npz"))
